@@ -1,0 +1,253 @@
+/*
+ * mipgen_accel.h — C-ABI drop-in boundary for the candidate-MIP enumeration + scoring hot path of MIPgen,
+ * implemented as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (shendurelab/MIPGEN, C++03, single-threaded) has no FFI; the seam this library sits behind
+ * is the body of mipgen::tile_regions' innermost loop and the mixed-mode re-scores
+ * (file:line citations are into /root/reference):
+ *
+ *   reference call site / callee                                   replaced by
+ *   -------------------------------------------------------------  -------------------------------------------
+ *   mipgen.cpp:446-497  new Plus/MinusSVMipv4 + design_mip()        mipgen_accel_score_regions()  (dense grid)
+ *                       + get_score() | get_parameters()+predict_value()
+ *   mipgen.cpp:599-762  design_mip(Featurev5*, shared_ptr<SVMipv4>)  (same call; copies / masked / flags / SNP ints)
+ *   SVMipv4.h:60        double SVMipv4::get_score()                  MIPGEN_SCORE_LOGISTIC
+ *   SVMipv4.h:59        void SVMipv4::get_parameters(vector<double>&, double[])   mipgen_accel_score_candidates(.., features_out)
+ *   mipgen.cpp:1948     double predict_value(vector<double>&, svm_model*)         MIPGEN_SCORE_SVR
+ *   svm.h:78            svm_model* svm_load_model(const char*)      mipgen_accel_load_model_file()
+ *   svm.h:88            double svm_predict(const svm_model*, const svm_node*)     (inside the SVR kernels)
+ *   Featurev5.h:25      void Featurev5::get_long_range_content(string, string[])  mipgen_accel_long_range_content()
+ *   mipgen.cpp:1525-1526,1535-1536,1548-1549,1875-1876  mixed-mode re-score        mipgen_accel_score_candidates()
+ *   mipgen.cpp:426-437,494-497  score-dependent early exits (replay)               mipgen_accel_replay_condense()
+ *   mipgen.cpp:1670-1746 condense_mips                                             mipgen_accel_replay_condense()
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary.
+ *   - every entry point returns 0 on success, a negative MIPGEN_E_* code otherwise;
+ *     mipgen_accel_last_error() returns a human-readable message for the calling thread's last failure.
+ *     (reference: C++ `throw <int>` caught in main → exit 1, mipgen.cpp:2029-2035; svm_load_model → NULL, svm.cpp:2762.)
+ *   - a handle is single-owner and not thread-safe (the reference is not re-entrant either: SURVEY.md section 5);
+ *     one handle per GPU.  The library owns device buffers and the densified model; the caller owns every
+ *     host array it passes in or receives results into.  Nothing is transferred across the boundary.
+ *   - there is NO CPU fallback: if no HIP device is usable every call fails with MIPGEN_E_NODEVICE.
+ *   - coordinates are 1-based inclusive chromosome positions, as in the reference.
+ */
+#ifndef MIPGEN_ACCEL_H
+#define MIPGEN_ACCEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPGEN_ACCEL_ABI_VERSION 1
+
+#define MIPGEN_MAX_ARM_PAIRS 256     /* flattened (ext,lig) list, enumeration order */
+#define MIPGEN_N_FEATURES 192        /* SVMipv4.cpp:14 TOTAL_FEATURES */
+#define MIPGEN_N_LRC 44              /* Featurev5.h:4 MER_NUM */
+#define MIPGEN_MIN_OLIGO 1
+#define MIPGEN_MAX_OLIGO 64          /* arm lengths accepted by this library (reference default 16..30) */
+
+/* error codes */
+#define MIPGEN_OK 0
+#define MIPGEN_E_INVALID (-1)        /* bad argument / inconsistent sizes */
+#define MIPGEN_E_NODEVICE (-2)       /* no usable HIP device: this library has no CPU path */
+#define MIPGEN_E_HIP (-3)            /* a HIP runtime call or kernel failed */
+#define MIPGEN_E_MODEL (-4)          /* libsvm model missing / unparsable / unsupported kernel type */
+#define MIPGEN_E_NOMEM (-5)
+#define MIPGEN_E_STATE (-6)          /* call sequence error (e.g. scoring before regions are resident) */
+
+/* score_method (mipgen.cpp:182,217; "-score_method") */
+#define MIPGEN_SCORE_LOGISTIC 0
+#define MIPGEN_SCORE_SVR 1
+#define MIPGEN_SCORE_MIXED 2         /* logistic during enumeration, SVR on picked/tested MIPs */
+
+/*
+ * Run-wide parameters, parsed once on the host (the reference re-reads map<string,string> args inside the
+ * hot loop: mipgen.cpp:467,469,476,494,619,626).
+ */
+typedef struct mipgen_params {
+    int32_t abi_version;             /* MIPGEN_ACCEL_ABI_VERSION */
+    int32_t score_method;            /* MIPGEN_SCORE_* */
+    int32_t min_capture_size;        /* -min_capture_size  (mipgen.cpp:272) */
+    int32_t max_capture_size;        /* -max_capture_size  (mipgen.cpp:271) */
+    int32_t capture_increment;       /* -capture_increment (mipgen.cpp:273-274; 0 is coerced to 1) */
+    int32_t max_mip_overlap;         /* -max_mip_overlap   (static size skip, mipgen.cpp:429) */
+    /* flattened arm-length pairs in enumeration order: arm sum descending, then list order within the sum
+     * (mipgen.cpp:431-442; lists built at :222-261).  arm_sum_of[i] = arm_ext[i] + arm_lig[i]. */
+    int32_t n_arm_pairs;
+    int32_t arm_ext[MIPGEN_MAX_ARM_PAIRS];
+    int32_t arm_lig[MIPGEN_MAX_ARM_PAIRS];
+    int32_t check_copy_number;       /* 0 iff "-check_copy_number off" (mipgen.cpp:619) */
+    int32_t logistic_heuristic;      /* 0 iff "-logistic_heuristic off" (mipgen.cpp:494) */
+    double masked_arm_threshold;     /* -masked_arm_threshold (mipgen.cpp:626) */
+    /* enumeration / condense thresholds in force while scanning (mipgen.cpp:264-265):
+     * logistic and mixed use the logistic pair, svr the svr pair. */
+    double upper_score_limit;
+    double lower_score_limit;
+    int32_t max_arm_copy_product;    /* -max_arm_copy_product (mipgen.cpp:197) */
+    int32_t target_arm_copy;         /* -target_arm_copy (mipgen.cpp:198) */
+    int32_t reserved[6];
+} mipgen_params;
+
+/*
+ * One merged BED interval +/- flank: the hot-path view of Featurev5 (Featurev5.h:7-28) plus the per-region
+ * slices of the global lookup tables design_mip consults (mipgen.cpp:612-618,634-760).
+ * All per-base arrays cover [seq_start, seq_stop] (index = position - seq_start), length seq_len.
+ */
+typedef struct mipgen_region {
+    int32_t start_flanked;           /* Featurev5::start_position_flanked */
+    int32_t stop_flanked;            /* Featurev5::stop_position_flanked */
+    int32_t seq_start;               /* Featurev5::chromosomal_sequence_start_position */
+    int32_t seq_stop;                /* Featurev5::chromosomal_sequence_stop_position */
+    int32_t seq_len;                 /* strlen(seq); normally seq_stop - seq_start + 1 */
+    int32_t reserved0;
+    const char* seq;                 /* Featurev5::chromosomal_sequence (upper case) */
+    const char* masked_seq;          /* Featurev5::masked_chromosomal_sequence, or NULL = same as seq */
+    /* copy_chr_start_stop[chr][start][start+len-1] for oligo length len (mipgen.cpp:612-613):
+     * copy[len] points to int32[seq_len] indexed by (start - seq_start); absent keys are 0, as
+     * std::map::operator[] yields.  copy[len] may be NULL for lengths no arm pair uses, and the whole
+     * pointer table may be NULL = "every oligo has copy 1". */
+    const int32_t* const* copy;      /* table of MIPGEN_MAX_OLIGO+1 pointers, indexed by oligo length */
+    /* unmappable_positions[capture_size][chr] (mipgen.cpp:615-618): byte [k * seq_len + (pos - seq_start)] != 0
+     * iff a MIP of capture size (max_capture_size - k*capture_increment) starting at pos is ambiguous.
+     * NULL = none. */
+    const uint8_t* unmappable;
+    /* chr_snp_positions[chr] restricted to the region (mipgen.cpp:634-760): per base 0 = no SNP,
+     * 1 = SNP for which an alternate-allele arm can be generated, 2 = SNP for which it cannot.  NULL = none. */
+    const uint8_t* snp_class;
+    double long_range_content[MIPGEN_N_LRC];   /* Featurev5::long_range_content (features 22..65) */
+} mipgen_region;
+
+/* Geometry of a region's dense candidate grid, as laid out in the result arrays. */
+typedef struct mipgen_grid {
+    int64_t offset;                  /* index of the region's first candidate in the batch-wide result arrays */
+    int64_t count;                   /* n_pos * n_sizes * n_arm_pairs * 2 */
+    int32_t first_pos;               /* first scan-start position p (mipgen.cpp:421-425) */
+    int32_t n_pos;                   /* positions p = first_pos .. stop_flanked */
+    int32_t first_size_index;        /* k0: capture sizes with k < k0 are removed by the static skip (mipgen.cpp:429) */
+    int32_t n_sizes;                 /* surviving sizes C = max_capture - k*inc, k = k0 .. k0+n_sizes-1 */
+} mipgen_grid;
+
+/*
+ * Dense-grid candidate index within a region:
+ *     idx = (((p - first_pos) * n_sizes + (k - k0)) * n_arm_pairs + a) * 2 + strand        strand 0 = '+', 1 = '-'
+ * i.e. exactly the reference's generation order (p asc, C desc, arm sum desc, ext asc, plus then minus).
+ *
+ * Integer record per candidate (uint64), the fields design_mip() produces:
+ */
+#define MIPGEN_REC_EXT_COPY(r)   ((uint32_t)((r) & 0xFFFFu))            /* ext_probe_copy, saturated at 65535 */
+#define MIPGEN_REC_LIG_COPY(r)   ((uint32_t)(((r) >> 16) & 0xFFFFu))    /* lig_probe_copy, saturated at 65535 */
+#define MIPGEN_REC_MASKED_N(r)   ((uint32_t)(((r) >> 32) & 0xFFu))      /* #N in masked ext + masked lig (mipgen.cpp:606-610) */
+#define MIPGEN_REC_SNP_COUNT(r)  ((uint32_t)(((r) >> 40) & 0xFFu))      /* snp_count, saturated at 255 */
+#define MIPGEN_REC_FLAGS(r)      ((uint32_t)(((r) >> 48) & 0xFFu))
+#define MIPGEN_REC_JUNCTION(r)   ((uint32_t)(((r) >> 56) & 0xFFu))      /* 4*code(lj[0])+code(lj[1]), A<C<G<T; 255 if not ACGT */
+#define MIPGEN_FLAG_VALID        0x01u   /* passes the bounds skips of mipgen.cpp:443-444 (a candidate the reference could emit) */
+#define MIPGEN_FLAG_GUARD        0x02u   /* N in either arm or '-' in mip_seq: score -1000 / all-zero vector (SVMipv4.cpp:63,116) */
+#define MIPGEN_FLAG_MAPPING      0x04u   /* mapping_failed == '1' (mipgen.cpp:615-625) */
+#define MIPGEN_FLAG_MASKING      0x08u   /* masking_failed == '1' (mipgen.cpp:626-633) */
+#define MIPGEN_FLAG_SNP          0x10u   /* snp_failed == '1'     (mipgen.cpp:690-693,753-760) */
+#define MIPGEN_FLAG_HAS_SNP_MIP  0x20u   /* has_snp_mip           (mipgen.cpp:685,747) */
+
+/* A single candidate addressed by coordinates, for sparse (mixed-mode) re-scoring and inspection. */
+typedef struct mipgen_candidate {
+    int32_t region;                  /* index into the resident region batch */
+    int32_t scan_start;              /* p */
+    int32_t capture_size;            /* C */
+    int32_t ext_len;
+    int32_t lig_len;
+    int32_t strand;                  /* 0 '+', 1 '-' */
+} mipgen_candidate;
+
+/* Integer features of one candidate as the two scorers see them (strand-oriented sequences). */
+typedef struct mipgen_candidate_ints {
+    int32_t ext_a, ext_c, ext_g, ext_t;        /* base counts of the extension arm */
+    int32_t lig_a, lig_c, lig_g, lig_t;
+    int32_t ins_a, ins_c, ins_g, ins_t;        /* base counts of the insert (scan target) */
+    int32_t run_count;                         /* GC/AT run counter incl. the final ++ (SVMipv4.cpp:118-142) */
+    int32_t junction;                          /* as MIPGEN_REC_JUNCTION */
+    int32_t ext_copy, lig_copy;                /* unsaturated */
+    int32_t masked_n;
+    int32_t snp_count;
+    int32_t flags;
+    int32_t scan_size;
+} mipgen_candidate_ints;
+
+/* Per (scan-start, strand) survivor of the reference's replay + condense_mips fold (mipgen.cpp:1670-1746). */
+typedef struct mipgen_survivor {
+    int64_t cand_index;              /* dense-grid index within the batch, or -1 if no candidate survived */
+    double score;
+    uint64_t record;
+} mipgen_survivor;
+
+typedef struct mipgen_accel mipgen_accel;   /* opaque */
+
+/* ---- lifecycle ------------------------------------------------------------------------------------ */
+int mipgen_accel_abi_version(void);
+const char* mipgen_accel_last_error(void);
+/* number of usable HIP devices (0 if none); never fails */
+int mipgen_accel_device_count(void);
+/* device: HIP ordinal.  stream: a hipStream_t the caller owns (e.g. torch's current stream) or NULL for a private one. */
+int mipgen_accel_create(const mipgen_params* params, int device, void* stream, mipgen_accel** out);
+void mipgen_accel_destroy(mipgen_accel* h);
+
+/* ---- model (svm.h:78 svm_load_model) -------------------------------------------------------------- */
+/* Parses a libsvm 3.17 text model (grammar svm.cpp:2779-2962).  Only epsilon_svr/nu_svr + rbf are accepted;
+ * anything else, or a missing file, is MIPGEN_E_MODEL (the reference dereferences NULL instead, svm.cpp:2507). */
+int mipgen_accel_load_model_file(mipgen_accel* h, const char* path);
+/* Same from memory: sv is row-major [n_sv][192] (absent libsvm indices = 0), coef[n_sv]. */
+int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double rho, const double* coef, const double* sv);
+int mipgen_accel_model_info(const mipgen_accel* h, int32_t* n_sv, double* gamma, double* rho);
+
+/* ---- region batch: host -> HBM -------------------------------------------------------------------- */
+/* Copies the batch into device memory (sequence bytes, masked bytes, copy tables, SNP / mappability maps,
+ * long-range content) and lays out the dense grids.  grids_out (n entries, caller-allocated) may be NULL.
+ * Replaces any previously resident batch. */
+int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, mipgen_grid* grids_out);
+/* total dense-grid candidates of the resident batch */
+int64_t mipgen_accel_batch_candidates(const mipgen_accel* h);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* Scores the resident batch's dense grid with `method` (MIPGEN_SCORE_LOGISTIC or MIPGEN_SCORE_SVR) into
+ * library-owned device arrays (double scores[], uint64 records[], both batch_candidates long).
+ * Asynchronous on the handle's stream. */
+int mipgen_accel_score_resident(mipgen_accel* h, int32_t method);
+/* device pointers of the result arrays of the last mipgen_accel_score_resident (valid until the next upload) */
+int mipgen_accel_result_device_ptrs(const mipgen_accel* h, void** scores_dev, void** records_dev);
+/* blocks until the stream is idle, then copies results to host arrays (either may be NULL) */
+int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* records, int64_t first, int64_t count);
+/* upload + score + download in one call: the literal replacement for the loop body of mipgen.cpp:446-497 */
+int mipgen_accel_score_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, int32_t method,
+                               mipgen_grid* grids_out, double* scores, uint64_t* records, int64_t capacity);
+
+/* Sparse list against the resident batch (mixed-mode re-scores, mipgen.cpp:1525-1526,1875-1876; inspection).
+ * Any output pointer may be NULL.  features: [n][192] as SVMipv4::get_parameters fills it. */
+int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands, int32_t n, int32_t method,
+                                  double* scores, uint64_t* records, double* features, mipgen_candidate_ints* ints);
+
+/* Featurev5::get_long_range_content on the device: extended_seq covers the region +/- 1000 bases
+ * (mipgen.cpp:1125-1128,1225); denominator = chrom_seq_stop - chrom_seq_start + 2001 (Featurev5.cpp:49,53). */
+int mipgen_accel_long_range_content(mipgen_accel* h, const char* extended_seq, int32_t len,
+                                    int32_t chrom_seq_start, int32_t chrom_seq_stop, double* out44);
+
+/* Replays the reference's score-dependent enumeration control flow (mipgen.cpp:426-437,494-497) over the
+ * scored dense grid on the device and folds condense_mips (mipgen.cpp:1670-1746) per (scan start, strand).
+ * emitted_dev/ survivors are library-owned device arrays; results are fetched with the calls below. */
+int mipgen_accel_replay_condense(mipgen_accel* h);
+/* per-region emitted-candidate counts (int64[n_regions]) and survivors (2 per scan position: '+','-') */
+int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors,
+                                 int64_t survivor_capacity, uint8_t* emitted_mask, int64_t mask_capacity);
+
+/* ---- instrumentation ------------------------------------------------------------------------------ */
+/* HIP-event time (ms) of the dominant kernel of the last mipgen_accel_score_resident call, measured on the
+ * handle's stream; negative if unavailable.  which: 0 = scoring kernel, 1 = all kernels of the call. */
+double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which);
+/* enable/disable per-call event timing (it inserts two hipEventRecord per call) */
+int mipgen_accel_set_timing(mipgen_accel* h, int32_t enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPGEN_ACCEL_H */

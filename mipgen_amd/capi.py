@@ -1,0 +1,425 @@
+"""ctypes binding of the C-ABI in include/mipgen_accel.h (libmipgen_accel.so, hand-written HIP for gfx950).
+
+This is plumbing for tests and bench.py: Python is not the product's host language (the reference is C++,
+and so is the host side under mipgen_amd/host/); everything here maps 1:1 onto the C entry points.
+There is no CPU fallback: if the shared library is missing or no HIP device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmipgen_accel.so")
+
+MAX_ARM_PAIRS = 256
+N_FEATURES = 192
+N_LRC = 44
+MAX_OLIGO = 64
+
+SCORE_LOGISTIC, SCORE_SVR, SCORE_MIXED = 0, 1, 2
+
+FLAG_VALID, FLAG_GUARD, FLAG_MAPPING, FLAG_MASKING, FLAG_SNP, FLAG_HAS_SNP_MIP = 1, 2, 4, 8, 16, 32
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("score_method", C.c_int32),
+        ("min_capture_size", C.c_int32), ("max_capture_size", C.c_int32), ("capture_increment", C.c_int32),
+        ("max_mip_overlap", C.c_int32), ("n_arm_pairs", C.c_int32),
+        ("arm_ext", C.c_int32 * MAX_ARM_PAIRS), ("arm_lig", C.c_int32 * MAX_ARM_PAIRS),
+        ("check_copy_number", C.c_int32), ("logistic_heuristic", C.c_int32),
+        ("masked_arm_threshold", C.c_double), ("upper_score_limit", C.c_double), ("lower_score_limit", C.c_double),
+        ("max_arm_copy_product", C.c_int32), ("target_arm_copy", C.c_int32), ("reserved", C.c_int32 * 6),
+    ]
+
+
+class Region(C.Structure):
+    _fields_ = [
+        ("start_flanked", C.c_int32), ("stop_flanked", C.c_int32), ("seq_start", C.c_int32), ("seq_stop", C.c_int32),
+        ("seq_len", C.c_int32), ("reserved0", C.c_int32),
+        ("seq", C.c_char_p), ("masked_seq", C.c_char_p),
+        ("copy", C.POINTER(C.POINTER(C.c_int32))), ("unmappable", C.POINTER(C.c_uint8)), ("snp_class", C.POINTER(C.c_uint8)),
+        ("long_range_content", C.c_double * N_LRC),
+    ]
+
+
+class Grid(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("first_pos", C.c_int32), ("n_pos", C.c_int32),
+                ("first_size_index", C.c_int32), ("n_sizes", C.c_int32)]
+
+
+class Candidate(C.Structure):
+    _fields_ = [("region", C.c_int32), ("scan_start", C.c_int32), ("capture_size", C.c_int32),
+                ("ext_len", C.c_int32), ("lig_len", C.c_int32), ("strand", C.c_int32)]
+
+
+class CandidateInts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "ext_a", "ext_c", "ext_g", "ext_t", "lig_a", "lig_c", "lig_g", "lig_t", "ins_a", "ins_c", "ins_g", "ins_t",
+        "run_count", "junction", "ext_copy", "lig_copy", "masked_n", "snp_count", "flags", "scan_size")]
+
+
+class Survivor(C.Structure):
+    _fields_ = [("cand_index", C.c_int64), ("score", C.c_double), ("record", C.c_uint64)]
+
+
+SURVIVOR_DTYPE = np.dtype([("cand_index", "<i8"), ("score", "<f8"), ("record", "<u8")])
+INTS_FIELDS = [f[0] for f in CandidateInts._fields_]
+
+
+def make_params(min_capture: int, max_capture: int, score_method: int = SCORE_LOGISTIC, capture_increment: int = 5,
+                max_mip_overlap: int = 30, arm_pairs: Optional[Sequence[Tuple[int, int]]] = None,
+                check_copy_number: bool = True, logistic_heuristic: bool = True, masked_arm_threshold: float = 0.5,
+                logistic_optimal: float = 0.98, logistic_priority: float = 0.9, svr_optimal: float = 2.2,
+                svr_priority: float = 1.5, max_arm_copy_product: int = 75, target_arm_copy: int = 20) -> Params:
+    """Defaults as mipgen::set_default_args / parse_arg_values (/root/reference/mipgen.cpp:164-188,209-216,243,264-265)."""
+    from .synth import arm_pairs_from_sums
+    p = Params()
+    p.abi_version = 1
+    p.score_method = score_method
+    p.min_capture_size, p.max_capture_size = min_capture, max_capture
+    p.capture_increment = capture_increment if capture_increment != 0 else 1
+    p.max_mip_overlap = max_mip_overlap
+    pairs = list(arm_pairs) if arm_pairs is not None else arm_pairs_from_sums()
+    assert len(pairs) <= MAX_ARM_PAIRS
+    p.n_arm_pairs = len(pairs)
+    for i, (e, l) in enumerate(pairs):
+        p.arm_ext[i], p.arm_lig[i] = e, l
+    p.check_copy_number = int(check_copy_number)
+    p.logistic_heuristic = int(logistic_heuristic)
+    p.masked_arm_threshold = masked_arm_threshold
+    svr = score_method == SCORE_SVR
+    p.upper_score_limit = svr_optimal if svr else logistic_optimal
+    p.lower_score_limit = svr_priority if svr else logistic_priority
+    p.max_arm_copy_product = max_arm_copy_product
+    p.target_arm_copy = target_arm_copy
+    return p
+
+
+def arm_pairs_of(p: Params) -> List[Tuple[int, int]]:
+    return [(p.arm_ext[i], p.arm_lig[i]) for i in range(p.n_arm_pairs)]
+
+
+class RegionData:
+    """Owns the host arrays a mipgen_region points into (keeps them alive for ctypes)."""
+
+    def __init__(self, start_flanked: int, stop_flanked: int, seq_start: int, seq: bytes,
+                 masked: Optional[bytes] = None, copy: Optional[Dict[int, np.ndarray]] = None,
+                 unmappable: Optional[np.ndarray] = None, snp_class: Optional[np.ndarray] = None,
+                 lrc: Optional[Sequence[float]] = None, chrom: str = "1", label: str = "x",
+                 start: Optional[int] = None, stop: Optional[int] = None):
+        self.chrom, self.label = chrom, label
+        self.start = start if start is not None else start_flanked      # unflanked, for print_details
+        self.stop = stop if stop is not None else stop_flanked
+        self.seq = bytes(seq)
+        self.masked = bytes(masked) if masked is not None else None
+        self.copy = {k: np.ascontiguousarray(v, dtype=np.int32) for k, v in (copy or {}).items()}
+        self.unmappable = np.ascontiguousarray(unmappable, dtype=np.uint8) if unmappable is not None else None
+        self.snp_class = np.ascontiguousarray(snp_class, dtype=np.uint8) if snp_class is not None else None
+        self.alleles: Optional[bytes] = None                              # oracle-only allele table
+        self.c = Region()
+        r = self.c
+        r.start_flanked, r.stop_flanked = start_flanked, stop_flanked
+        r.seq_start = seq_start
+        r.seq_len = len(self.seq)
+        r.seq_stop = seq_start + len(self.seq) - 1
+        r.seq = self.seq
+        r.masked_seq = self.masked if self.masked is not None else None
+        if copy is not None:
+            self._copy_tab = (C.POINTER(C.c_int32) * (MAX_OLIGO + 1))()
+            for k, v in self.copy.items():
+                assert v.shape == (r.seq_len,)
+                self._copy_tab[k] = v.ctypes.data_as(C.POINTER(C.c_int32))
+            r.copy = C.cast(self._copy_tab, C.POINTER(C.POINTER(C.c_int32)))
+        if self.unmappable is not None:
+            r.unmappable = self.unmappable.ctypes.data_as(C.POINTER(C.c_uint8))
+        if self.snp_class is not None:
+            assert self.snp_class.shape == (r.seq_len,)
+            r.snp_class = self.snp_class.ctypes.data_as(C.POINTER(C.c_uint8))
+        if lrc is not None:
+            for i in range(N_LRC):
+                r.long_range_content[i] = float(lrc[i])
+
+
+def region_array(regions: Sequence[RegionData]):
+    arr = (Region * len(regions))()
+    for i, r in enumerate(regions):
+        arr[i] = r.c
+    return arr
+
+
+def n_sizes_all(p: Params) -> int:
+    if p.max_capture_size < p.min_capture_size:
+        return 0
+    return (p.max_capture_size - p.min_capture_size) // p.capture_increment + 1
+
+
+def build_region(genome: bytes, chrom: str, bed_start: int, bed_end: int, params: Params, flank: int = 0,
+                 label: str = "x", bwa_mode: str = "unique", snp_tab: Optional[Dict[int, str]] = None,
+                 mask_record: Optional[int] = None, lrc: Optional[Sequence[float]] = None,
+                 pad: int = 15) -> RegionData:
+    """Host-side construction of one region exactly as the reference's -genome_dir input path lays it out
+    (/root/reference/mipgen.cpp:1180-1229: sequence = [max(1, start_fl - maxC), min(len, stop_fl + maxC + 15)])
+    with the lookup tables the external-tool stand-ins imply (see synth.shim_*)."""
+    from . import synth
+    start = bed_start + 1
+    stop = bed_end
+    sf, ef = start - flank, stop + flank
+    maxC = params.max_capture_size
+    cs = max(1, sf - maxC)
+    ce = min(len(genome), ef + maxC + pad)
+    seq = genome[cs - 1:ce].upper()
+    n = len(seq)
+    pairs = arm_pairs_of(params)
+    sizes = sorted({e for e, _ in pairs} | {l for _, l in pairs})
+    copy = None
+    unmappable = None
+    if bwa_mode != "unique":
+        copy = {}
+        starts = np.arange(cs, cs + n, dtype=np.int64)
+        for k in sizes:
+            c = synth.shim_copy(starts, k, bwa_mode)
+            # the reference only writes oligos with relative start < len - size (mipgen.cpp:829): later keys are absent -> 0
+            c[max(0, n - k):] = 0
+            copy[k] = c
+        K = n_sizes_all(params)
+        unmappable = np.zeros((K, n), dtype=np.uint8)
+        for k in range(K):
+            size = maxC - k * params.capture_increment
+            # capture windows are written for start in [sf - size, ef) with start > 0 and start+size-1 <= ce (mipgen.cpp:812-823)
+            pos = np.arange(cs, cs + n, dtype=np.int64)
+            ok = (pos >= sf - size) & (pos < ef) & (pos > 0) & (pos + size - 1 <= ce)
+            unmappable[k] = (synth.shim_unmappable(pos, size, bwa_mode) & ok).astype(np.uint8)
+    else:
+        # unique mode: table built by the reference still lacks the tail oligos -> model exactly
+        copy = {}
+        for k in sizes:
+            c = np.ones(n, dtype=np.int32)
+            c[max(0, n - k):] = 0
+            copy[k] = c
+    masked = synth.shim_mask(seq, mask_record) if mask_record is not None else None
+    snp_class = None
+    alleles = None
+    if snp_tab:
+        snp_class = np.zeros(n, dtype=np.uint8)
+        al = bytearray(2 * n)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        for pos, a in snp_tab.items():
+            i = pos - cs
+            if 0 <= i < n:
+                g = chr(seq[i])
+                okc = (len(a) == 2 and a[0] not in "N-" and a[1] not in "N-" and (g == a[0] or (a[0] in comp and g == comp[a[0]])))
+                snp_class[i] = 1 if okc else 2
+                if len(a) == 2:
+                    al[2 * i], al[2 * i + 1] = ord(a[0]), ord(a[1])
+                else:
+                    al[2 * i], al[2 * i + 1] = ord("*"), ord("*")
+        alleles = bytes(al)
+    rd = RegionData(sf, ef, cs, seq, masked=masked, copy=copy, unmappable=unmappable, snp_class=snp_class,
+                    lrc=lrc, chrom=chrom, label=label, start=start, stop=stop)
+    rd.alleles = alleles
+    return rd
+
+
+# ----------------------------------------------------------------------------------------------------
+# the library
+# ----------------------------------------------------------------------------------------------------
+
+class AccelError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libmipgen_accel.so and declare every prototype of include/mipgen_accel.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise AccelError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback)")
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.mipgen_accel_abi_version.restype = C.c_int
+    lib.mipgen_accel_last_error.restype = C.c_char_p
+    lib.mipgen_accel_device_count.restype = C.c_int
+    lib.mipgen_accel_create.argtypes = [C.POINTER(Params), C.c_int, vp, C.POINTER(vp)]
+    lib.mipgen_accel_destroy.argtypes = [vp]
+    lib.mipgen_accel_destroy.restype = None
+    lib.mipgen_accel_load_model_file.argtypes = [vp, C.c_char_p]
+    lib.mipgen_accel_set_model.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mipgen_accel_model_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mipgen_accel_upload_regions.argtypes = [vp, C.POINTER(Region), C.c_int32, C.POINTER(Grid)]
+    lib.mipgen_accel_batch_candidates.argtypes = [vp]
+    lib.mipgen_accel_batch_candidates.restype = C.c_int64
+    lib.mipgen_accel_score_resident.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_result_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.mipgen_accel_download_results.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int64, C.c_int64]
+    lib.mipgen_accel_score_regions.argtypes = [vp, C.POINTER(Region), C.c_int32, C.c_int32, C.POINTER(Grid),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int64]
+    lib.mipgen_accel_score_candidates.argtypes = [vp, C.POINTER(Candidate), C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(CandidateInts)]
+    lib.mipgen_accel_long_range_content.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    lib.mipgen_accel_replay_condense.argtypes = [vp]
+    lib.mipgen_accel_download_replay.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(Survivor), C.c_int64,
+                                                 C.POINTER(C.c_uint8), C.c_int64]
+    lib.mipgen_accel_last_kernel_ms.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_last_kernel_ms.restype = C.c_double
+    lib.mipgen_accel_set_timing.argtypes = [vp, C.c_int32]
+    for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
+                 "result_device_ptrs", "download_results", "score_regions", "score_candidates",
+                 "long_range_content", "replay_condense", "download_replay", "set_timing"):
+        getattr(lib, "mipgen_accel_" + name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "mipgen_accel_abi_version", "mipgen_accel_last_error", "mipgen_accel_device_count", "mipgen_accel_create",
+    "mipgen_accel_destroy", "mipgen_accel_load_model_file", "mipgen_accel_set_model", "mipgen_accel_model_info",
+    "mipgen_accel_upload_regions", "mipgen_accel_batch_candidates", "mipgen_accel_score_resident",
+    "mipgen_accel_result_device_ptrs", "mipgen_accel_download_results", "mipgen_accel_score_regions",
+    "mipgen_accel_score_candidates", "mipgen_accel_long_range_content", "mipgen_accel_replay_condense",
+    "mipgen_accel_download_replay", "mipgen_accel_last_kernel_ms", "mipgen_accel_set_timing",
+]
+
+
+class Accel:
+    """Thin RAII wrapper around a mipgen_accel handle."""
+
+    def __init__(self, params: Params, device: int = 0, stream: int = 0):
+        self.lib = load_library()
+        self.params = params
+        self.h = C.c_void_p()
+        self._check(self.lib.mipgen_accel_create(C.byref(params), device, C.c_void_p(stream), C.byref(self.h)))
+        self.grids: List[Grid] = []
+        self._regions: Sequence[RegionData] = []
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            msg = self.lib.mipgen_accel_last_error()
+            raise AccelError(f"mipgen_accel error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.mipgen_accel_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # model
+    def load_model_file(self, path: str) -> None:
+        self._check(self.lib.mipgen_accel_load_model_file(self.h, path.encode()))
+
+    def set_model(self, gamma: float, rho: float, coef: np.ndarray, sv: np.ndarray) -> None:
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        sv = np.ascontiguousarray(sv, dtype=np.float64)
+        assert sv.shape == (coef.shape[0], N_FEATURES)
+        self._check(self.lib.mipgen_accel_set_model(self.h, coef.shape[0], gamma, rho,
+                                                    coef.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    sv.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def model_info(self) -> Tuple[int, float, float]:
+        n, g, r = C.c_int32(), C.c_double(), C.c_double()
+        self._check(self.lib.mipgen_accel_model_info(self.h, C.byref(n), C.byref(g), C.byref(r)))
+        return n.value, g.value, r.value
+
+    # regions
+    def upload(self, regions: Sequence[RegionData]) -> List[Grid]:
+        arr = region_array(regions)
+        grids = (Grid * len(regions))()
+        self._check(self.lib.mipgen_accel_upload_regions(self.h, arr, len(regions), grids))
+        self.grids = list(grids)
+        self._regions = regions
+        return self.grids
+
+    def batch_candidates(self) -> int:
+        return int(self.lib.mipgen_accel_batch_candidates(self.h))
+
+    def score_resident(self, method: int) -> None:
+        self._check(self.lib.mipgen_accel_score_resident(self.h, method))
+
+    def result_device_ptrs(self) -> Tuple[int, int]:
+        a, b = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.mipgen_accel_result_device_ptrs(self.h, C.byref(a), C.byref(b)))
+        return a.value or 0, b.value or 0
+
+    def download(self, first: int = 0, count: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        n = self.batch_candidates() - first if count is None else count
+        scores = np.empty(n, dtype=np.float64)
+        records = np.empty(n, dtype=np.uint64)
+        self._check(self.lib.mipgen_accel_download_results(self.h, scores.ctypes.data_as(C.POINTER(C.c_double)),
+                                                           records.ctypes.data_as(C.POINTER(C.c_uint64)), first, n))
+        return scores, records
+
+    def score_regions(self, regions: Sequence[RegionData], method: int) -> Tuple[List[Grid], np.ndarray, np.ndarray]:
+        self.upload(regions)
+        self.score_resident(method)
+        s, r = self.download()
+        return self.grids, s, r
+
+    def score_candidates(self, cands: Sequence[Tuple[int, int, int, int, int, int]], method: int,
+                         want_features: bool = False, want_ints: bool = False):
+        n = len(cands)
+        arr = (Candidate * n)()
+        for i, c in enumerate(cands):
+            arr[i] = Candidate(*c)
+        scores = np.empty(n, dtype=np.float64)
+        records = np.empty(n, dtype=np.uint64)
+        feats = np.empty((n, N_FEATURES), dtype=np.float64) if want_features else None
+        ints = (CandidateInts * n)() if want_ints else None
+        self._check(self.lib.mipgen_accel_score_candidates(
+            self.h, arr, n, method, scores.ctypes.data_as(C.POINTER(C.c_double)),
+            records.ctypes.data_as(C.POINTER(C.c_uint64)),
+            feats.ctypes.data_as(C.POINTER(C.c_double)) if feats is not None else None,
+            ints if ints is not None else None))
+        return scores, records, feats, ints
+
+    def long_range_content(self, extended_seq: bytes, chrom_seq_start: int, chrom_seq_stop: int) -> np.ndarray:
+        out = np.empty(N_LRC, dtype=np.float64)
+        self._check(self.lib.mipgen_accel_long_range_content(self.h, extended_seq, len(extended_seq), chrom_seq_start,
+                                                             chrom_seq_stop, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def replay_condense(self) -> None:
+        self._check(self.lib.mipgen_accel_replay_condense(self.h))
+
+    def download_replay(self, want_mask: bool = True):
+        nreg = len(self.grids)
+        emitted = np.zeros(nreg, dtype=np.int64)
+        npos = sum(g.n_pos for g in self.grids)
+        surv = np.zeros(2 * npos, dtype=SURVIVOR_DTYPE)
+        total = self.batch_candidates()
+        mask = np.zeros(total if want_mask else 0, dtype=np.uint8)
+        self._check(self.lib.mipgen_accel_download_replay(
+            self.h, emitted.ctypes.data_as(C.POINTER(C.c_int64)), surv.ctypes.data_as(C.POINTER(Survivor)), 2 * npos,
+            mask.ctypes.data_as(C.POINTER(C.c_uint8)) if want_mask else None, mask.shape[0]))
+        return emitted, surv, mask
+
+    def set_timing(self, on: bool) -> None:
+        self._check(self.lib.mipgen_accel_set_timing(self.h, int(on)))
+
+    def last_kernel_ms(self, which: int = 0) -> float:
+        return float(self.lib.mipgen_accel_last_kernel_ms(self.h, which))
+
+
+# record field accessors (vectorised)
+def rec_ext_copy(r): return (r & np.uint64(0xFFFF)).astype(np.int64)
+def rec_lig_copy(r): return ((r >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64)
+def rec_masked_n(r): return ((r >> np.uint64(32)) & np.uint64(0xFF)).astype(np.int64)
+def rec_snp_count(r): return ((r >> np.uint64(40)) & np.uint64(0xFF)).astype(np.int64)
+def rec_flags(r): return ((r >> np.uint64(48)) & np.uint64(0xFF)).astype(np.int64)
+def rec_junction(r): return ((r >> np.uint64(56)) & np.uint64(0xFF)).astype(np.int64)

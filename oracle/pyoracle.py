@@ -1,0 +1,246 @@
+"""ctypes wrappers for the oracle (oracle/_build/libmipgen_oracle.so, plain-C restatement) and for the real
+reference's function-level driver (oracle/_ref/libmipgen_refdrv.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under mipgen_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from mipgen_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(HERE, "_build", "libmipgen_oracle.so")
+REFDRV_LIB = os.path.join(HERE, "_ref", "libmipgen_refdrv.so")
+
+
+def build(ref: bool = True) -> None:
+    """make the oracle (and, when /root/reference is present, oracle/_ref)."""
+    subprocess.run(["make", "-s", "-C", HERE, "oracle"], check=True)
+    if ref:
+        subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
+
+
+class Designed(C.Structure):
+    _fields_ = [("ext_start", C.c_int32), ("ext_stop", C.c_int32), ("lig_start", C.c_int32), ("lig_stop", C.c_int32),
+                ("scan_start", C.c_int32), ("scan_stop", C.c_int32), ("scan_size", C.c_int32),
+                ("ext_copy", C.c_int32), ("lig_copy", C.c_int32), ("snp_count", C.c_int32), ("masked_n", C.c_int32),
+                ("arm_fraction_masked", C.c_double),
+                ("mapping_failed", C.c_char), ("snp_failed", C.c_char), ("masking_failed", C.c_char), ("has_snp_mip", C.c_char),
+                ("ext_seq", C.c_char * (capi.MAX_OLIGO + 1)), ("lig_seq", C.c_char * (capi.MAX_OLIGO + 1)),
+                ("junction", C.c_char * 3), ("ins_seq", C.c_char * 1024),
+                ("snp_ext_seq", C.c_char * (capi.MAX_OLIGO + 1)), ("snp_lig_seq", C.c_char * (capi.MAX_OLIGO + 1))]
+
+
+class Emitted(C.Structure):
+    _fields_ = [("scan_start", C.c_int32), ("capture_size", C.c_int32), ("ext_len", C.c_int32), ("lig_len", C.c_int32),
+                ("strand", C.c_int32), ("ext_copy", C.c_int32), ("lig_copy", C.c_int32), ("snp_count", C.c_int32),
+                ("score", C.c_double), ("flags", C.c_char * 4), ("dense_index", C.c_int64)]
+
+
+_o = None
+_r = None
+
+
+def oracle():
+    global _o
+    if _o is not None:
+        return _o
+    if not os.path.exists(ORACLE_LIB):
+        build(ref=False)
+    lib = C.CDLL(ORACLE_LIB)
+    cp, dp, vp = C.c_char_p, C.POINTER(C.c_double), C.c_void_p
+    lib.mo_reverse_comp.argtypes = [cp, C.c_int, cp]
+    lib.mo_get_score.argtypes = [cp, cp, cp, cp, C.c_int, C.c_int, C.POINTER(capi.CandidateInts)]
+    lib.mo_get_score.restype = C.c_double
+    lib.mo_get_parameters.argtypes = [cp, cp, cp, cp, C.c_int, C.c_int, dp, dp]
+    lib.mo_long_range_content.argtypes = [cp, C.c_int, C.c_int, dp]
+    lib.mo_svm_load_model.argtypes = [cp]
+    lib.mo_svm_load_model.restype = vp
+    lib.mo_svm_free_model.argtypes = [vp]
+    for n in ("mo_svm_nsv", "mo_svm_kernel_type", "mo_svm_svm_type"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = C.c_int
+    for n in ("mo_svm_gamma", "mo_svm_rho"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = C.c_double
+    lib.mo_svm_densify.argtypes = [vp, dp, dp]
+    lib.mo_predict_value.argtypes = [vp, dp]
+    lib.mo_predict_value.restype = C.c_double
+    PP, RP = C.POINTER(capi.Params), C.POINTER(capi.Region)
+    lib.mo_design.argtypes = [PP, RP, C.POINTER(capi.Candidate), cp, C.POINTER(Designed)]
+    lib.mo_score_designed.argtypes = [C.POINTER(Designed), C.c_int, vp, dp, dp, C.POINTER(capi.CandidateInts)]
+    lib.mo_score_designed.restype = C.c_double
+    lib.mo_record_of.argtypes = [C.POINTER(Designed), C.c_int, C.POINTER(capi.CandidateInts)]
+    lib.mo_record_of.restype = C.c_uint64
+    lib.mo_grid.argtypes = [PP, RP, C.POINTER(capi.Grid)]
+    lib.mo_score_region_dense.argtypes = [PP, RP, vp, C.c_int, dp, C.POINTER(C.c_uint64)]
+    lib.mo_replay_region.argtypes = [PP, RP, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
+    lib.mo_replay_region.restype = C.c_int64
+    lib.mo_condense_region.argtypes = [PP, RP, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(capi.Survivor)]
+    lib.mo_enumerate_region.argtypes = [PP, RP, vp, C.c_int, cp, C.POINTER(Emitted), C.c_int64]
+    lib.mo_enumerate_region.restype = C.c_int64
+    lib.mo_print_details.argtypes = [cp, cp, C.c_int, C.c_int, C.c_int, C.POINTER(Designed), C.c_double, cp, C.c_int, C.c_int, cp, C.c_int]
+    _o = lib
+    return lib
+
+
+def have_refdrv() -> bool:
+    return os.path.exists(REFDRV_LIB)
+
+
+def refdrv():
+    """The REAL reference classes behind a C ABI (built only where /root/reference exists; travels prebuilt)."""
+    global _r
+    if _r is not None:
+        return _r
+    lib = C.CDLL(REFDRV_LIB)
+    cp, dp, vp = C.c_char_p, C.POINTER(C.c_double), C.c_void_p
+    lib.ref_logistic.argtypes = [C.c_int, cp, cp, cp, C.c_int, C.c_int, cp]
+    lib.ref_logistic.restype = C.c_double
+    lib.ref_parameters.argtypes = [C.c_int, cp, cp, cp, C.c_int, C.c_int, cp, dp, dp]
+    lib.ref_parameters.restype = C.c_int
+    lib.ref_oriented.argtypes = [C.c_int, cp, cp, cp, cp, cp, cp, cp]
+    lib.ref_long_range_content.argtypes = [cp, C.c_int, C.c_int, dp]
+    lib.ref_svm_load_model.argtypes = [cp]
+    lib.ref_svm_load_model.restype = vp
+    lib.ref_svm_nsv.argtypes = [vp]
+    lib.ref_svm_gamma.argtypes = [vp]
+    lib.ref_svm_gamma.restype = C.c_double
+    lib.ref_svm_rho.argtypes = [vp]
+    lib.ref_svm_rho.restype = C.c_double
+    lib.ref_svm_free_model.argtypes = [vp]
+    lib.ref_predict_dense.argtypes = [vp, dp, C.c_int]
+    lib.ref_predict_dense.restype = C.c_double
+    lib.ref_predict_text.argtypes = [vp, dp, C.c_int]
+    lib.ref_predict_text.restype = C.c_double
+    _r = lib
+    return lib
+
+
+# ---- convenience -------------------------------------------------------------------------------------
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def revcomp(s: bytes) -> bytes:
+    out = C.create_string_buffer(len(s) + 1)
+    oracle().mo_reverse_comp(s, len(s), out)
+    return out.value
+
+
+def orient(strand: int, ext_fwd: bytes, lig_fwd: bytes, ins_fwd: bytes) -> Tuple[bytes, bytes, bytes]:
+    if strand == 0:
+        return ext_fwd, lig_fwd, ins_fwd
+    return revcomp(ext_fwd), revcomp(lig_fwd), revcomp(ins_fwd)
+
+
+def get_score(ext: bytes, lig: bytes, ins: bytes, ext_copy: int, lig_copy: int, mip_seq: Optional[bytes] = None):
+    ints = capi.CandidateInts()
+    s = oracle().mo_get_score(ext, lig, ins, mip_seq, ext_copy, lig_copy, C.byref(ints))
+    return s, ints
+
+
+def get_parameters(ext: bytes, lig: bytes, ins: bytes, ext_copy: int, lig_copy: int, lrc: np.ndarray,
+                   mip_seq: Optional[bytes] = None) -> np.ndarray:
+    out = np.empty(capi.N_FEATURES)
+    lrc = np.ascontiguousarray(lrc, dtype=np.float64)
+    oracle().mo_get_parameters(ext, lig, ins, mip_seq, ext_copy, lig_copy, _dp(lrc), _dp(out))
+    return out
+
+
+def long_range_content(seq: bytes, cs: int, ce: int) -> np.ndarray:
+    out = np.empty(capi.N_LRC)
+    oracle().mo_long_range_content(seq, cs, ce, _dp(out))
+    return out
+
+
+class Model:
+    def __init__(self, path: str):
+        self.lib = oracle()
+        self.h = self.lib.mo_svm_load_model(path.encode())
+        if not self.h:
+            raise RuntimeError("oracle: model load failed: " + path)
+        self.n_sv = self.lib.mo_svm_nsv(self.h)
+        self.gamma = self.lib.mo_svm_gamma(self.h)
+        self.rho = self.lib.mo_svm_rho(self.h)
+
+    def densify(self) -> Tuple[np.ndarray, np.ndarray]:
+        sv = np.empty((self.n_sv, capi.N_FEATURES))
+        coef = np.empty(self.n_sv)
+        self.lib.mo_svm_densify(self.h, _dp(sv), _dp(coef))
+        return sv, coef
+
+    def predict(self, x: np.ndarray) -> float:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        return self.lib.mo_predict_value(self.h, _dp(x))
+
+
+def grid(params: capi.Params, region: capi.RegionData) -> capi.Grid:
+    g = capi.Grid()
+    oracle().mo_grid(C.byref(params), C.byref(region.c), C.byref(g))
+    return g
+
+
+def score_region_dense(params: capi.Params, region: capi.RegionData, method: int, model: Optional[Model] = None):
+    g = grid(params, region)
+    scores = np.empty(g.count)
+    records = np.empty(g.count, dtype=np.uint64)
+    oracle().mo_score_region_dense(C.byref(params), C.byref(region.c), model.h if model else None, method,
+                                   _dp(scores), records.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return g, scores, records
+
+
+def replay_region(params: capi.Params, region: capi.RegionData, scores: np.ndarray, records: np.ndarray):
+    emitted = np.zeros(scores.shape[0], dtype=np.uint8)
+    n = oracle().mo_replay_region(C.byref(params), C.byref(region.c), _dp(scores),
+                                  records.ctypes.data_as(C.POINTER(C.c_uint64)), emitted.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return int(n), emitted
+
+
+def condense_region(params: capi.Params, region: capi.RegionData, scores, records, emitted) -> np.ndarray:
+    g = grid(params, region)
+    out = np.zeros(2 * g.n_pos, dtype=capi.SURVIVOR_DTYPE)
+    oracle().mo_condense_region(C.byref(params), C.byref(region.c), _dp(scores), records.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                emitted.ctypes.data_as(C.POINTER(C.c_uint8)), out.ctypes.data_as(C.POINTER(capi.Survivor)))
+    return out
+
+
+def enumerate_region(params: capi.Params, region: capi.RegionData, method: int, model: Optional[Model] = None,
+                     capacity: Optional[int] = None):
+    g = grid(params, region)
+    cap = capacity if capacity is not None else int(g.count)
+    buf = (Emitted * max(cap, 1))()
+    n = oracle().mo_enumerate_region(C.byref(params), C.byref(region.c), model.h if model else None, method,
+                                     region.alleles, buf, cap)
+    return int(n), buf
+
+
+def design(params: capi.Params, region: capi.RegionData, cand: Tuple[int, int, int, int, int, int]):
+    d = Designed()
+    c = capi.Candidate(*cand)
+    skipped = oracle().mo_design(C.byref(params), C.byref(region.c), C.byref(c), region.alleles, C.byref(d))
+    return skipped, d
+
+
+def score_designed(d: Designed, method: int, lrc: np.ndarray, model: Optional[Model] = None):
+    feats = np.empty(capi.N_FEATURES)
+    ints = capi.CandidateInts()
+    lrc = np.ascontiguousarray(lrc, dtype=np.float64)
+    s = oracle().mo_score_designed(C.byref(d), method, model.h if model else None, _dp(lrc), _dp(feats), C.byref(ints))
+    return s, feats, ints
+
+
+def print_details(region: capi.RegionData, strand: int, d: Designed, score: float, middle: bytes, mip_index: int,
+                  minor: bool = False) -> bytes:
+    buf = C.create_string_buffer(4096)
+    n = oracle().mo_print_details(region.chrom.encode(), region.label.encode(), region.start, region.stop, strand,
+                                  C.byref(d), score, middle, mip_index, int(minor), buf, 4096)
+    return buf.raw[:n]
