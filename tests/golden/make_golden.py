@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference (oracle/_ref, compiled by
+oracle/Makefile from the sources under /root/reference).  Run in the build container only:
+
+    make -C oracle all && python tests/golden/make_golden.py
+
+What is committed is DATA: inputs (small synthetic genomes / BEDs / VCFs / libsvm models, all generated here
+from fixed seeds) and the reference's outputs on them.  No reference source text is stored.
+
+Fixtures
+  candidates.npz / candidates.json   per-candidate known answers from the reference classes
+                                     (SVMipv4::get_score, SVMipv4::get_parameters, svm_predict,
+                                      Featurev5::get_long_range_content) at full double precision
+  design_<name>/                      end-to-end designs run through the reference binary: inputs + the
+                                      reference's all_mips (gz) / collapsed / picked / snp files + sha256
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from mipgen_amd import synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from oracle.run_reference import run_reference  # noqa: E402
+
+MIDDLE = b"CTTCAGCTTCCCGATATCCGACGGTAGTGTNNNNN"   # universal_middle_mip_seq for the default -tag_sizes 5,0
+
+
+def sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def gen_models(genome: bytes) -> None:
+    os.makedirs(os.path.join(HERE, "models"), exist_ok=True)
+    synth.synthetic_svr_model(os.path.join(HERE, "models", "svr_syn_64.model"), genome, 64, seed=7)
+    synth.synthetic_svr_model(os.path.join(HERE, "models", "svr_syn_200.model"), genome, 200, seed=8, drop_zero_frac=0.5)
+
+
+def gen_candidates(genome: bytes) -> None:
+    """Known answers at full precision, incl. edge cases: N in arm / insert, copy 0/1/100/101, both strands,
+    every junction, scan sizes past the 250 clamp."""
+    R = po.refdrv()
+    rng = np.random.default_rng(42)
+    dp = C.POINTER(C.c_double)
+    m64 = R.ref_svm_load_model(os.path.join(HERE, "models", "svr_syn_64.model").encode())
+    m200 = R.ref_svm_load_model(os.path.join(HERE, "models", "svr_syn_200.model").encode())
+    g = genome
+    recs = []
+    logistic, params, svr64, svr200, lrcs = [], [], [], [], []
+    n = 400
+    for t in range(n):
+        e = int(rng.integers(16, 31)); l = int(rng.integers(16, 31))
+        ss = int(rng.integers(70, 230)) if t % 10 else int(rng.integers(250, 300))
+        p = int(rng.integers(400, len(g) - 700)); strand = int(rng.integers(0, 2))
+        ext = bytearray(g[p - 1 - e:p - 1] if strand == 0 else g[p - 1 + ss:p - 1 + ss + e])
+        ins = bytearray(g[p - 1:p - 1 + ss])
+        lig = bytearray(g[p - 1 + ss:p - 1 + ss + l] if strand == 0 else g[p - 1 - l:p - 1])
+        kind = t % 20
+        if kind == 3: ext[int(rng.integers(0, e))] = ord("N")
+        if kind == 5: lig[int(rng.integers(0, l))] = ord("N")
+        if kind == 7:
+            a = int(rng.integers(0, ss - 12)); ins[a:a + int(rng.integers(1, 12))] = b"N" * 12
+            ins = ins[:ss]
+        if kind == 9: ins[0] = ord("N")
+        if kind == 11: ins[int(rng.integers(0, ss))] = ord("R")          # IUPAC code: not N, not ACGT
+        if kind == 13: lig[0 if strand == 0 else l - 1] = ord("N")       # junction with N -> guard
+        ec = int(rng.choice([0, 1, 1, 1, 1, 2, 7, 20, 21, 75, 100, 101, 500, 70000]))
+        lc = int(rng.choice([0, 1, 1, 1, 1, 3, 19, 100, 101, 1000]))
+        lrc = rng.uniform(0, 0.3, 44)
+        ext, lig, ins = bytes(ext), bytes(lig), bytes(ins)
+        s = R.ref_logistic(strand, ext, lig, ins, ec, lc, MIDDLE)
+        x = np.empty(192)
+        R.ref_parameters(strand, ext, lig, ins, ec, lc, MIDDLE, lrc.ctypes.data_as(dp), x.ctypes.data_as(dp))
+        recs.append({"strand": strand, "ext_fwd": ext.decode(), "lig_fwd": lig.decode(), "ins_fwd": ins.decode(),
+                     "ext_copy": ec, "lig_copy": lc})
+        logistic.append(s); params.append(x); lrcs.append(lrc)
+        svr64.append(R.ref_predict_text(m64, x.ctypes.data_as(dp), 192))
+        svr200.append(R.ref_predict_text(m200, x.ctypes.data_as(dp), 192))
+    # long-range content known answers
+    lr_in, lr_out = [], []
+    for t in range(6):
+        a = int(rng.integers(0, len(g) - 4000)); ln = int(rng.integers(2300, 3500))
+        seq = g[a:a + ln]
+        cs = a + 1001; ce = a + ln - 1000
+        out = np.empty(44)
+        R.ref_long_range_content(seq, cs, ce, out.ctypes.data_as(dp))
+        lr_in.append({"offset": a, "len": ln, "chrom_seq_start": cs, "chrom_seq_stop": ce}); lr_out.append(out)
+    np.savez_compressed(os.path.join(HERE, "candidates.npz"), logistic=np.array(logistic), params=np.array(params),
+                        svr64=np.array(svr64), svr200=np.array(svr200), lrc=np.array(lrcs), lr_out=np.array(lr_out))
+    with open(os.path.join(HERE, "candidates.json"), "w") as fh:
+        json.dump({"middle": MIDDLE.decode(), "candidates": recs, "long_range": lr_in}, fh)
+    print(f"candidates: {n} known answers, {len(lr_in)} long-range vectors")
+
+
+DESIGNS = [
+    # name, method, intervals, minC, maxC, sums, flank, tags, snps, trf, bwa_mode, model, keep_all
+    dict(name="logistic_snp_trf", method="logistic", ivs=[("1", 5000, 5070, "a"), ("1", 9000, 9046, "b")], minC=120, maxC=125,
+         sums=[40, 41], flank=5, tags="4,4", snps=True, trf=True, bwa="hashed", model=None, keep_all=True),
+    dict(name="svr_small", method="svr", ivs=[("1", 5000, 5060, "a")], minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0",
+         snps=False, trf=False, bwa="hashed", model="svr_syn_64.model", keep_all=True),
+    dict(name="mixed_small", method="mixed", ivs=[("1", 5000, 5090, "a"), ("1", 5400, 5460, "b")], minC=125, maxC=135, sums=[42, 43],
+         flank=0, tags="5,0", snps=True, trf=False, bwa="hashed", model="svr_syn_64.model", keep_all=True),
+    dict(name="logistic_default_arms", method="logistic", ivs=[("1", 5000, 5120, "a"), ("1", 5300, 5420, "b"), ("1", 5440, 5500, "c")],
+         minC=152, maxC=162, sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="unique", model=None,
+         keep_all=False),
+]
+
+
+def gen_design(genome: bytes, d: dict) -> None:
+    out = os.path.join(HERE, "design_" + d["name"])
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    w = "/tmp/mipgen_golden_" + d["name"]
+    shutil.rmtree(w, ignore_errors=True)
+    os.makedirs(w + "/genome")
+    synth.write_fasta(w + "/genome/chr1.fa", "chr1", genome)
+    ivs = [synth.Interval(*iv) for iv in d["ivs"]]
+    synth.write_bed(w + "/regions.bed", ivs)
+    shutil.copy(w + "/regions.bed", out + "/regions.bed")
+    extra = ["-arm_length_sums", ",".join(map(str, d["sums"])), "-feature_flank", str(d["flank"]), "-tag_sizes", d["tags"]]
+    snp_path = None
+    if d["snps"]:
+        snps = synth.random_snps("1", genome, 4000, 10000, seed=13, per_bp=1 / 40.0)
+        snp_path = w + "/snps.vcf"
+        synth.write_vcf(snp_path, snps)
+        shutil.copy(snp_path, out + "/snps.vcf")
+    model = os.path.join(HERE, "models", d["model"]) if d["model"] else None
+    r = run_reference(w, w + "/genome", w + "/regions.bed", "out", d["minC"], d["maxC"], score_method=d["method"],
+                      model_path=model, bwa_mode=d["bwa"], snp_file=snp_path, use_trf=d["trf"], extra=extra)
+    assert r["returncode"] == 0, r["stderr"]
+    meta = {k: d[k] for k in ("name", "method", "minC", "maxC", "sums", "flank", "tags", "snps", "trf", "bwa", "model")}
+    meta["intervals"] = d["ivs"]
+    meta["genome"] = "genome_chr1.fa.gz"
+    meta["sha256"] = {}
+    meta["lines"] = {}
+    for key in ("all_mips", "collapsed_mips", "picked_mips", "snp_mips"):
+        path = r[key]
+        meta["sha256"][key] = sha256(path)
+        with open(path, "rb") as fh:
+            data = fh.read()
+        meta["lines"][key] = data.count(b"\n")
+        if key == "all_mips" and not d["keep_all"]:
+            continue
+        with gzip.GzipFile(out + f"/ref.{key}.txt.gz", "wb", mtime=0) as gz:
+            gz.write(data)
+    for gap in ("coverage_failed.bed",):
+        p = os.path.join(w, "out." + gap)
+        if os.path.exists(p):
+            shutil.copy(p, out + "/ref." + gap)
+    with open(out + "/meta.json", "w") as fh:
+        json.dump(meta, fh, indent=1)
+    print("design", d["name"], meta["lines"])
+
+
+def main() -> None:
+    if not (po.have_refdrv() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mipgen_ref"))):
+        raise SystemExit("oracle/_ref is not built: run `make -C oracle all` where /root/reference exists")
+    genome = synth.random_genome(20000, 101, n_run_frac=0.003, n_run_len=6)
+    with gzip.GzipFile(os.path.join(HERE, "genome_chr1.fa.gz"), "wb", mtime=0) as gz:
+        gz.write(b">chr1\n")
+        for i in range(0, len(genome), 60):
+            gz.write(genome[i:i + 60] + b"\n")
+    gen_models(genome)
+    gen_candidates(genome)
+    for d in DESIGNS:
+        gen_design(genome, d)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""Shared test helpers: golden-fixture loading and a BED -> region builder following the reference's input
+stage (/root/reference/mipgen.cpp:981-1043 sort/merge, :1180-1229 -genome_dir slicing).  Test infrastructure."""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from mipgen_amd import capi, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+UNIVERSAL = b"CTTCAGCTTCCCGATATCCGACGGTAGTGT"
+
+
+def golden_genome() -> bytes:
+    with gzip.open(os.path.join(GOLDEN, "genome_chr1.fa.gz"), "rb") as fh:
+        return b"".join(l.strip() for l in fh.read().split(b"\n")[1:])
+
+
+def load_design(name: str) -> dict:
+    d = os.path.join(GOLDEN, "design_" + name)
+    with open(os.path.join(d, "meta.json")) as fh:
+        meta = json.load(fh)
+    meta["dir"] = d
+    return meta
+
+
+def ref_lines(meta: dict, key: str) -> List[bytes]:
+    with gzip.open(os.path.join(meta["dir"], f"ref.{key}.txt.gz"), "rb") as fh:
+        lines = fh.read().split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    return lines
+
+
+def middle_of(tags: str) -> bytes:
+    et, lt = map(int, tags.split(","))
+    return b"N" * lt + UNIVERSAL + b"N" * et          # mipgen.cpp:199-200
+
+
+def merged_features(intervals, flank: int, min_capture: int) -> List[Tuple[str, int, int, str]]:
+    """(chr, start_position, stop_position, label) after the reference's sort + merge (mipgen.cpp:999-1033)."""
+    ivs = sorted(intervals, key=lambda t: (t[0], t[1]))
+    out: List[List] = []
+    for chrom, bs, be, label in ivs:
+        if out and out[-1][0] == chrom and bs - out[-1][2] - 2 * flank < min_capture // 2:
+            out[-1][2] = max(be, out[-1][2])
+            out[-1][3] = label
+        else:
+            out.append([chrom, bs + 1, be, label])
+    return [tuple(x) for x in out]
+
+
+def design_params(meta: dict, score_method: Optional[int] = None) -> capi.Params:
+    sm = {"logistic": 0, "svr": 1, "mixed": 2}[meta["method"]] if score_method is None else score_method
+    return capi.make_params(meta["minC"], meta["maxC"], score_method=sm, arm_pairs=synth.arm_pairs_from_sums(meta["sums"]))
+
+
+def design_snp_table(meta: dict) -> Optional[Dict[int, str]]:
+    if not meta["snps"]:
+        return None
+    tab: Dict[int, str] = {}
+    with open(os.path.join(meta["dir"], "snps.vcf")) as fh:
+        for line in fh:
+            if len(line) < 2 or line[0] == "#":
+                continue
+            f = line.split()
+            pos, ref, alt = int(f[1]), f[3], f[4]
+            if len(ref) > 1:
+                for i in range(1, len(ref)):
+                    tab[pos + i] = ref + alt
+            else:
+                tab[pos] = ref + alt
+    return tab
+
+
+def design_regions(meta: dict, genome: bytes, params: capi.Params, lrc_fn=None) -> List[capi.RegionData]:
+    feats = merged_features([tuple(iv) for iv in meta["intervals"]], meta["flank"], meta["minC"])
+    snp_tab = design_snp_table(meta)
+    out = []
+    for ri, (chrom, start, stop, label) in enumerate(feats):
+        rd = capi.build_region(genome, chrom, start - 1, stop, params, flank=meta["flank"], label=label,
+                               bwa_mode=meta["bwa"], snp_tab=snp_tab, mask_record=ri if meta["trf"] else None)
+        if meta["method"] != "logistic" and lrc_fn is not None:
+            n = rd.c.seq_stop - rd.c.seq_start + 1
+            s0 = rd.c.start_flanked - params.max_capture_size - 1 - 1000          # mipgen.cpp:1225
+            lrc = lrc_fn(genome[s0:s0 + n + 2000], rd.c.seq_start, rd.c.seq_stop)
+            for i in range(capi.N_LRC):
+                rd.c.long_range_content[i] = lrc[i]
+        out.append(rd)
+    return out
+
+
+def normalise_flags(line: bytes) -> bytes:
+    """The reference leaves masking_failed uninitialised when mapping fails (mipgen.cpp:615-625 returns before
+    :626-633 assigns it), printing an arbitrary byte; compare such records with that byte forced to '0'."""
+    f = line.split(b"\t")
+    if len(f) > 18 and len(f[18]) == 3 and f[18][0:1] == b"1":
+        f[18] = f[18][0:2] + b"0"
+    return b"\t".join(f)
