@@ -1,0 +1,657 @@
+// accel.hip — host side of libmipgen_accel.so: the C-ABI of include/mipgen_accel.h over the gfx950 kernels.
+// No CPU scoring path exists in this library: every entry point either drives the GPU or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "logistic_device.h"
+
+// ---- kernel launchers (other translation units) -------------------------------------------------------
+struct LrcMers { int8_t k[MIPGEN_N_LRC]; int8_t code[MIPGEN_N_LRC]; int8_t rc[MIPGEN_N_LRC]; };
+struct TileDims;
+extern "C" {
+size_t mipgen_logistic_lds_bytes(int span);
+hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, int span_max, const DevParams*, const DevRegion*,
+                                          const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
+                                          double*, uint64_t*);
+size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group);
+hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int n_tiles, size_t lds_bytes, const DevParams*, const SvrGeom*,
+                                   const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
+                                   const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
+                                   const uint64_t* records, double* scores);
+hipError_t mipgen_launch_candidates(hipStream_t, int n, const DevParams*, const DevRegion*, const mipgen_candidate*, const uint8_t*,
+                                    const int32_t*, const uint8_t*, const HostConsts*, const double* model, int n_sv, double gamma,
+                                    double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*);
+hipError_t mipgen_launch_long_range(hipStream_t, const char*, int len, int denom, const LrcMers*, double*);
+hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, const DevRegion*,
+                                         const int32_t* pos_region, const int32_t* pos_local, const double* scores,
+                                         const uint64_t* records, uint8_t* emitted, mipgen_survivor* survivors,
+                                         unsigned long long* emitted_per_region);
+}
+
+// ---- errors ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) return fail(MIPGEN_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(MIPGEN_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct mipgen_accel {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    mipgen_params params;
+    DevParams hp;                    // host copy
+    DevParams* dp = nullptr;
+    HostConsts* dconsts = nullptr;
+    HostConsts hconsts;
+    SvrGeom geom;
+    // model
+    int n_sv = 0;
+    double gamma = 0, rho = 0, s_guard = 0, sum_abs_coef = 0;
+    int exp_deg = 10;
+    DevBuf<double> model;
+    // batch
+    int n_regions = 0;
+    int64_t n_cand = 0;
+    int64_t total_pos = 0;
+    std::vector<DevRegion> hregions;
+    std::vector<mipgen_grid> grids;
+    DevBuf<DevRegion> regions;
+    DevBuf<uint8_t> bases, unmap;
+    DevBuf<int32_t> copy;
+    DevBuf<LogTile> log_tiles;
+    DevBuf<SvrTile> svr_tiles;
+    int n_log_tiles = 0, n_svr_tiles = 0, log_span_max = 0;
+    size_t svr_lds = 0;
+    DevBuf<double> scores;
+    DevBuf<uint64_t> records;
+    bool scored = false;
+    // replay
+    DevBuf<uint8_t> emitted;
+    DevBuf<mipgen_survivor> survivors;
+    DevBuf<unsigned long long> emitted_per_region;
+    DevBuf<int32_t> pos_region, pos_local;
+    bool replayed = false;
+    // sparse scratch
+    DevBuf<mipgen_candidate> cand_in;
+    DevBuf<double> cand_scores, cand_feats;
+    DevBuf<uint64_t> cand_records;
+    DevBuf<mipgen_candidate_ints> cand_ints;
+    DevBuf<char> lrc_seq;
+    DevBuf<double> lrc_out;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+// ---- small helpers ----------------------------------------------------------------------------------------
+static int n_sizes_all(const mipgen_params& P)
+{
+    if (P.max_capture_size < P.min_capture_size) return 0;
+    return (P.max_capture_size - P.min_capture_size) / P.capture_increment + 1;
+}
+
+static void grid_of(const mipgen_params& P, const DevParams& D, const mipgen_region& R, mipgen_grid* g)
+{
+    // positions: mipgen.cpp:421-425; static size skip: mipgen.cpp:429
+    int cur = R.start_flanked - P.max_capture_size + D.max_sum;
+    if (cur < 0) cur = 0;
+    g->first_pos = cur + 1;
+    g->n_pos = std::max(0, R.stop_flanked - cur);
+    int K = D.n_sizes_all, k0 = 0;
+    while (k0 < K) {
+        int C = P.max_capture_size - k0 * P.capture_increment;
+        if (C > R.stop_flanked - R.start_flanked + P.max_mip_overlap && C - P.capture_increment >= P.min_capture_size) k0++;
+        else break;
+    }
+    g->first_size_index = k0;
+    g->n_sizes = K - k0;
+    g->count = (int64_t)g->n_pos * g->n_sizes * P.n_arm_pairs * 2;
+    g->offset = 0;
+}
+
+static uint8_t base_code(char c)
+{
+    switch (c) {
+        case 'A': return BASE_A; case 'C': return BASE_C; case 'G': return BASE_G; case 'T': return BASE_T;
+        case 'N': return BASE_N; case '-': return BASE_DASH; default: return BASE_OTHER;
+    }
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int mipgen_accel_abi_version(void) { return MIPGEN_ACCEL_ABI_VERSION; }
+const char* mipgen_accel_last_error(void) { return g_err; }
+
+int mipgen_accel_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mipgen_accel_create(const mipgen_params* params, int device, void* stream, mipgen_accel** out)
+{
+    if (!params || !out) return fail(MIPGEN_E_INVALID, "null argument");
+    *out = nullptr;
+    if (params->abi_version != MIPGEN_ACCEL_ABI_VERSION) return fail(MIPGEN_E_INVALID, "abi_version %d != %d", params->abi_version, MIPGEN_ACCEL_ABI_VERSION);
+    if (params->n_arm_pairs < 1 || params->n_arm_pairs > MIPGEN_MAX_ARM_PAIRS) return fail(MIPGEN_E_INVALID, "n_arm_pairs out of range");
+    if (params->capture_increment <= 0) return fail(MIPGEN_E_INVALID, "capture_increment must be positive (the reference coerces 0 to 1 before this call)");
+    if (params->max_capture_size < params->min_capture_size) return fail(MIPGEN_E_INVALID, "max_capture_size < min_capture_size");
+    int ndev = mipgen_accel_device_count();
+    if (ndev <= 0) return fail(MIPGEN_E_NODEVICE, "no HIP device: libmipgen_accel has no CPU path");
+    if (device < 0 || device >= ndev) return fail(MIPGEN_E_INVALID, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mipgen_accel* h = new mipgen_accel();
+    h->device = device;
+    h->params = *params;
+    DevParams& D = h->hp;
+    memset(&D, 0, sizeof D);
+    D.min_capture = params->min_capture_size; D.max_capture = params->max_capture_size; D.inc = params->capture_increment;
+    D.n_sizes_all = n_sizes_all(*params);
+    D.n_pairs = params->n_arm_pairs;
+    D.check_copy_number = params->check_copy_number; D.logistic_heuristic = params->logistic_heuristic;
+    D.score_method = params->score_method;
+    D.masked_arm_threshold = params->masked_arm_threshold; D.upper = params->upper_score_limit; D.lower = params->lower_score_limit;
+    D.max_arm_copy_product = params->max_arm_copy_product; D.target_arm_copy = params->target_arm_copy;
+    D.min_sum = 1 << 30; D.max_sum = 0; D.e_min = D.l_min = 1 << 30; D.e_max = D.l_max = 0;
+    for (int i = 0; i <= MIPGEN_MAX_OLIGO; i++) D.len_slot[i] = -1;
+    for (int i = 0; i < D.n_pairs; i++) {
+        int e = params->arm_ext[i], l = params->arm_lig[i];
+        if (e < 2 || l < 2 || e > MIPGEN_MAX_OLIGO || l > MIPGEN_MAX_OLIGO) { delete h; return fail(MIPGEN_E_INVALID, "arm length out of range [2,%d]", MIPGEN_MAX_OLIGO); }
+        D.arm_ext[i] = (uint8_t)e; D.arm_lig[i] = (uint8_t)l;
+        D.min_sum = std::min(D.min_sum, e + l); D.max_sum = std::max(D.max_sum, e + l);
+        D.e_min = std::min(D.e_min, e); D.e_max = std::max(D.e_max, e);
+        D.l_min = std::min(D.l_min, l); D.l_max = std::max(D.l_max, l);
+        D.len_slot[e] = 0; D.len_slot[l] = 0;
+    }
+    if (params->min_capture_size - D.max_sum < 3) { delete h; return fail(MIPGEN_E_INVALID, "min_capture_size leaves a scan size < 3"); }
+    int slot = 0;
+    for (int i = 0; i <= MIPGEN_MAX_OLIGO; i++) if (D.len_slot[i] == 0) D.len_slot[i] = (int8_t)slot++;
+    D.n_len_slots = slot;
+    for (int i = 0; i < D.n_pairs;) {                         // arm-sum lists are contiguous runs (mipgen.cpp:431-438)
+        int j = i, s = D.arm_ext[i] + D.arm_lig[i];
+        while (j < D.n_pairs && D.arm_ext[j] + D.arm_lig[j] == s) j++;
+        for (int k = i; k < j; k++) D.group_end[k] = (uint16_t)j;
+        i = j;
+    }
+    // SVR thread geometry
+    SvrGeom& G = h->geom;
+    memset(&G, 0, sizeof G);
+    G.nchunk = (D.n_pairs + SVR_MAX_CHUNK - 1) / SVR_MAX_CHUNK;
+    G.chunk_len = (D.n_pairs + G.nchunk - 1) / G.nchunk;
+    G.n_e = D.e_max - D.e_min + 1; G.n_l = D.l_max - D.l_min + 1;
+    G.group = 2;
+
+    if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(MIPGEN_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    for (int i = 0; i < 101; i++) h->hconsts.log10_tab[i] = log10((double)i);    // host libm, as the reference computes it
+    h->hconsts.ln_base = log(MIPGEN_LOGISTIC_BASE);
+    hipError_t e1 = hipMalloc((void**)&h->dp, sizeof(DevParams));
+    hipError_t e2 = hipMalloc((void**)&h->dconsts, sizeof(HostConsts));
+    if (e1 != hipSuccess || e2 != hipSuccess) { mipgen_accel_destroy(h); return fail(MIPGEN_E_NOMEM, "hipMalloc failed"); }
+    HIP_TRY(hipMemcpy(h->dp, &D, sizeof D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->dconsts, &h->hconsts, sizeof(HostConsts), hipMemcpyHostToDevice));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[i]));
+    *out = h;
+    return MIPGEN_OK;
+}
+
+void mipgen_accel_destroy(mipgen_accel* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->model.release(); h->regions.release(); h->bases.release(); h->unmap.release(); h->copy.release();
+    h->log_tiles.release(); h->svr_tiles.release(); h->scores.release(); h->records.release();
+    h->emitted.release(); h->survivors.release(); h->emitted_per_region.release(); h->pos_region.release(); h->pos_local.release();
+    h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
+    h->lrc_seq.release(); h->lrc_out.release();
+    if (h->dp) (void)hipFree(h->dp);
+    if (h->dconsts) (void)hipFree(h->dconsts);
+    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// ---- model ----------------------------------------------------------------------------------------------------
+int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double rho, const double* coef, const double* sv)
+{
+    if (!h || n_sv < 0 || (n_sv > 0 && (!coef || !sv))) return fail(MIPGEN_E_INVALID, "bad model arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<double> rows((size_t)std::max(n_sv, 1) * SV_ROW, 0.0);
+    double s_guard = 0.0, sum_abs = 0.0;
+    for (int i = 0; i < n_sv; i++) {
+        double* r = &rows[(size_t)i * SV_ROW];
+        const double* x = sv + (size_t)i * MIPGEN_N_FEATURES;
+        double ne = 0, ni = 0, nl = 0, nj = 0, tot = 0;
+        for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
+            r[j] = x[j];
+            double q = x[j] * x[j];
+            tot += q;                                     // index order, as the sparse merge walk accumulates (svm.cpp:329-368)
+            if (j <= 20) ne += q;
+            else if (j >= F_INS && j <= 150) ni += q;
+            else if (j >= F_LIG && j <= 172) nl += q;
+            else if (j >= F_JUNC && j <= 189) nj += q;
+        }
+        r[SVR_COEF] = coef[i]; r[SVR_N_EXT] = ne; r[SVR_N_INS] = ni; r[SVR_N_LIG] = nl; r[SVR_N_JUNC] = nj;
+        r[SVR_N_TOTAL] = tot; r[SVR_N_EXTRA] = 0.0;
+        s_guard += coef[i] * exp(-gamma * tot);
+        sum_abs += fabs(coef[i]);
+    }
+    if (h->model.reserve(rows.size())) return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho; h->sum_abs_coef = sum_abs;
+    // smallest exp2 polynomial whose error, amplified by sum|coef|, stays below 1e-7 (gate: 1e-5)
+    const double budget = 1e-7;
+    if (sum_abs * 2.6e-9 <= budget) h->exp_deg = 6;
+    else if (sum_abs * 5.6e-11 <= budget) h->exp_deg = 7;
+    else if (sum_abs * 1.1e-12 <= budget) h->exp_deg = 8;
+    else h->exp_deg = 10;
+    if (const char* f = getenv("MIPGEN_ACCEL_EXP_DEG")) h->exp_deg = atoi(f);
+    return MIPGEN_OK;
+}
+
+// libsvm 3.17 text model (grammar: svm.cpp:2779-2962)
+int mipgen_accel_load_model_file(mipgen_accel* h, const char* path)
+{
+    if (!h || !path) return fail(MIPGEN_E_INVALID, "null argument");
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return fail(MIPGEN_E_MODEL, "cannot open model file %s (the reference would dereference NULL here, svm.cpp:2507)", path);
+    char cmd[128];
+    std::string svm_type, kernel_type;
+    double gamma = 0, rho = 0;
+    int nr_class = 2, total_sv = -1;
+    bool ok = true, seen_sv = false;
+    while (ok && fscanf(fp, "%127s", cmd) == 1) {
+        std::string c(cmd);
+        if (c == "svm_type") { ok = fscanf(fp, "%127s", cmd) == 1; svm_type = cmd; }
+        else if (c == "kernel_type") { ok = fscanf(fp, "%127s", cmd) == 1; kernel_type = cmd; }
+        else if (c == "degree") { int d; ok = fscanf(fp, "%d", &d) == 1; }
+        else if (c == "gamma") ok = fscanf(fp, "%lf", &gamma) == 1;
+        else if (c == "coef0") { double d; ok = fscanf(fp, "%lf", &d) == 1; }
+        else if (c == "nr_class") ok = fscanf(fp, "%d", &nr_class) == 1;
+        else if (c == "total_sv") ok = fscanf(fp, "%d", &total_sv) == 1;
+        else if (c == "rho") { int n = nr_class * (nr_class - 1) / 2; for (int i = 0; i < n && ok; i++) { double r; ok = fscanf(fp, "%lf", &r) == 1; if (i == 0) rho = r; } }
+        else if (c == "label" || c == "nr_sv") { for (int i = 0; i < nr_class && ok; i++) { int d; ok = fscanf(fp, "%d", &d) == 1; } }
+        else if (c == "probA" || c == "probB") { int n = nr_class * (nr_class - 1) / 2; for (int i = 0; i < n && ok; i++) { double d; ok = fscanf(fp, "%lf", &d) == 1; } }
+        else if (c == "SV") { int ch; while ((ch = getc(fp)) != EOF && ch != '\n') {} seen_sv = true; break; }
+        else { fclose(fp); return fail(MIPGEN_E_MODEL, "unknown text in model file: [%s]", cmd); }
+    }
+    if (!ok || !seen_sv || total_sv < 0) { fclose(fp); return fail(MIPGEN_E_MODEL, "malformed model header in %s", path); }
+    if (svm_type != "epsilon_svr" && svm_type != "nu_svr") { fclose(fp); return fail(MIPGEN_E_MODEL, "svm_type %s unsupported (SVR only)", svm_type.c_str()); }
+    if (kernel_type != "rbf") { fclose(fp); return fail(MIPGEN_E_MODEL, "kernel_type %s unsupported (rbf only)", kernel_type.c_str()); }
+    std::vector<double> sv((size_t)std::max(total_sv, 1) * MIPGEN_N_FEATURES, 0.0), coef((size_t)std::max(total_sv, 1), 0.0), extra((size_t)std::max(total_sv, 1), 0.0);
+    char* line = nullptr; size_t cap = 0;
+    int got = 0;
+    while (got < total_sv && getline(&line, &cap, fp) >= 0) {
+        char* save = nullptr;
+        char* p = strtok_r(line, " \t\n", &save);
+        if (!p) continue;
+        coef[got] = strtod(p, nullptr);
+        for (int k = 1; k < nr_class - 1; k++) strtok_r(nullptr, " \t", &save);
+        for (;;) {
+            char* idx = strtok_r(nullptr, ":", &save);
+            char* val = strtok_r(nullptr, " \t\n", &save);
+            if (!val) break;
+            long j = strtol(idx, nullptr, 10);
+            double v = strtod(val, nullptr);
+            if (j >= 1 && j <= MIPGEN_N_FEATURES) sv[(size_t)got * MIPGEN_N_FEATURES + (j - 1)] = v;
+            else if (j > MIPGEN_N_FEATURES) extra[got] += v * v;   // x has no such index: contributes sv^2 (svm.cpp:359-363)
+        }
+        got++;
+    }
+    free(line);
+    fclose(fp);
+    if (got != total_sv) return fail(MIPGEN_E_MODEL, "model file has %d SV lines, header says %d", got, total_sv);
+    int rc = mipgen_accel_set_model(h, total_sv, gamma, rho, coef.data(), sv.data());
+    if (rc) return rc;
+    bool any_extra = false;
+    for (double x : extra) any_extra |= x != 0.0;
+    if (any_extra) {
+        std::vector<double> rows((size_t)total_sv * SV_ROW);
+        HIP_TRY(hipMemcpy(rows.data(), h->model.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double sg = 0;
+        for (int i = 0; i < total_sv; i++) {
+            rows[(size_t)i * SV_ROW + SVR_N_EXTRA] = extra[i];
+            rows[(size_t)i * SV_ROW + SVR_N_TOTAL] += extra[i];
+            sg += coef[i] * exp(-gamma * rows[(size_t)i * SV_ROW + SVR_N_TOTAL]);
+        }
+        HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->s_guard = sg - rho;
+    }
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_model_info(const mipgen_accel* h, int32_t* n_sv, double* gamma, double* rho)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (n_sv) *n_sv = h->n_sv;
+    if (gamma) *gamma = h->gamma;
+    if (rho) *rho = h->rho;
+    return MIPGEN_OK;
+}
+
+// ---- region batch ---------------------------------------------------------------------------------------------
+int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, mipgen_grid* grids_out)
+{
+    if (!h || n < 0 || (n > 0 && !regions)) return fail(MIPGEN_E_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    const mipgen_params& P = h->params;
+    const DevParams& D = h->hp;
+    h->scored = false; h->replayed = false;
+    h->hregions.assign((size_t)n, DevRegion());
+    h->grids.assign((size_t)n, mipgen_grid());
+    int64_t seq_total = 0, copy_total = 0, unmap_total = 0, cand_total = 0, pos_total = 0;
+    for (int i = 0; i < n; i++) {
+        const mipgen_region& R = regions[i];
+        if (!R.seq || R.seq_len <= 0) return fail(MIPGEN_E_INVALID, "region %d has no sequence", i);
+        if (R.seq_stop - R.seq_start + 1 != R.seq_len) return fail(MIPGEN_E_INVALID, "region %d: seq_len %d != seq_stop-seq_start+1 = %d", i, R.seq_len, R.seq_stop - R.seq_start + 1);
+        DevRegion& d = h->hregions[i];
+        mipgen_grid& g = h->grids[i];
+        grid_of(P, D, R, &g);
+        g.offset = cand_total;
+        d.out_off = cand_total; d.seq_off = seq_total;
+        d.seq_len = R.seq_len; d.seq_start = R.seq_start; d.seq_stop = R.seq_stop;
+        d.start_fl = R.start_flanked; d.stop_fl = R.stop_flanked;
+        d.first_pos = g.first_pos; d.n_pos = g.n_pos; d.k0 = g.first_size_index; d.n_sizes = g.n_sizes;
+        d.copy_off = R.copy ? copy_total : -1;
+        d.unmap_off = R.unmappable ? unmap_total : -1;
+        memcpy(d.lrc, R.long_range_content, sizeof d.lrc);
+        seq_total += R.seq_len;
+        if (R.copy) copy_total += (int64_t)D.n_len_slots * R.seq_len;
+        if (R.unmappable) unmap_total += (int64_t)D.n_sizes_all * R.seq_len;
+        cand_total += g.count;
+        pos_total += g.n_pos;
+    }
+    // encode + pack on the host
+    std::vector<uint8_t> hb((size_t)std::max<int64_t>(seq_total, 1));
+    std::vector<int32_t> hc((size_t)std::max<int64_t>(copy_total, 1));
+    std::vector<uint8_t> hu((size_t)std::max<int64_t>(unmap_total, 1));
+    for (int i = 0; i < n; i++) {
+        const mipgen_region& R = regions[i];
+        const DevRegion& d = h->hregions[i];
+        uint8_t* b = &hb[(size_t)d.seq_off];
+        for (int k = 0; k < R.seq_len; k++) {
+            uint8_t v = base_code(R.seq[k]);
+            const char m = R.masked_seq ? R.masked_seq[k] : R.seq[k];
+            if (m == 'N') v |= BASE_MASKED_BIT;
+            if (R.snp_class) v |= (uint8_t)((R.snp_class[k] & 3) << BASE_SNP_SHIFT);
+            b[k] = v;
+        }
+        if (R.copy) {
+            for (int len = 0; len <= MIPGEN_MAX_OLIGO; len++) {
+                int s = D.len_slot[len];
+                if (s < 0) continue;
+                int32_t* dst = &hc[(size_t)d.copy_off + (size_t)s * R.seq_len];
+                if (R.copy[len]) memcpy(dst, R.copy[len], (size_t)R.seq_len * sizeof(int32_t));
+                else memset(dst, 0, (size_t)R.seq_len * sizeof(int32_t));
+            }
+        }
+        if (R.unmappable) memcpy(&hu[(size_t)d.unmap_off], R.unmappable, (size_t)D.n_sizes_all * R.seq_len);
+    }
+    // tiles
+    std::vector<LogTile> lt;
+    std::vector<SvrTile> st;
+    const int Lmax = std::max(D.e_max, D.l_max);
+    int span_max = 0;
+    size_t svr_lds = 0;
+    const int n_arm = std::max(h->geom.n_e, h->geom.n_l);
+    for (int i = 0; i < n; i++) {
+        const DevRegion& d = h->hregions[i];
+        if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
+        const int Cmax = D.max_capture - d.k0 * D.inc;
+        const int NPL = 32;
+        for (int p0 = 0; p0 < d.n_pos; p0 += NPL) {
+            LogTile t = {i, p0, std::min(NPL, d.n_pos - p0), 0};
+            lt.push_back(t);
+            span_max = std::max(span_max, t.np + Cmax + Lmax);
+        }
+        // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs filling 256 threads
+        const int KC_CAP = 9, NP_CAP = 32;
+        const int nkc = (d.n_sizes + KC_CAP - 1) / KC_CAP;
+        for (int c = 0; c < nkc; c++) {
+            const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
+            const int kc = ki1 - ki0;
+            int np = std::max(1, std::min(NP_CAP, SVR_THREADS / (kc * h->geom.nchunk)));
+            const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
+            const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
+            for (int p0 = 0; p0 < d.n_pos; p0 += np) {
+                const int npt = std::min(np, d.n_pos - p0);
+                for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; st.push_back(t); }
+            }
+            svr_lds = std::max(svr_lds, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group));
+        }
+    }
+    if (svr_lds > 160 * 1024) return fail(MIPGEN_E_INVALID, "SVR tile needs %zu bytes of LDS (> 160 KiB): capture range / arm lists too wide", svr_lds);
+    if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
+        h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
+        h->scores.reserve((size_t)std::max<int64_t>(cand_total, 1)) || h->records.reserve((size_t)std::max<int64_t>(cand_total, 1)))
+        return MIPGEN_E_NOMEM;
+    if (n > 0) HIP_TRY(hipMemcpyAsync(h->regions.p, h->hregions.data(), (size_t)n * sizeof(DevRegion), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->bases.p, hb.data(), hb.size(), hipMemcpyHostToDevice, h->stream));
+    if (copy_total) HIP_TRY(hipMemcpyAsync(h->copy.p, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (unmap_total) HIP_TRY(hipMemcpyAsync(h->unmap.p, hu.data(), hu.size(), hipMemcpyHostToDevice, h->stream));
+    if (!lt.empty()) HIP_TRY(hipMemcpyAsync(h->log_tiles.p, lt.data(), lt.size() * sizeof(LogTile), hipMemcpyHostToDevice, h->stream));
+    if (!st.empty()) HIP_TRY(hipMemcpyAsync(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
+    h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
+    h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds;
+    if (grids_out) memcpy(grids_out, h->grids.data(), (size_t)n * sizeof(mipgen_grid));
+    return MIPGEN_OK;
+}
+
+int64_t mipgen_accel_batch_candidates(const mipgen_accel* h) { return h ? h->n_cand : 0; }
+
+int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (method != MIPGEN_SCORE_LOGISTIC && method != MIPGEN_SCORE_SVR) return fail(MIPGEN_E_INVALID, "method must be logistic or svr");
+    if (h->n_regions <= 0 && h->n_cand == 0 && h->regions.p == nullptr) return fail(MIPGEN_E_STATE, "no resident region batch");
+    if (method == MIPGEN_SCORE_SVR && h->n_sv <= 0 && h->model.p == nullptr) return fail(MIPGEN_E_MODEL, "SVR scoring requested but no model is loaded");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, h->n_log_tiles, h->log_span_max, h->dp, h->regions.p,
+                                           h->log_tiles.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    if (method == MIPGEN_SCORE_SVR) {
+        const double gamma_l2e = h->gamma * 1.4426950408889634074;
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->n_svr_tiles, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
+                                        h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard,
+                                        h->records.p, h->scores.p));
+    }
+    if (h->timing) { HIP_TRY(hipEventRecord(h->ev[2], h->stream)); h->ev_valid = true; }
+    h->scored = true; h->replayed = false;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_result_device_ptrs(const mipgen_accel* h, void** scores_dev, void** records_dev)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (scores_dev) *scores_dev = h->scores.p;
+    if (records_dev) *records_dev = h->records.p;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* records, int64_t first, int64_t count)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (!h->scored) return fail(MIPGEN_E_STATE, "nothing scored yet");
+    if (first < 0 || count < 0 || first + count > h->n_cand) return fail(MIPGEN_E_INVALID, "range [%lld,+%lld) outside the batch (%lld)", (long long)first, (long long)count, (long long)h->n_cand);
+    HIP_TRY(hipSetDevice(h->device));
+    if (count == 0) { HIP_TRY(hipStreamSynchronize(h->stream)); return MIPGEN_OK; }
+    if (scores) HIP_TRY(hipMemcpyAsync(scores, h->scores.p + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (records) HIP_TRY(hipMemcpyAsync(records, h->records.p + first, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_score_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, int32_t method, mipgen_grid* grids_out,
+                               double* scores, uint64_t* records, int64_t capacity)
+{
+    int rc = mipgen_accel_upload_regions(h, regions, n, grids_out);
+    if (rc) return rc;
+    if (h->n_cand > capacity) return fail(MIPGEN_E_INVALID, "result capacity %lld < %lld candidates", (long long)capacity, (long long)h->n_cand);
+    rc = mipgen_accel_score_resident(h, method);
+    if (rc) return rc;
+    return mipgen_accel_download_results(h, scores, records, 0, h->n_cand);
+}
+
+int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands, int32_t n, int32_t method, double* scores,
+                                  uint64_t* records, double* features, mipgen_candidate_ints* ints)
+{
+    if (!h || n < 0 || (n > 0 && !cands)) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (method != MIPGEN_SCORE_LOGISTIC && method != MIPGEN_SCORE_SVR) return fail(MIPGEN_E_INVALID, "method must be logistic or svr");
+    if (h->regions.p == nullptr) return fail(MIPGEN_E_STATE, "no resident region batch");
+    if (method == MIPGEN_SCORE_SVR && h->model.p == nullptr) return fail(MIPGEN_E_MODEL, "SVR scoring requested but no model is loaded");
+    if (n == 0) return MIPGEN_OK;
+    for (int i = 0; i < n; i++) if (cands[i].region < 0 || cands[i].region >= h->n_regions) return fail(MIPGEN_E_INVALID, "candidate %d: region %d not resident", i, cands[i].region);
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->cand_in.reserve((size_t)n) || h->cand_scores.reserve((size_t)n) || h->cand_records.reserve((size_t)n) ||
+        (features && h->cand_feats.reserve((size_t)n * MIPGEN_N_FEATURES)) || (ints && h->cand_ints.reserve((size_t)n)))
+        return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(h->cand_in.p, cands, (size_t)n * sizeof(mipgen_candidate), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(mipgen_launch_candidates(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
+                                     h->model.p, h->n_sv, h->gamma, h->rho, method, h->cand_scores.p, h->cand_records.p,
+                                     features ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
+    if (scores) HIP_TRY(hipMemcpyAsync(scores, h->cand_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (records) HIP_TRY(hipMemcpyAsync(records, h->cand_records.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    if (features) HIP_TRY(hipMemcpyAsync(features, h->cand_feats.p, (size_t)n * MIPGEN_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (ints) HIP_TRY(hipMemcpyAsync(ints, h->cand_ints.p, (size_t)n * sizeof(mipgen_candidate_ints), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_long_range_content(mipgen_accel* h, const char* extended_seq, int32_t len, int32_t chrom_seq_start,
+                                    int32_t chrom_seq_stop, double* out44)
+{
+    if (!h || !extended_seq || len < 0 || !out44) return fail(MIPGEN_E_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    static const char* mers[MIPGEN_N_LRC] = MIPGEN_FEATURE_MERS;
+    LrcMers M;
+    auto code = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
+    for (int i = 0; i < MIPGEN_N_LRC; i++) {
+        const int k = (int)strlen(mers[i]);
+        int cd = 0, rc = 0;
+        for (int j = 0; j < k; j++) cd = cd * 4 + code(mers[i][j]);
+        for (int j = k - 1; j >= 0; j--) rc = rc * 4 + (3 - code(mers[i][j]));
+        M.k[i] = (int8_t)k; M.code[i] = (int8_t)cd; M.rc[i] = (int8_t)(rc == cd ? -1 : rc);
+    }
+    if (h->lrc_seq.reserve((size_t)std::max(len, 1)) || h->lrc_out.reserve(MIPGEN_N_LRC)) return MIPGEN_E_NOMEM;
+    if (len) HIP_TRY(hipMemcpyAsync(h->lrc_seq.p, extended_seq, (size_t)len, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(mipgen_launch_long_range(h->stream, h->lrc_seq.p, len, chrom_seq_stop - chrom_seq_start + 2001, &M, h->lrc_out.p));
+    HIP_TRY(hipMemcpyAsync(out44, h->lrc_out.p, MIPGEN_N_LRC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_replay_condense(mipgen_accel* h)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (!h->scored) return fail(MIPGEN_E_STATE, "replay requested before scoring");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t npos = h->total_pos;
+    if (h->emitted.reserve((size_t)std::max<int64_t>(h->n_cand, 1)) || h->survivors.reserve((size_t)std::max<int64_t>(2 * npos, 1)) ||
+        h->emitted_per_region.reserve((size_t)std::max(h->n_regions, 1)) || h->pos_region.reserve((size_t)std::max<int64_t>(npos, 1)) ||
+        h->pos_local.reserve((size_t)std::max<int64_t>(npos, 1)))
+        return MIPGEN_E_NOMEM;
+    std::vector<int32_t> pr((size_t)npos), pl((size_t)npos);
+    int64_t k = 0;
+    for (int i = 0; i < h->n_regions; i++) for (int p = 0; p < h->hregions[i].n_pos; p++, k++) { pr[(size_t)k] = i; pl[(size_t)k] = p; }
+    if (npos) {
+        HIP_TRY(hipMemcpyAsync(h->pos_region.p, pr.data(), (size_t)npos * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->pos_local.p, pl.data(), (size_t)npos * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipMemsetAsync(h->emitted_per_region.p, 0, (size_t)std::max(h->n_regions, 1) * sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipMemsetAsync(h->emitted.p, 0, (size_t)std::max<int64_t>(h->n_cand, 1), h->stream));
+    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)npos, h->dp, h->regions.p, h->pos_region.p, h->pos_local.p,
+                                          h->scores.p, h->records.p, h->emitted.p, h->survivors.p, h->emitted_per_region.p));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->replayed = true;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity,
+                                 uint8_t* emitted_mask, int64_t mask_capacity)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (!h->replayed) return fail(MIPGEN_E_STATE, "mipgen_accel_replay_condense has not run on these scores");
+    HIP_TRY(hipSetDevice(h->device));
+    if (emitted_per_region && h->n_regions)
+        HIP_TRY(hipMemcpy(emitted_per_region, h->emitted_per_region.p, (size_t)h->n_regions * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (survivors) {
+        if (survivor_capacity < 2 * h->total_pos) return fail(MIPGEN_E_INVALID, "survivor capacity too small");
+        if (h->total_pos) HIP_TRY(hipMemcpy(survivors, h->survivors.p, (size_t)(2 * h->total_pos) * sizeof(mipgen_survivor), hipMemcpyDeviceToHost));
+    }
+    if (emitted_mask) {
+        if (mask_capacity < h->n_cand) return fail(MIPGEN_E_INVALID, "mask capacity too small");
+        if (h->n_cand) HIP_TRY(hipMemcpy(emitted_mask, h->emitted.p, (size_t)h->n_cand, hipMemcpyDeviceToHost));
+    }
+    return MIPGEN_OK;
+}
+
+double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which)
+{
+    if (!h || !h->ev_valid) return -1.0;
+    if (hipSetDevice(h->device) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(h->ev[2]) != hipSuccess) return -1.0;
+    float ms = -1.f;
+    hipError_t e;
+    if (which == 0) e = hipEventElapsedTime(&ms, h->ev[1], h->ev[2]);       // SVR kernel (or ~0 for logistic)
+    else if (which == 2) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);  // records/logistic kernel
+    else e = hipEventElapsedTime(&ms, h->ev[0], h->ev[2]);
+    return e == hipSuccess ? (double)ms : -1.0;
+}
+
+int mipgen_accel_set_timing(mipgen_accel* h, int32_t enabled)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    h->timing = enabled != 0;
+    h->ev_valid = false;
+    return MIPGEN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// common.h — device/host shared definitions for libmipgen_accel (gfx950 only).
+//
+// Data layout in HBM for one resident region batch (see DESIGN.md "Data layout"):
+//   bases   : u8  per base, all regions concatenated:  bits 0-2 base code (A0 C1 G2 T3 N4 '-'5 other6),
+//                 bit 3 = masked-sequence 'N', bits 4-5 = SNP class (0 none / 1 alt ok / 2 alt fails)
+//   copy    : i32 [n_len_slots][seq_len] per region (copy_chr_start_stop slices), or absent (= all 1)
+//   unmap   : u8  [n_sizes_all][seq_len] per region (unmappable_positions slices), or absent
+//   regions : DevRegion[n]
+//   scores  : f64 [batch candidates]   records : u64 [batch candidates]     (dense-grid order, mipgen_accel.h)
+//   model   : f64 [n_sv][SV_ROW]  row = 192 SV values, coef, partial |sv|^2 per feature block
+#pragma once
+#include <stdint.h>
+#include "../../include/mipgen_accel.h"
+
+#define BASE_A 0
+#define BASE_C 1
+#define BASE_G 2
+#define BASE_T 3
+#define BASE_N 4
+#define BASE_DASH 5
+#define BASE_OTHER 6
+#define BASE_CODE_MASK 7
+#define BASE_MASKED_BIT 8
+#define BASE_SNP_SHIFT 4
+
+// feature-vector layout (SVMipv4.cpp:69-112)
+#define F_EXT 0          // 0..20 mers (+GC at 15), 21 = ext length
+#define F_EXT_GC 15
+#define F_EXT_LEN 21
+#define F_LRC 22         // 22..65
+#define F_INS 66         // 66..150 mers (+GC at 129), 151 = scan size
+#define F_INS_GC 129
+#define F_INS_LEN 151
+#define F_LIG 152        // 152..172 mers (+GC at 167), 173 = lig length
+#define F_LIG_GC 167
+#define F_LIG_LEN 173
+#define F_JUNC 174       // 174..189 one-hot
+#define F_LEC 190
+#define F_LLC 191
+
+// model row
+#define SV_ROW 200
+#define SVR_COEF 192
+#define SVR_N_EXT 193    // sum sv_j^2, j in 0..20
+#define SVR_N_INS 194    // j in 66..150
+#define SVR_N_LIG 195    // j in 152..172
+#define SVR_N_JUNC 196   // j in 174..189
+#define SVR_N_TOTAL 197  // all 192 + any libsvm index > 192
+#define SVR_N_EXTRA 198  // libsvm indices > 192 (x has none: they contribute sv^2, svm.cpp:359-363)
+
+struct DevRegion {
+    int64_t out_off;       // first candidate in scores/records
+    int64_t seq_off;       // into bases
+    int64_t copy_off;      // into copy (in int32 units), -1 = all copies 1
+    int64_t unmap_off;     // into unmap, -1 = none
+    int32_t seq_len, seq_start, seq_stop;
+    int32_t start_fl, stop_fl;
+    int32_t first_pos, n_pos;
+    int32_t k0, n_sizes;   // surviving capture sizes k0 .. k0+n_sizes-1
+    int32_t pad;
+    double lrc[MIPGEN_N_LRC];
+};
+
+struct DevParams {
+    int32_t min_capture, max_capture, inc, n_sizes_all;
+    int32_t n_pairs;
+    int32_t check_copy_number;
+    int32_t logistic_heuristic, score_method;
+    int32_t min_sum, max_sum;
+    int32_t e_min, e_max, l_min, l_max;        // arm-length ranges over the pair list
+    int32_t n_len_slots;                        // distinct oligo lengths (copy table slots)
+    int32_t max_arm_copy_product, target_arm_copy;
+    int32_t pad0;
+    double masked_arm_threshold, upper, lower;
+    uint8_t arm_ext[MIPGEN_MAX_ARM_PAIRS];
+    uint8_t arm_lig[MIPGEN_MAX_ARM_PAIRS];
+    int8_t len_slot[MIPGEN_MAX_OLIGO + 1];      // oligo length -> slot in the copy table, -1 unused
+    uint16_t group_end[MIPGEN_MAX_ARM_PAIRS];    // for pair a: index one past the last pair of a's arm-sum list
+};
+
+// one workgroup of the logistic / records kernel: a run of scan-start positions of one region
+struct LogTile {
+    int32_t region;
+    int32_t p0;            // index of first position (0-based within region)
+    int32_t np;
+    int32_t pad;
+};
+
+// one workgroup of the dense SVR kernel
+struct SvrTile {
+    int32_t region;
+    int32_t strand;
+    int32_t p0, np;        // positions (0-based within region)
+    int32_t ki0, kc;       // capture sizes ki0 .. ki0+kc-1 (0-based within the region's surviving list)
+};
+
+// static thread geometry of the dense SVR kernel for a parameter set (computed on the host once)
+struct SvrGeom {
+    int32_t nchunk;        // per-thread chunks of the arm-pair list
+    int32_t chunk_len;     // pairs per chunk (<= SVR_MAX_CHUNK)
+    int32_t n_e, n_l;      // e_max-e_min+1, l_max-l_min+1
+    int32_t group;         // support vectors staged per iteration
+    int32_t pad[3];
+};
+
+// LDS layout of one dense-SVR tile (offsets in doubles unless noted); shared by host sizing and the kernel
+struct SvrLayout {
+    int NI, NUn, NUc, NDn, NDc, rinv, grp;     // SV-independent tables, then the per-SV blocks
+    int row, fi1, fi2, fi3, u1, u2, d1, d2, tu, td, ci, stride;   // inside one per-SV block
+    int bytes_jU, bytes_jD, bytes_sb;          // byte offsets of the u8 arrays
+    int total_bytes;
+    int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
+};
+
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group)
+{
+    SvrLayout L;
+    const int ssr = ssmax - ssmin + 1;
+    L.nq = np + ssr - 1;
+    L.ins_len = np + ssmax;                 // insert prefix arrays cover positions [p_first, p_first + ins_len)
+    L.up_cnt = Lmax + np;
+    L.dn_cnt = L.nq + Lmax;
+    L.span_b = np + ssmax + 2 * Lmax + 1;
+    L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
+    int o = 0;
+    L.NI = o; o += np * ssr;
+    L.NUn = o; o += np * n_arm; L.NUc = o; o += np * n_arm;
+    L.NDn = o; o += L.nq * n_arm; L.NDc = o; o += L.nq * n_arm;
+    L.rinv = o; o += L.rinv_len;
+    L.grp = o;
+    int g = 0;
+    L.row = g; g += SV_ROW;
+    L.fi1 = g; g += L.ins_len + 1; L.fi2 = g; g += L.ins_len + 1; L.fi3 = g; g += L.ins_len + 1;
+    L.u1 = g; g += L.up_cnt + 1; L.u2 = g; g += L.up_cnt + 1;
+    L.d1 = g; g += L.dn_cnt + 1; L.d2 = g; g += L.dn_cnt + 1;
+    L.tu = g; g += np * n_arm;
+    L.td = g; g += L.nq * n_arm;
+    L.ci = g; g += 2;
+    L.stride = g;
+    // the phase-0c scratch (np * 80 u16 counters) aliases the per-SV area
+    int grp_doubles = group * L.stride;
+    const int scratch_doubles = (np * 80 * 2 + 7) / 8;
+    if (grp_doubles < scratch_doubles) grp_doubles = scratch_doubles;
+    o += grp_doubles;
+    int bytes = o * 8;
+    L.bytes_jU = bytes; bytes += np * n_arm;
+    L.bytes_jD = bytes; bytes += L.nq * n_arm;
+    L.bytes_sb = bytes; bytes += L.span_b + 8;
+    L.total_bytes = (bytes + 15) & ~15;
+    return L;
+}
+
+#define SVR_MAX_CHUNK 20
+#define SVR_THREADS 256
+#define LOG_THREADS 256

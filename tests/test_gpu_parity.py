@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libmipgen_accel.so), against the oracle and the
+committed golden vectors.  Integer fields bit-exact; logistic / SVR scores within 1e-5 (BASELINE.json north_star).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mipgen_amd import capi, synth
+from oracle import pyoracle as po
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5          # score tolerance stated by BASELINE.json north_star
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a), np.asarray(b)
+    nan_ok = np.isnan(a) & np.isnan(b)
+    inf_ok = np.isinf(a) & (a == b)
+    with np.errstate(invalid="ignore"):
+        d = np.abs(a - b)
+    ok = nan_ok | inf_ok | (d <= tol)
+    return ok, np.nanmax(np.where(nan_ok | inf_ok, 0.0, d)) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def genome():
+    return H.golden_genome()
+
+
+def _model_path(meta):
+    return os.path.join(H.GOLDEN, "models", meta["model"]) if meta["model"] else os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+
+
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small", "logistic_default_arms"])
+@pytest.mark.parametrize("method", [capi.SCORE_LOGISTIC, capi.SCORE_SVR])
+def test_dense_grid_vs_oracle(name, method, genome):
+    """Every dense-grid candidate of the golden designs: records bit-exact, scores within 1e-5."""
+    meta = H.load_design(name)
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    mp = _model_path(meta)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    grids, scores, records = acc.score_regions(regions, method)
+    n_guard = 0
+    for rd, g in zip(regions, grids):
+        og, os_, or_ = po.score_region_dense(P, rd, method, om)
+        assert (g.first_pos, g.n_pos, g.first_size_index, g.n_sizes, g.count) == (og.first_pos, og.n_pos, og.first_size_index, og.n_sizes, og.count)
+        s = scores[g.offset:g.offset + g.count]
+        r = records[g.offset:g.offset + g.count]
+        bad = np.nonzero(r != or_)[0]
+        assert bad.size == 0, (name, "first differing record", int(bad[0]), hex(int(r[bad[0]])), hex(int(or_[bad[0]])))
+        ok, mx = _close(s, os_)
+        assert ok.all(), (name, method, "max |diff|", mx, "at", int(np.nonzero(~ok)[0][0]))
+        if method == capi.SCORE_LOGISTIC:
+            guard = (capi.rec_flags(r) & capi.FLAG_GUARD) != 0
+            assert np.all(s[guard & ((capi.rec_flags(r) & capi.FLAG_VALID) != 0)] == -1000.0)
+            n_guard += int(guard.sum())
+    acc.close()
+
+
+def _region_for_candidate(c, lrc, P):
+    """Embed one golden known-answer candidate (raw forward-strand strings) in a synthetic region."""
+    ext, lig, ins = c["ext_fwd"].encode(), c["lig_fwd"].encode(), c["ins_fwd"].encode()
+    pad = b"ACGT" * 20
+    up, down = (ext, lig) if c["strand"] == 0 else (lig, ext)
+    seq = pad + up + ins + down + pad
+    seq_start = 1000
+    p = seq_start + len(pad) + len(up)
+    n = len(seq)
+    copy = {}
+    for ln in {len(ext), len(lig)}:
+        copy[ln] = np.ones(n, dtype=np.int32)
+    ext_start = p - len(ext) if c["strand"] == 0 else p + len(ins)
+    lig_start = p + len(ins) if c["strand"] == 0 else p - len(lig)
+    # when both arms have the same length and the same start cannot happen; distinct starts always
+    copy[len(ext)][ext_start - seq_start] = c["ext_copy"]
+    copy[len(lig)][lig_start - seq_start] = c["lig_copy"]
+    rd = capi.RegionData(p, p + 10, seq_start, seq, copy=copy, lrc=lrc)
+    cand = (0, p, len(ext) + len(lig) + len(ins), len(ext), len(lig), c["strand"])
+    return rd, cand
+
+
+def test_sparse_candidates_vs_golden_known_answers():
+    """mipgen_accel_score_candidates against the reference's own known answers (tests/golden/candidates.*):
+    the 192 features bit-exact (integer counts / integer denominators), logistic and SVR within 1e-5."""
+    with open(os.path.join(H.GOLDEN, "candidates.json")) as fh:
+        meta = json.load(fh)
+    z = np.load(os.path.join(H.GOLDEN, "candidates.npz"))
+    n_checked = 0
+    for model_name, key in (("svr_syn_64.model", "svr64"), ("svr_syn_200.model", "svr200")):
+        for i, c in enumerate(meta["candidates"]):
+            if any(ch not in "ACGTN" for ch in c["ext_fwd"] + c["lig_fwd"]):
+                continue
+            if i % 2 == (0 if key == "svr64" else 1) and i > 60:
+                continue                                    # alternate candidates between the two models to bound run time
+            e, l = len(c["ext_fwd"]), len(c["lig_fwd"])
+            P = capi.make_params(100, 400, score_method=capi.SCORE_SVR, arm_pairs=[(e, l)])
+            rd, cand = _region_for_candidate(c, z["lrc"][i], P)
+            acc = capi.Accel(P)
+            acc.load_model_file(os.path.join(H.GOLDEN, "models", model_name))
+            acc.upload([rd])
+            s_svr, rec, feats, ints = acc.score_candidates([cand], capi.SCORE_SVR, want_features=True, want_ints=True)
+            s_log, _, _, _ = acc.score_candidates([cand], capi.SCORE_LOGISTIC)
+            acc.close()
+            assert np.array_equal(feats[0], z["params"][i], equal_nan=True), (i, np.nonzero(feats[0] != z["params"][i]))
+            ok, mx = _close(s_log, [z["logistic"][i]])
+            assert ok.all(), ("logistic", i, s_log[0], z["logistic"][i])
+            ok, mx = _close(s_svr, [z[key][i]])
+            assert ok.all(), ("svr", key, i, s_svr[0], z[key][i])
+            # integer fields against the oracle's restatement
+            oe, ol, oi = po.orient(c["strand"], c["ext_fwd"].encode(), c["lig_fwd"].encode(), c["ins_fwd"].encode())
+            _, oints = po.get_score(oe, ol, oi, c["ext_copy"], c["lig_copy"])
+            for f in ("ext_a", "ext_c", "ext_g", "ext_t", "lig_a", "lig_c", "lig_g", "lig_t", "ins_a", "ins_c", "ins_g", "ins_t",
+                      "run_count", "junction", "ext_copy", "lig_copy", "scan_size"):
+                assert getattr(ints[0], f) == getattr(oints, f), (i, f)
+            n_checked += 1
+    assert n_checked > 100
+
+
+def test_long_range_content_vs_golden(genome):
+    with open(os.path.join(H.GOLDEN, "candidates.json")) as fh:
+        meta = json.load(fh)
+    z = np.load(os.path.join(H.GOLDEN, "candidates.npz"))
+    P = capi.make_params(120, 130)
+    acc = capi.Accel(P)
+    for i, lr in enumerate(meta["long_range"]):
+        seq = genome[lr["offset"]:lr["offset"] + lr["len"]]
+        got = acc.long_range_content(seq, lr["chrom_seq_start"], lr["chrom_seq_stop"])
+        assert np.array_equal(got, z["lr_out"][i])       # integer counts / integer denominator: bit-exact
+    acc.close()
+
+
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small", "logistic_default_arms"])
+def test_replay_condense_vs_oracle(name, genome):
+    """Device replay of the early exits + condense fold == the oracle's, fed with the device's own scores."""
+    meta = H.load_design(name)
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
+    acc = capi.Accel(P)
+    if meta["model"]:
+        acc.load_model_file(_model_path(meta))
+    grids, scores, records = acc.score_regions(regions, method)
+    acc.replay_condense()
+    emitted, surv, mask = acc.download_replay()
+    pos0 = 0
+    total = 0
+    for ri, (rd, g) in enumerate(zip(regions, grids)):
+        s = scores[g.offset:g.offset + g.count]
+        r = records[g.offset:g.offset + g.count]
+        n_emit, omask = po.replay_region(P, rd, s, r)
+        assert emitted[ri] == n_emit
+        assert np.array_equal(mask[g.offset:g.offset + g.count], omask)
+        osurv = po.condense_region(P, rd, s, r, omask)
+        got = surv[2 * pos0:2 * (pos0 + g.n_pos)]
+        exp_idx = np.where(osurv["cand_index"] >= 0, osurv["cand_index"] + g.offset, -1)
+        assert np.array_equal(got["cand_index"], exp_idx)
+        assert np.array_equal(got["score"], osurv["score"], equal_nan=True)
+        assert np.array_equal(got["record"], osurv["record"])
+        pos0 += g.n_pos
+        total += n_emit
+    # with the device's scores the emitted count equals the reference's all_mips line count
+    assert total == meta["lines"]["all_mips"] - 1
+    acc.close()
+
+
+def test_edge_cases(genome):
+    """Empty batch, ragged capture-size sets (static skip), the widest capture sweep (120-250, K=27), regions at the
+    chromosome start (bounds skips), copy 0 / 100 / 101, N runs."""
+    P = capi.make_params(120, 250, score_method=capi.SCORE_SVR)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    # empty batch
+    grids, scores, records = acc.score_regions([], capi.SCORE_LOGISTIC)
+    assert len(grids) == 0 and scores.size == 0
+    # ragged: a 40-bp region keeps few sizes, a 260-bp one keeps all 27; one region hugging the chromosome start
+    regs = [capi.build_region(genome, "1", 3000, 3040, P, bwa_mode="hashed", label="short", lrc=np.full(44, 0.1)),
+            capi.build_region(genome, "1", 6000, 6260, P, bwa_mode="hashed", label="long", lrc=np.full(44, 0.2)),
+            capi.build_region(genome, "1", 150, 200, P, bwa_mode="hashed", label="edge", lrc=np.full(44, 0.05))]
+    for method in (capi.SCORE_LOGISTIC, capi.SCORE_SVR):
+        grids, scores, records = acc.score_regions(regs, method)
+        assert grids[0].n_sizes < grids[1].n_sizes == 27
+        rng = np.random.default_rng(3)
+        for rd, g in zip(regs, grids):
+            _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_LOGISTIC, om)        # records (method independent)
+            r = records[g.offset:g.offset + g.count]
+            assert np.array_equal(r, or_)
+            if method == capi.SCORE_LOGISTIC:
+                ok, mx = _close(scores[g.offset:g.offset + g.count], os_)
+                assert ok.all(), mx
+            else:
+                # the oracle's SVR is slow: check a random sample of 1500 candidates + every guard / zero-copy one
+                valid = np.nonzero((capi.rec_flags(r) & capi.FLAG_VALID) != 0)[0]
+                special = valid[((capi.rec_flags(r[valid]) & capi.FLAG_GUARD) != 0) | (capi.rec_ext_copy(r[valid]) == 0) |
+                                (capi.rec_lig_copy(r[valid]) == 0)][:300]
+                pick = np.unique(np.concatenate([rng.choice(valid, size=min(1500, valid.size), replace=False), special]))
+                A = P.n_arm_pairs
+                for idx in pick:
+                    strand = idx & 1
+                    a = (idx >> 1) % A
+                    rest = (idx >> 1) // A
+                    ki, pi = rest % g.n_sizes, rest // g.n_sizes
+                    cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment,
+                            P.arm_ext[a], P.arm_lig[a], int(strand))
+                    sk, d = po.design(P, rd, cand)
+                    assert not sk
+                    so, _, _ = po.score_designed(d, capi.SCORE_SVR, np.array(rd.c.long_range_content[:]), om)
+                    ok, mx = _close([scores[g.offset + idx]], [so])
+                    assert ok.all(), (rd.label, cand, scores[g.offset + idx], so)
+        # invalid (bounds-skipped) candidates exist only in the chromosome-start region
+        assert ((capi.rec_flags(records[grids[2].offset:grids[2].offset + grids[2].count]) & capi.FLAG_VALID) == 0).any()
+    acc.close()
+
+
+def test_error_paths(genome):
+    lib = capi.load_library()
+    P = capi.make_params(120, 130)
+    acc = capi.Accel(P)
+    with pytest.raises(capi.AccelError):
+        acc.load_model_file("/nonexistent/mipgen_svr.model")          # the reference would segfault (svm.cpp:2507)
+    rd = capi.build_region(genome, "1", 5000, 5050, P)
+    acc.upload([rd])
+    with pytest.raises(capi.AccelError):
+        acc.score_resident(capi.SCORE_SVR)                              # no model loaded
+    with pytest.raises(capi.AccelError):
+        acc.download()                                                  # nothing scored
+    bad = capi.make_params(120, 130)
+    bad.abi_version = 99
+    with pytest.raises(capi.AccelError):
+        capi.Accel(bad)
+    acc.close()
+    assert lib.mipgen_accel_device_count() >= 1
