@@ -86,7 +86,7 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
     for (uint32_t idx = tid; idx < n_cand; idx += LOG_THREADS) {
         uint32_t rc = fastdiv(idx, M_row);                     // (pl, ki)
         uint32_t in_row = idx - rc * row;
-        uint32_t pl = fastdiv(rc, M_k);
+        uint32_t pl = nK == 1 ? rc : fastdiv(rc, M_k);            // the magic constant overflows for divisor 1
         uint32_t ki = rc - pl * (uint32_t)nK;
         const int a = (int)(in_row >> 1);
         const bool minus = in_row & 1;
