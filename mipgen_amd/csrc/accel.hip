@@ -22,8 +22,8 @@ size_t mipgen_logistic_lds_bytes(int span);
 hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, int span_max, const DevParams*, const DevRegion*,
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
                                           double*, uint64_t*);
-size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group);
-hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int n_tiles, size_t lds_bytes, const DevParams*, const SvrGeom*,
+size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l);
+hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
                                    const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
                                    const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
                                    const uint64_t* records, double* scores);
@@ -220,7 +220,10 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     G.nchunk = (D.n_pairs + SVR_MAX_CHUNK - 1) / SVR_MAX_CHUNK;
     G.chunk_len = (D.n_pairs + G.nchunk - 1) / G.nchunk;
     G.n_e = D.e_max - D.e_min + 1; G.n_l = D.l_max - D.l_min + 1;
-    G.group = 2;
+    G.group = SVR_GROUP;
+    G.wpc = 2;
+    while (G.wpc > 1 && G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) G.wpc--;
+    if (G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) { delete h; return fail(MIPGEN_E_INVALID, "too many arm pairs for the dense SVR kernel (max %d)", SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64)); }
 
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
@@ -287,9 +290,7 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
     h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho; h->sum_abs_coef = sum_abs;
     // smallest exp2 polynomial whose error, amplified by sum|coef|, stays below 1e-7 (gate: 1e-5)
     const double budget = 1e-7;
-    if (sum_abs * 2.6e-9 <= budget) h->exp_deg = 6;
-    else if (sum_abs * 5.6e-11 <= budget) h->exp_deg = 7;
-    else if (sum_abs * 1.1e-12 <= budget) h->exp_deg = 8;
+    if (sum_abs * 5.6e-11 <= budget) h->exp_deg = 7;
     else h->exp_deg = 10;
     if (const char* f = getenv("MIPGEN_ACCEL_EXP_DEG")) h->exp_deg = atoi(f);
     return MIPGEN_OK;
@@ -439,7 +440,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     const int Lmax = std::max(D.e_max, D.l_max);
     int span_max = 0;
     size_t svr_lds = 0;
-    const int n_arm = std::max(h->geom.n_e, h->geom.n_l);
+    const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
     for (int i = 0; i < n; i++) {
         const DevRegion& d = h->hregions[i];
         if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
@@ -456,14 +457,14 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         for (int c = 0; c < nkc; c++) {
             const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
             const int kc = ki1 - ki0;
-            int np = std::max(1, std::min(NP_CAP, SVR_THREADS / (kc * h->geom.nchunk)));
+            int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
             const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
             const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
             for (int p0 = 0; p0 < d.n_pos; p0 += np) {
                 const int npt = std::min(np, d.n_pos - p0);
                 for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; st.push_back(t); }
             }
-            svr_lds = std::max(svr_lds, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group));
+            svr_lds = std::max(svr_lds, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
         }
     }
     if (svr_lds > 160 * 1024) return fail(MIPGEN_E_INVALID, "SVR tile needs %zu bytes of LDS (> 160 KiB): capture range / arm lists too wide", svr_lds);
@@ -471,6 +472,19 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
         h->scores.reserve((size_t)std::max<int64_t>(cand_total, 1)) || h->records.reserve((size_t)std::max<int64_t>(cand_total, 1)))
         return MIPGEN_E_NOMEM;
+    if (h->emitted.reserve((size_t)std::max<int64_t>(cand_total, 1)) || h->survivors.reserve((size_t)std::max<int64_t>(2 * pos_total, 1)) ||
+        h->emitted_per_region.reserve((size_t)std::max(n, 1)) || h->pos_region.reserve((size_t)std::max<int64_t>(pos_total, 1)) ||
+        h->pos_local.reserve((size_t)std::max<int64_t>(pos_total, 1)))
+        return MIPGEN_E_NOMEM;
+    std::vector<int32_t> pr((size_t)pos_total), pl((size_t)pos_total);
+    {
+        int64_t k = 0;
+        for (int i = 0; i < n; i++) for (int p = 0; p < h->hregions[i].n_pos; p++, k++) { pr[(size_t)k] = i; pl[(size_t)k] = p; }
+    }
+    if (pos_total) {
+        HIP_TRY(hipMemcpyAsync(h->pos_region.p, pr.data(), (size_t)pos_total * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->pos_local.p, pl.data(), (size_t)pos_total * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    }
     if (n > 0) HIP_TRY(hipMemcpyAsync(h->regions.p, h->hregions.data(), (size_t)n * sizeof(DevRegion), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->bases.p, hb.data(), hb.size(), hipMemcpyHostToDevice, h->stream));
     if (copy_total) HIP_TRY(hipMemcpyAsync(h->copy.p, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
@@ -499,7 +513,7 @@ int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     if (method == MIPGEN_SCORE_SVR) {
         const double gamma_l2e = h->gamma * 1.4426950408889634074;
-        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->n_svr_tiles, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
                                         h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard,
                                         h->records.p, h->scores.p));
     }
@@ -593,23 +607,12 @@ int mipgen_accel_replay_condense(mipgen_accel* h)
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
     if (!h->scored) return fail(MIPGEN_E_STATE, "replay requested before scoring");
     HIP_TRY(hipSetDevice(h->device));
-    const int64_t npos = h->total_pos;
-    if (h->emitted.reserve((size_t)std::max<int64_t>(h->n_cand, 1)) || h->survivors.reserve((size_t)std::max<int64_t>(2 * npos, 1)) ||
-        h->emitted_per_region.reserve((size_t)std::max(h->n_regions, 1)) || h->pos_region.reserve((size_t)std::max<int64_t>(npos, 1)) ||
-        h->pos_local.reserve((size_t)std::max<int64_t>(npos, 1)))
-        return MIPGEN_E_NOMEM;
-    std::vector<int32_t> pr((size_t)npos), pl((size_t)npos);
-    int64_t k = 0;
-    for (int i = 0; i < h->n_regions; i++) for (int p = 0; p < h->hregions[i].n_pos; p++, k++) { pr[(size_t)k] = i; pl[(size_t)k] = p; }
-    if (npos) {
-        HIP_TRY(hipMemcpyAsync(h->pos_region.p, pr.data(), (size_t)npos * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->pos_local.p, pl.data(), (size_t)npos * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    }
+    // asynchronous on the handle's stream; buffers and the position map were laid out at upload
     HIP_TRY(hipMemsetAsync(h->emitted_per_region.p, 0, (size_t)std::max(h->n_regions, 1) * sizeof(unsigned long long), h->stream));
     HIP_TRY(hipMemsetAsync(h->emitted.p, 0, (size_t)std::max<int64_t>(h->n_cand, 1), h->stream));
-    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)npos, h->dp, h->regions.p, h->pos_region.p, h->pos_local.p,
+    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)h->total_pos, h->dp, h->regions.p, h->pos_region.p, h->pos_local.p,
                                           h->scores.p, h->records.p, h->emitted.p, h->survivors.p, h->emitted_per_region.p));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     h->replayed = true;
     return MIPGEN_OK;
 }
@@ -620,6 +623,7 @@ int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, m
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
     if (!h->replayed) return fail(MIPGEN_E_STATE, "mipgen_accel_replay_condense has not run on these scores");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     if (emitted_per_region && h->n_regions)
         HIP_TRY(hipMemcpy(emitted_per_region, h->emitted_per_region.p, (size_t)h->n_regions * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (survivors) {
@@ -642,6 +646,7 @@ double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which)
     hipError_t e;
     if (which == 0) e = hipEventElapsedTime(&ms, h->ev[1], h->ev[2]);       // SVR kernel (or ~0 for logistic)
     else if (which == 2) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);  // records/logistic kernel
+    else if (which == 3) { if (hipEventSynchronize(h->ev[3]) != hipSuccess) return -1.0; e = hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); }  // replay+condense
     else e = hipEventElapsedTime(&ms, h->ev[0], h->ev[2]);
     return e == hipSuccess ? (double)ms : -1.0;
 }

@@ -100,22 +100,30 @@ struct SvrGeom {
     int32_t chunk_len;     // pairs per chunk (<= SVR_MAX_CHUNK)
     int32_t n_e, n_l;      // e_max-e_min+1, l_max-l_min+1
     int32_t group;         // support vectors staged per iteration
-    int32_t pad[3];
+    int32_t wpc;           // waves per arm-pair chunk (block = nchunk * wpc waves)
+    int32_t pad[2];
 };
 
 // LDS layout of one dense-SVR tile (offsets in doubles unless noted); shared by host sizing and the kernel
+#define SVR_N_ARR 7          // prefix arrays per support vector: insert 1/2/3-mers, upstream arm 1/2-mers, downstream arm 1/2-mers
 struct SvrLayout {
-    int NI, NUn, NUc, NDn, NDc, rinv, grp;     // SV-independent tables, then the per-SV blocks
-    int row, fi1, fi2, fi3, u1, u2, d1, d2, tu, td, ci, stride;   // inside one per-SV block
-    int bytes_jU, bytes_jD, bytes_sb;          // byte offsets of the u8 arrays
+    int NI, rinv, lg10, ent_n, rows, grp;             // SV-independent: insert norms, reciprocals, log10(0..100); SV rows (2 x group); per-SV blocks
+    int arr[SVR_N_ARR];                        // inside one per-SV block: the seven prefix arrays (len+1 slots each)
+    int arr_len[SVR_N_ARR];                    // elements per array (without the trailing total slot)
+    int tu, td, ku, kd, ci, stride;            // partial-distance tables, per-length constants, insert constant
+    int bytes_desc, bytes_ent, bytes_sb;       // byte offsets: scan descriptors (int), table-entry descriptors (2 x u32), bases (u8)
+    int n_ent;                                 // partial-distance table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
+    int chunk[2];                              // slots per lane of the two fused wave scans (part 0: insert arrays 0..2, part 1: arm arrays 3..6)
+    int lane0[SVR_N_ARR];                      // first lane of each array inside its part's wavefront
+    int lane1[SVR_N_ARR];                      // one past the last lane
 };
 
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group)
+static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group, int n_up, int n_dn)
 {
     SvrLayout L;
     const int ssr = ssmax - ssmin + 1;
@@ -127,32 +135,51 @@ static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n
     L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
     int o = 0;
     L.NI = o; o += np * ssr;
-    L.NUn = o; o += np * n_arm; L.NUc = o; o += np * n_arm;
-    L.NDn = o; o += L.nq * n_arm; L.NDc = o; o += L.nq * n_arm;
     L.rinv = o; o += L.rinv_len;
+    L.lg10 = o; o += 102;
+    L.n_ent = np * n_up + L.nq * n_dn;
+    L.ent_n = o; o += L.n_ent;
+    L.rows = o; o += 2 * group * SV_ROW;
     L.grp = o;
     int g = 0;
-    L.row = g; g += SV_ROW;
-    L.fi1 = g; g += L.ins_len + 1; L.fi2 = g; g += L.ins_len + 1; L.fi3 = g; g += L.ins_len + 1;
-    L.u1 = g; g += L.up_cnt + 1; L.u2 = g; g += L.up_cnt + 1;
-    L.d1 = g; g += L.dn_cnt + 1; L.d2 = g; g += L.dn_cnt + 1;
+    for (int k = 0; k < SVR_N_ARR; k++) {
+        L.arr_len[k] = k < 3 ? L.ins_len : (k < 5 ? L.up_cnt : L.dn_cnt);
+        L.arr[k] = g; g += L.arr_len[k] + 1;
+    }
     L.tu = g; g += np * n_arm;
     L.td = g; g += L.nq * n_arm;
+    L.ku = g; g += n_arm; L.kd = g; g += n_arm;
     L.ci = g; g += 2;
     L.stride = g;
-    // the phase-0c scratch (np * 80 u16 counters) aliases the per-SV area
+    // the phase-0 scratch (np * 80 u16 counters) aliases the per-SV area
     int grp_doubles = group * L.stride;
     const int scratch_doubles = (np * 80 * 2 + 7) / 8;
     if (grp_doubles < scratch_doubles) grp_doubles = scratch_doubles;
     o += grp_doubles;
     int bytes = o * 8;
-    L.bytes_jU = bytes; bytes += np * n_arm;
-    L.bytes_jD = bytes; bytes += L.nq * n_arm;
+    L.bytes_desc = bytes; bytes += SVR_N_ARR * 16 * 4;
+    L.bytes_ent = bytes; bytes += 2 * L.n_ent * 4;
     L.bytes_sb = bytes; bytes += L.span_b + 8;
     L.total_bytes = (bytes + 15) & ~15;
+    // fused scans: each array gets whole lanes of its part's wavefront; every lane owns `chunk` consecutive slots
+    for (int part = 0; part < 2; part++) {
+        const int k0 = part == 0 ? 0 : 3, k1 = part == 0 ? 3 : SVR_N_ARR;
+        int total = 0;
+        for (int k = k0; k < k1; k++) total += L.arr_len[k] + 1;
+        int c = (total + 63) / 64;
+        for (;; c++) {
+            int lanes = 0;
+            for (int k = k0; k < k1; k++) lanes += (L.arr_len[k] + 1 + c - 1) / c;
+            if (lanes <= 64) break;
+        }
+        L.chunk[part] = c;
+        int l0 = 0;
+        for (int k = k0; k < k1; k++) { L.lane0[k] = l0; l0 += (L.arr_len[k] + 1 + c - 1) / c; L.lane1[k] = l0; }
+    }
     return L;
 }
 
 #define SVR_MAX_CHUNK 20
-#define SVR_THREADS 256
+#define SVR_GROUP 3            // support vectors staged (and interleaved in the candidate loop) per iteration
+#define SVR_MAX_THREADS 512   // nchunk * wpc * 64 <= 512
 #define LOG_THREADS 256
