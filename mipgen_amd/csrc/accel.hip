@@ -220,8 +220,17 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     G.nchunk = (D.n_pairs + SVR_MAX_CHUNK - 1) / SVR_MAX_CHUNK;
     G.chunk_len = (D.n_pairs + G.nchunk - 1) / G.nchunk;
     G.n_e = D.e_max - D.e_min + 1; G.n_l = D.l_max - D.l_min + 1;
+    for (int c = 0; c < G.nchunk; c++) {                     // arm-sum lists touched by one chunk of pairs
+        int lists = 0, prev = -1;
+        for (int i = c * G.chunk_len; i < std::min(D.n_pairs, (c + 1) * G.chunk_len); i++) {
+            const int sum = D.arm_ext[i] + D.arm_lig[i];
+            if (sum != prev) { lists++; prev = sum; }
+        }
+        if (lists > SVR_MAX_LISTS) { delete h; return fail(MIPGEN_E_INVALID, "arm-pair list too fragmented for the dense SVR kernel: %d arm sums within %d consecutive pairs (max %d)", lists, G.chunk_len, SVR_MAX_LISTS); }
+    }
     G.group = SVR_GROUP;
-    G.wpc = 2;
+    G.wpc = 4;
+    if (const char* e = getenv("MIPGEN_ACCEL_SVR_WPC")) G.wpc = std::max(1, atoi(e));   // tuning knob: waves per arm-pair chunk
     while (G.wpc > 1 && G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) G.wpc--;
     if (G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) { delete h; return fail(MIPGEN_E_INVALID, "too many arm pairs for the dense SVR kernel (max %d)", SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64)); }
 
@@ -464,6 +473,13 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                 const int npt = std::min(np, d.n_pos - p0);
                 for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; st.push_back(t); }
             }
+            {
+                const SvrLayout Lt = svr_layout(np, ssmin, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
+                int cmax = 0;
+                for (int k = 0; k < SVR_N_ARR; k++) cmax = std::max(cmax, Lt.chunk[k]);
+                if (cmax > SVR_CW_MAX)
+                    return fail(MIPGEN_E_INVALID, "capture range too wide for the dense SVR kernel: %d prefix slots per lane (max %d)", cmax, SVR_CW_MAX);
+            }
             svr_lds = std::max(svr_lds, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
         }
     }
@@ -494,6 +510,9 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
     h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds;
+    if (getenv("MIPGEN_ACCEL_VERBOSE"))
+        fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates, %d record tiles (LDS %zu B), %d SVR tiles x %d threads (LDS %zu B)\n", n,
+                (long long)cand_total, h->n_log_tiles, mipgen_logistic_lds_bytes(span_max), h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, svr_lds);
     if (grids_out) memcpy(grids_out, h->grids.data(), (size_t)n * sizeof(mipgen_grid));
     return MIPGEN_OK;
 }

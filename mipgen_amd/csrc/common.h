@@ -46,7 +46,8 @@
 #define SVR_N_LIG 195    // j in 152..172
 #define SVR_N_JUNC 196   // j in 174..189
 #define SVR_N_TOTAL 197  // all 192 + any libsvm index > 192
-#define SVR_N_EXTRA 198  // libsvm indices > 192 (x has none: they contribute sv^2, svm.cpp:359-363)
+#define SVR_N_EXTRA 198
+#define SVR_ZERO 199       // always 0.0: target of "no contribution" gathers  // libsvm indices > 192 (x has none: they contribute sv^2, svm.cpp:359-363)
 
 struct DevRegion {
     int64_t out_off;       // first candidate in scores/records
@@ -104,20 +105,34 @@ struct SvrGeom {
     int32_t pad[2];
 };
 
-// LDS layout of one dense-SVR tile (offsets in doubles unless noted); shared by host sizing and the kernel
+#define SVR_MAX_CHUNK 20
+#define SVR_CW_MAX 6           // max prefix-array slots per lane in the fused scans (host checks)
+#define SVR_TB 2               // table entries per thread per batch
+#define SVR_MAX_LISTS 3        // arm-sum lists a wave's chunk of <= 20 pairs may touch (host checks)
+#define SVR_GROUP 3            // support vectors staged (and interleaved in the candidate loop) per iteration
+#define SVR_MAX_THREADS 768   // nchunk * wpc * 64 <= 768 (12 waves = 3 per SIMD at <= 168 VGPRs)
+#define LOG_THREADS 256
+
+// LDS layout of one dense-SVR tile (offsets in doubles unless noted); shared by host sizing and the kernel.
+// The SV loop is software pipelined over groups of SVR_GROUP support vectors:
+//     scan(k)    writes PF[k % 2]   (seven prefix arrays + per-length constants + insert constant of each SV of the group)
+//     tables(k)  reads  PF[k % 2], writes TB[k % 2]   (partial distances of the upstream / downstream arm windows)
+//     accumulate(k) reads TB[k % 2]  (and latches its insert partials from PF[k % 2] one barrier earlier)
+// rows[k % 3] holds the group's SV rows.
 #define SVR_N_ARR 7          // prefix arrays per support vector: insert 1/2/3-mers, upstream arm 1/2-mers, downstream arm 1/2-mers
 struct SvrLayout {
-    int NI, rinv, lg10, ent_n, rows, grp;             // SV-independent: insert norms, reciprocals, log10(0..100); SV rows (2 x group); per-SV blocks
-    int arr[SVR_N_ARR];                        // inside one per-SV block: the seven prefix arrays (len+1 slots each)
+    int NI, rinv, lg10, rows, pf, tb;          // SV-independent: insert norms, reciprocals, log10(0..100); then the buffers
+    int arr[SVR_N_ARR];                        // inside one per-SV PF block: the seven prefix arrays (len+1 slots each)
     int arr_len[SVR_N_ARR];                    // elements per array (without the trailing total slot)
-    int tu, td, ku, kd, ci, stride;            // partial-distance tables, per-length constants, insert constant
-    int bytes_desc, bytes_ent, bytes_sb;       // byte offsets: scan descriptors (int), table-entry descriptors (2 x u32), bases (u8)
+    int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; doubles per SV
+    int tu, td, tb_stride;                     // TB block: partial-distance tables; doubles per SV
+    int bytes_desc, bytes_ent, bytes_idx, bytes_sb;   // byte offsets: scan descriptors (int), table-entry descriptors (3 x u32),
+                                               // per-slot SV-row indices of the scans (u16), bases (u8)
+    int idx_off[SVR_N_ARR];                    // first u16 of each array in the index table
     int n_ent;                                 // partial-distance table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
-    int chunk[2];                              // slots per lane of the two fused wave scans (part 0: insert arrays 0..2, part 1: arm arrays 3..6)
-    int lane0[SVR_N_ARR];                      // first lane of each array inside its part's wavefront
-    int lane1[SVR_N_ARR];                      // one past the last lane
+    int chunk[SVR_N_ARR];                      // prefix-array slots per lane in that array's scan unit (<= SVR_CW_MAX)
 };
 
 #if defined(__HIPCC__)
@@ -138,48 +153,37 @@ static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n
     L.rinv = o; o += L.rinv_len;
     L.lg10 = o; o += 102;
     L.n_ent = np * n_up + L.nq * n_dn;
-    L.ent_n = o; o += L.n_ent;
-    L.rows = o; o += 2 * group * SV_ROW;
-    L.grp = o;
+    L.rows = o; o += 3 * group * SV_ROW;
     int g = 0;
     for (int k = 0; k < SVR_N_ARR; k++) {
         L.arr_len[k] = k < 3 ? L.ins_len : (k < 5 ? L.up_cnt : L.dn_cnt);
         L.arr[k] = g; g += L.arr_len[k] + 1;
     }
-    L.tu = g; g += np * n_arm;
-    L.td = g; g += L.nq * n_arm;
     L.ku = g; g += n_arm; L.kd = g; g += n_arm;
     L.ci = g; g += 2;
-    L.stride = g;
-    // the phase-0 scratch (np * 80 u16 counters) aliases the per-SV area
-    int grp_doubles = group * L.stride;
+    L.pf_stride = g;
+    // the phase-0 scratch (np * 80 u16 counters) aliases the PF area
+    int pf_doubles = 2 * group * L.pf_stride;
     const int scratch_doubles = (np * 80 * 2 + 7) / 8;
-    if (grp_doubles < scratch_doubles) grp_doubles = scratch_doubles;
-    o += grp_doubles;
+    if (pf_doubles < scratch_doubles) pf_doubles = scratch_doubles;
+    L.pf = o; o += pf_doubles;
+    L.tu = 0; L.td = np * n_arm; L.tb_stride = np * n_arm + L.nq * n_arm;
+    L.tb = o; o += 2 * group * L.tb_stride;
     int bytes = o * 8;
     L.bytes_desc = bytes; bytes += SVR_N_ARR * 16 * 4;
-    L.bytes_ent = bytes; bytes += 2 * L.n_ent * 4;
+    L.bytes_ent = bytes; bytes += 3 * L.n_ent * 4;     // per entry: packed slots, packed fields, f32 window norm
+    L.bytes_idx = bytes;
+    { int t = 0; for (int k = 0; k < SVR_N_ARR; k++) { L.idx_off[k] = t; t += L.arr_len[k] + 1; } bytes += 2 * t; bytes = (bytes + 7) & ~7; }
     L.bytes_sb = bytes; bytes += L.span_b + 8;
     L.total_bytes = (bytes + 15) & ~15;
-    // fused scans: each array gets whole lanes of its part's wavefront; every lane owns `chunk` consecutive slots
-    for (int part = 0; part < 2; part++) {
-        const int k0 = part == 0 ? 0 : 3, k1 = part == 0 ? 3 : SVR_N_ARR;
-        int total = 0;
-        for (int k = k0; k < k1; k++) total += L.arr_len[k] + 1;
-        int c = (total + 63) / 64;
-        for (;; c++) {
-            int lanes = 0;
-            for (int k = k0; k < k1; k++) lanes += (L.arr_len[k] + 1 + c - 1) / c;
-            if (lanes <= 64) break;
-        }
-        L.chunk[part] = c;
-        int l0 = 0;
-        for (int k = k0; k < k1; k++) { L.lane0[k] = l0; l0 += (L.arr_len[k] + 1 + c - 1) / c; L.lane1[k] = l0; }
+    // scan units: one wavefront per array; the array occupies 16, 32 or 64 lanes (DPP rows)
+    for (int k = 0; k < SVR_N_ARR; k++) {
+        const int slots = L.arr_len[k] + 1;
+        int lanes = 16;
+        while (lanes < 64 && (slots + lanes - 1) / lanes > SVR_CW_MAX) lanes *= 2;
+        L.chunk[k] = (slots + lanes - 1) / lanes;
     }
     return L;
 }
 
-#define SVR_MAX_CHUNK 20
-#define SVR_GROUP 3            // support vectors staged (and interleaved in the candidate loop) per iteration
-#define SVR_MAX_THREADS 512   // nchunk * wpc * 64 <= 512
-#define LOG_THREADS 256
+
