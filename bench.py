@@ -137,17 +137,11 @@ def main() -> None:
     survivors_gathered = 0
     if distributed and not args.no_replay:
         # the one exchange step of the path: per-position survivors -> rank 0 (RCCL gather over xGMI)
+        from mipgen_amd import dist as mdist
         emitted, surv, _ = acc.download_replay(want_mask=False)
-        t = torch.from_numpy(surv.view(np.uint8).copy()).cuda()
-        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([t.numel()], dtype=torch.int64, device="cuda"))
-        mx = int(max(int(s.item()) for s in sizes))
-        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-        pad[:t.numel()] = t
-        gl = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, gl, dst=0)
+        allsurv = mdist.gather_to_rank0(surv, device=f"cuda:{local_rank}")
         if rank == 0:
-            survivors_gathered = sum(int(s.item()) for s in sizes) // surv.dtype.itemsize
+            survivors_gathered = int(allsurv.shape[0])
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()

@@ -1,0 +1,40 @@
+"""CPU: the N>1 host path (region sharding + one gather of survivors to rank 0) with world size 2 over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from mipgen_amd import dist as mdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_regions_is_contiguous_balanced_and_complete():
+    rng = np.random.default_rng(1)
+    for world in (1, 2, 3, 4, 8):
+        for n in (1, 2, 7, 8, 62, 200):
+            w = rng.integers(1, 10_000, size=n).tolist()
+            sh = mdist.shard_regions(w, world)
+            assert len(sh) == world
+            assert sh[0][0] == 0 and sh[-1][1] == n
+            assert all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+            if n >= world:
+                assert all(hi > lo for lo, hi in sh)          # nobody idles when there is enough work
+                loads = [sum(w[lo:hi]) for lo, hi in sh]
+                assert max(loads) <= sum(w) / world + max(w)  # within one region of the ideal
+
+
+def test_two_rank_gather_over_gloo(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tmp_path / "r0.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(out)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    res = json.load(open(out))
+    assert res["ok"] and res["total"] == res["expected_total"]
+    assert len(res["shards"]) == 2 and res["shards"][0][1] == res["shards"][1][0]
