@@ -1,0 +1,392 @@
+// inputs.cpp — input stage of the drop-in front end: BED intervals, region sequences, TRF masks, SNPs, BWA copy numbers.
+// Semantics follow /root/reference/mipgen.cpp:796-1229 (get_features_to_scan, get_chr_fasta_sequence_*,
+// get_masked_features_to_scan, load_snps/parse_vcf, check_copy_numbers, find_copy); the external tools are invoked with
+// the same command lines so that real bwa / tabix / trf (or the test stand-ins) see what the reference would hand them.
+// One deliberate change: without -genome_dir the region sequences are sliced from the .fai-indexed
+// reference directly instead of forking `samtools faidx` twice per region.
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+
+#include "mipgen_host.hpp"
+
+namespace mipgen {
+
+static std::string trim(const std::string& s)
+{
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) a++;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+static std::vector<std::string> split_ws(const std::string& s)            // boost::split(is_any_of(" \t"), token_compress_on)
+{
+    std::vector<std::string> out;
+    std::string cur;
+    bool in_sep = false;
+    for (char c : s) {
+        if (c == ' ' || c == '\t') { if (!in_sep) { out.push_back(cur); cur.clear(); in_sep = true; } }
+        else { cur += c; in_sep = false; }
+    }
+    out.push_back(cur);
+    return out;
+}
+
+// compare_regions_to_scan, mipgen.cpp:37-67
+static bool bed_less(const std::string& a, const std::string& b)
+{
+    if (a[0] == '>' || a[0] == '#') return true;
+    auto chr_of = [](const std::string& s) {
+        size_t e = s.find_first_of(" \t");
+        return s.substr(0, 3) == "chr" ? s.substr(3, e - 3) : s.substr(0, e);
+    };
+    std::string ac = chr_of(a), bc = chr_of(b);
+    if (ac != bc) return ac < bc;
+    auto start_of = [](const std::string& s) {
+        size_t i = s.find_first_of(" \t", 0);
+        i = s.find_first_not_of(" \t", i);
+        size_t e = s.find_first_of(" \t", i);
+        return std::atoi(s.substr(i, e == std::string::npos ? std::string::npos : e - i).c_str());
+    };
+    return start_of(a) < start_of(b);
+}
+
+std::vector<Region> load_regions(const Options& o)
+{
+    std::vector<Region> out;
+    std::ifstream fh(o.regions_to_scan);
+    if (!fh.is_open()) return out;
+    std::cerr << "[mipgen] success on opening region file" << std::endl;
+    std::vector<std::string> lines;
+    std::string line;
+    while (std::getline(fh, line)) {
+        line = trim(line);
+        if (line.size() > 1 && line[0] != '#') lines.push_back(line);
+    }
+    std::stable_sort(lines.begin(), lines.end(), bed_less);                    // list::sort is a stable merge sort
+    std::string default_label = o.project_name;
+    if (default_label.rfind('/') != std::string::npos) default_label = default_label.substr(default_label.rfind('/') + 1);
+    for (const std::string& l : lines) {
+        if (l[0] == '>' || l[0] == '#' || l.find_first_not_of(" \t\n") == std::string::npos) continue;
+        std::vector<std::string> f = split_ws(l);
+        if (f.size() < 3) continue;
+        const std::string label = f.size() > 3 ? f[3] : default_label;
+        const std::string chr = f[0].substr(0, 3) == "chr" ? f[0].substr(3) : f[0];
+        const int bs = std::atoi(f[1].c_str()), be = std::atoi(f[2].c_str());
+        if (!out.empty() && out.back().chr == chr && bs - out.back().stop - 2 * o.feature_flank < o.min_capture / 2) {   // :1019
+            Region& p = out.back();
+            p.stop = std::max(be, p.stop);
+            p.label = label;
+            p.stop_fl = p.stop + o.feature_flank;
+        } else {
+            Region r;
+            r.chr = chr; r.label = label; r.start = bs + 1; r.stop = be;
+            r.start_fl = r.start - o.feature_flank; r.stop_fl = r.stop + o.feature_flank;
+            out.push_back(r);
+        }
+    }
+    return out;
+}
+
+static void upper(std::string& s) { for (char& c : s) c = (char)std::toupper((unsigned char)c); }
+
+// get_chr_fasta_sequence_from_genome_dir, mipgen.cpp:1180-1229
+bool load_sequences_from_genome_dir(const Options& o, std::vector<Region>& regs)
+{
+    std::string chr = "0", chr_seq;
+    std::ofstream fa(o.project_name + ".feature_sequences.fa");
+    const std::string dir = o.arg("-genome_dir");
+    for (Region& r : regs) {
+        if (chr != r.chr) {
+            chr_seq.clear();
+            chr = r.chr;
+            std::ifstream fh(dir + "/chr" + chr + ".fa");
+            if (!fh.is_open()) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; return false; }
+            std::string line;
+            while (std::getline(fh, line)) {
+                if (!line.empty() && line[0] == '>') continue;
+                while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+                upper(line);
+                chr_seq += line;
+            }
+        }
+        const int cs = r.start_fl - o.max_capture < 1 ? 1 : r.start_fl - o.max_capture;
+        const int ce = r.stop_fl + o.max_capture + 15 > (int)chr_seq.size() ? (int)chr_seq.size() : r.stop_fl + o.max_capture + 15;
+        const int len = ce - cs + 1;
+        r.seq = chr_seq.substr((size_t)(cs - 1), (size_t)std::max(len, 0));
+        r.seq_start = cs; r.seq_stop = ce;
+        fa << ">" << r.chr << ':' << cs << "-" << ce << std::endl << r.seq << std::endl;
+        if (o.score_method != MIPGEN_SCORE_LOGISTIC) {
+            long s0 = (long)r.start_fl - o.max_capture - 1 - 1000;               // :1225 (the reference throws if this is negative)
+            if (s0 < 0) s0 = 0;
+            r.long_range_seq = s0 < (long)chr_seq.size() ? chr_seq.substr((size_t)s0, (size_t)(len + 2000)) : std::string();
+        }
+    }
+    return true;
+}
+
+// replaces get_chr_fasta_sequence_using_samtools (mipgen.cpp:1087-1177): same coordinates ([start_fl-maxC, stop_fl+maxC+14],
+// long range +/- 1000), read through the .fai index instead of `samtools faidx` child processes
+bool load_sequences_from_indexed_fasta(const Options& o, std::vector<Region>& regs)
+{
+    struct Fai { long len, off; int bases, width; };
+    std::map<std::string, Fai> fai;
+    {
+        std::ifstream f(o.bwa_genome_index + ".fai");
+        if (!f.is_open()) { std::cerr << "[mipgen] " << o.bwa_genome_index << ".fai not found (index the reference with samtools faidx)" << std::endl; return false; }
+        std::string name; Fai e;
+        while (f >> name >> e.len >> e.off >> e.bases >> e.width) fai[name] = e;
+    }
+    FILE* fp = fopen(o.bwa_genome_index.c_str(), "rb");
+    if (!fp) { std::cerr << "genome fasta could not be opened; check file path and permissions?" << std::endl; return false; }
+    auto fetch = [&](const Fai& e, long a, long b) {                             // 1-based inclusive, clipped to the sequence
+        std::string out;
+        a = std::max(a, 1L); b = std::min(b, e.len);
+        if (b < a) return out;
+        out.reserve((size_t)(b - a + 1));
+        long i = a - 1;
+        fseek(fp, e.off + (i / e.bases) * e.width + (i % e.bases), SEEK_SET);
+        while ((long)out.size() < b - a + 1) {
+            int c = fgetc(fp);
+            if (c == EOF) break;
+            if (c == '\n' || c == '\r') continue;
+            out += (char)std::toupper(c);
+        }
+        return out;
+    };
+    std::ofstream fa(o.project_name + ".feature_sequences.fa");
+    for (Region& r : regs) {
+        auto it = fai.find(r.chr);
+        if (it == fai.end()) it = fai.find("chr" + r.chr);                      // mipgen.cpp:1106 adds "chr" when the reference uses it
+        if (it == fai.end()) { std::cerr << "[mipgen] chromosome " << r.chr << " not in " << o.bwa_genome_index << ".fai" << std::endl; fclose(fp); return false; }
+        const long a = (long)r.start_fl - o.max_capture, b = (long)r.stop_fl + o.max_capture + 14;
+        r.seq = fetch(it->second, a, b);
+        r.seq_start = (int)std::max(a, 1L);
+        r.seq_stop = r.seq_start + (int)r.seq.size() - 1;
+        fa << ">" << it->first << ':' << a << "-" << b << std::endl;
+        for (size_t i = 0; i < r.seq.size(); i += 60) fa << r.seq.substr(i, 60) << std::endl;
+        if (o.score_method != MIPGEN_SCORE_LOGISTIC) r.long_range_seq = fetch(it->second, a - 1000, b + 1000);
+    }
+    fclose(fp);
+    return true;
+}
+
+// get_masked_features_to_scan, mipgen.cpp:1045-1084
+bool load_masks(const Options& o, std::vector<Region>& regs)
+{
+    const std::string trf = o.arg("-trf");
+    if (trf != "off") {
+        int rc = std::system((trf + " " + o.project_name + ".feature_sequences.fa 2 7 7 80 10 14 100 -m -h").c_str());
+        (void)rc;
+    }
+    const size_t ps = o.project_name.rfind('/');
+    const std::string prefix = ps == std::string::npos ? o.project_name : o.project_name.substr(ps + 1);
+    std::ifstream mf(prefix + ".feature_sequences.fa.2.7.7.80.10.14.100.mask");
+    if (!mf.is_open() || trf == "off") {
+        std::cerr << "[mipgen] no masked feature file found" << std::endl;
+        for (Region& r : regs) r.masked = r.seq;
+        return trf == "off";
+    }
+    std::string line;
+    size_t idx = 0;
+    Region* cur = nullptr;
+    while (std::getline(mf, line)) {
+        if (line.empty()) continue;
+        if (line[0] == '>') { cur = idx < regs.size() ? &regs[idx] : nullptr; idx++; continue; }
+        if (cur) cur->masked += line;
+    }
+    return true;
+}
+
+// load_snps + parse_vcf, mipgen.cpp:875-978
+void load_snps(const Options& o, const std::vector<Region>& regs, Tables& t)
+{
+    if (o.arg("-snp_file") == "<none>" || regs.empty()) return;
+    std::string query;
+    int first = regs.front().start_fl - 500, last = regs.front().stop_fl + 500;
+    std::string cur = regs.front().chr, prev;
+    for (const Region& r : regs) {
+        prev = cur; cur = r.chr;
+        const int as = r.start_fl - 500, ae = r.stop_fl + 500;
+        if (prev == cur && ae >= last && as <= last) last = ae;
+        else {
+            query += prev + ":" + std::to_string(first) + "-" + std::to_string(last) + " ";
+            first = as; last = ae;
+        }
+    }
+    query += cur + ":" + std::to_string(first) + "-" + std::to_string(last) + " ";
+    if (std::system(o.arg("-tabix").c_str()) != 256) { std::cerr << "[mipgen] tabix not loaded" << std::endl; throw 16; }
+    const std::string vcf = o.project_name + ".local_snp_data.vcf";
+    int rc = std::system((o.arg("-tabix") + " " + o.arg("-snp_file") + " " + query + " > " + vcf).c_str());
+    (void)rc;
+    std::ifstream f(vcf);
+    if (!f.is_open()) { std::cerr << "[mipgen] VCF file could not be opened" << std::endl; return; }
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.size() < 2 || line[0] == '#') continue;
+        size_t a = 0, b = line.find_first_of(" \t", 0);
+        const std::string chr = line.substr(a, b);
+        a = b + 1; b = line.find_first_of(" \t", a);
+        const int pos = std::atoi(line.substr(a, b - a).c_str());
+        a = b + 1; b = line.find_first_of(" \t", a);                            // id
+        a = b + 1; b = line.find_first_of(" \t", a);
+        const std::string ref = line.substr(a, b - a);
+        a = b + 1; b = line.find_first_of(" \t", a);
+        const std::string alt = line.substr(a, b == std::string::npos ? std::string::npos : b - a);
+        const std::string alleles = ref + alt;
+        if (ref.size() > 1) for (size_t i = 1; i < ref.size(); i++) t.snps[chr][pos + (int)i] = alleles;
+        else t.snps[chr][pos] = alleles;
+        t.snp_load_count++;
+    }
+}
+
+// check_copy_numbers, mipgen.cpp:796-873
+std::string check_copy_numbers(const Options& o, const std::vector<Region>& regs, Tables& t)
+{
+    const std::string pn = o.project_name, bwa = o.arg("-bwa");
+    {
+        std::ofstream fq(pn + ".all_sequences.fq"), arms(pn + ".oligo_copy_count.fq");
+        if (!fq.is_open() || !arms.is_open()) { std::cerr << "[mipgen] copy_check files could not be opened" << std::endl; return ""; }
+        for (const Region& r : regs) {
+            for (int size = o.max_capture; size >= o.min_capture; size -= o.capture_increment) {
+                for (int start = r.start_fl - size; start < r.stop_fl; start++) {
+                    if (start > 0 && start + size - 1 <= r.seq_stop) {
+                        const long rel = (long)start - r.seq_start;
+                        if (rel < 0 || rel > (long)r.seq.size()) continue;         // the reference's substr would throw here
+                        fq << "@" << size << "_" << r.chr << "_" << start << "\n" << r.seq.substr((size_t)rel, (size_t)size) << "\n+\n"
+                           << std::string((size_t)size, '#') << "\n";
+                    }
+                }
+            }
+            for (int size : o.oligo_sizes) {
+                if ((long)r.seq.size() - size <= 0) continue;
+                for (size_t rel = 0; rel < r.seq.size() - (size_t)size; rel++) {
+                    arms << "@chr" << r.chr << ":" << (r.seq_start + (long)rel) << "-" << (r.seq_start + (long)rel + size - 1) << "\n"
+                         << r.seq.substr(rel, (size_t)size) << "\n+\n" << std::string((size_t)size, '#') << "\n";
+                }
+            }
+        }
+    }
+    int rc = std::system((bwa + " aln -t " + o.arg("-bwa_threads") + " " + o.bwa_genome_index + " " + pn + ".all_sequences.fq > " + pn + ".all_sequences.sai").c_str());
+    rc = std::system((bwa + " samse " + o.bwa_genome_index + " " + pn + ".all_sequences.sai " + pn + ".all_sequences.fq > " + pn + ".all_sequences.sam").c_str());
+    (void)rc;
+    std::ifstream sam(pn + ".all_sequences.sam");
+    if (!sam.is_open()) return "";
+    std::cerr << "[mipgen] sam file opened" << std::endl;
+    int bad = 0;
+    bool header = true;
+    std::string line;
+    while (std::getline(sam, line)) {
+        const size_t n = line.size();
+        if (header && line.find("X0:i:") >= n - 1) continue;                      // unsigned arithmetic as in the reference (:853)
+        else if (header) header = false;
+        if (n < 2) continue;
+        if (line.find("X0:i:1") >= n - 1 || line.find("X1:i:0") >= n - 1) {       // :857
+            const std::string key = line.substr(0, line.find('\t'));
+            const size_t s1 = key.find('_'), s2 = key.rfind('_');
+            const int size = std::atoi(key.substr(0, s1).c_str());
+            const std::string chr = key.substr(s1 + 1, s2 - s1 - 1);
+            const int pos = std::atoi(key.substr(s2 + 1).c_str());
+            t.unmappable[size][chr].insert(pos);
+            bad++;
+        }
+    }
+    return std::to_string(bad) + " ambiguously mapping start positions must be avoided\n";
+}
+
+// find_copy, mipgen.cpp:558-596
+void find_copy(const Options& o, Tables& t)
+{
+    const std::string pn = o.project_name, bwa = o.arg("-bwa");
+    int rc = std::system((bwa + " aln -t " + o.arg("-bwa_threads") + " " + o.bwa_genome_index + " " + pn + ".oligo_copy_count.fq > " + pn + ".oligo_copy_count.sai").c_str());
+    rc = std::system((bwa + " samse " + o.bwa_genome_index + " " + pn + ".oligo_copy_count.sai " + pn + ".oligo_copy_count.fq > " + pn + ".oligo_copy_count.sam").c_str());
+    (void)rc;
+    std::ifstream sam(pn + ".oligo_copy_count.sam");
+    if (!sam.is_open()) return;
+    std::cerr << "[mipgen] checking oligo copy" << std::endl;
+    std::string line;
+    while (std::getline(sam, line)) {
+        if (line.size() <= 1 || line[0] == '@') continue;
+        const size_t c0 = line.find("chr", 0) + 3, c1 = line.find(':', c0), s1 = line.find('-', c1 + 1), e1 = line.find('\t', s1 + 1);
+        const std::string chr = line.substr(c0, c1 - c0);
+        const int start = std::atoi(line.substr(c1 + 1, s1 - c1 - 1).c_str()), stop = std::atoi(line.substr(s1 + 1, e1 - s1 - 1).c_str());
+        const size_t x0 = line.find("X0:i:", 0);
+        if (x0 < line.size()) t.copies[chr][start][stop] = std::atoi(line.substr(x0 + 5, line.find('\t', x0 + 5) - (x0 + 5)).c_str());
+        else t.copies[chr][start][stop] = 100;                                    // :591
+    }
+}
+
+static char comp(char c)
+{
+    switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; default: return 0; }
+}
+
+// slices of the global tables in the layout of mipgen_region (include/mipgen_accel.h)
+void attach_tables(const Options& o, const Tables& t, Region& r)
+{
+    const int n = (int)r.seq.size();
+    r.copy_store.clear();
+    r.copy_ptr.assign(MIPGEN_MAX_OLIGO + 1, nullptr);
+    auto cit = t.copies.find(r.chr);
+    for (int len : o.oligo_sizes) {
+        if (len < 0 || len > MIPGEN_MAX_OLIGO) continue;
+        r.copy_store.emplace_back((size_t)n, 0);                                 // absent key -> 0 (std::map::operator[], mipgen.cpp:612-613)
+        std::vector<int32_t>& v = r.copy_store.back();
+        if (cit != t.copies.end()) {
+            auto lo = cit->second.lower_bound(r.seq_start), hi = cit->second.upper_bound(r.seq_stop);
+            for (auto it = lo; it != hi; ++it) {
+                auto e = it->second.find(it->first + len - 1);
+                if (e != it->second.end()) v[(size_t)(it->first - r.seq_start)] = e->second;
+            }
+        }
+    }
+    {
+        size_t k = 0;
+        for (int len : o.oligo_sizes) { if (len < 0 || len > MIPGEN_MAX_OLIGO) continue; r.copy_ptr[(size_t)len] = r.copy_store[k++].data(); }
+    }
+    r.unmappable.clear();
+    if (!t.unmappable.empty()) {
+        const int K = (o.max_capture - o.min_capture) / o.capture_increment + 1;
+        r.unmappable.assign((size_t)K * n, 0);
+        for (int k = 0; k < K; k++) {
+            auto s = t.unmappable.find(o.max_capture - k * o.capture_increment);
+            if (s == t.unmappable.end()) continue;
+            auto c = s->second.find(r.chr);
+            if (c == s->second.end()) continue;
+            for (auto it = c->second.lower_bound(r.seq_start); it != c->second.end() && *it <= r.seq_stop; ++it)
+                r.unmappable[(size_t)k * n + (size_t)(*it - r.seq_start)] = 1;
+        }
+    }
+    r.snp_class.clear();
+    auto sit = t.snps.find(r.chr);
+    if (sit != t.snps.end() && !sit->second.empty()) {
+        r.snp_class.assign((size_t)n, 0);
+        for (auto it = sit->second.lower_bound(r.seq_start); it != sit->second.end() && it->first <= r.seq_stop; ++it) {
+            const std::string& al = it->second;
+            const char g = r.seq[(size_t)(it->first - r.seq_start)];
+            bool ok = false;                                                      // can an alternate-allele arm be generated? (mipgen.cpp:644-682)
+            if (al.size() == 2 && al[0] != 'N' && al[1] != 'N' && al[0] != '-' && al[1] != '-')
+                ok = g == al[0] || (comp(al[0]) != 0 && g == comp(al[0]));
+            r.snp_class[(size_t)(it->first - r.seq_start)] = ok ? 1 : 2;
+        }
+    }
+}
+
+void fill_accel_region(const Region& r, mipgen_region& out)
+{
+    memset(&out, 0, sizeof out);
+    out.start_flanked = r.start_fl; out.stop_flanked = r.stop_fl;
+    out.seq_start = r.seq_start; out.seq_stop = r.seq_stop; out.seq_len = (int)r.seq.size();
+    out.seq = r.seq.c_str();
+    out.masked_seq = r.masked.size() == r.seq.size() ? r.masked.c_str() : nullptr;
+    out.copy = r.copy_ptr.empty() ? nullptr : r.copy_ptr.data();
+    out.unmappable = r.unmappable.empty() ? nullptr : r.unmappable.data();
+    out.snp_class = r.snp_class.empty() ? nullptr : r.snp_class.data();
+    memcpy(out.long_range_content, r.lrc, sizeof out.long_range_content);
+}
+
+}  // namespace mipgen

@@ -1,0 +1,131 @@
+// mipgen_host.hpp — host side of the drop-in `mipgen` front end (C++17, no Boost).
+//
+// Mirrors the reference's operator interface for the hot path and the stages either side of it
+// (citations into /root/reference):
+//   Options            <- mipgen::set_default_args / parse_command_line / parse_arg_values   mipgen.cpp:164-276,1280-1501
+//   Region             <- Featurev5                                                           Featurev5.h:7-28
+//   load_regions       <- get_features_to_scan (+ compare_regions_to_scan)                    mipgen.cpp:37-67,981-1043
+//   load_sequences     <- get_chr_fasta_sequence_from_genome_dir / _using_samtools            mipgen.cpp:1087-1229
+//   load_masks/snps/copies <- get_masked_features_to_scan, load_snps/parse_vcf, check_copy_numbers/find_copy
+//   Selector           <- collapse_mips, output_collapsed_mips, pick_mips, optimize_worst_in_region,
+//                         translocate_down_region, manage_picked_mip, print_gaps, create_gap       mipgen.cpp:1231-1278,1506-1939
+//   format_record      <- print_details                                                       mipgen.cpp:765-794
+// Candidate construction + scoring (tile_regions' loop body, design_mip, get_score, get_parameters, predict_value)
+// is NOT here: it is the accelerator's job (include/mipgen_accel.h).
+#pragma once
+#include <cstdint>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/mipgen_accel.h"
+
+namespace mipgen {
+
+struct Options {
+    std::map<std::string, std::string> args;     // raw option map, as the reference keeps it (mipgen.cpp:76)
+    bool has_arm_lengths = false, has_arm_length_sums = false;
+    // typed views (parse_arg_values, mipgen.cpp:190-276)
+    int feature_flank = 0, ext_tag = 5, lig_tag = 0, max_arm_copy = 75, target_arm_copy = 20;
+    int max_mip_overlap = 30, starting_mip_overlap = 0, max_capture = 0, min_capture = 0, capture_increment = 5;
+    bool double_tile = false, double_tile_strands_separately = false, silent = false;
+    bool seal_both = false, half_seal_both = false;
+    double masked_arm_threshold = 0.5;
+    double logistic_priority = 0.9, logistic_optimal = 0.98, svr_priority = 1.5, svr_optimal = 2.2;
+    int score_method = MIPGEN_SCORE_LOGISTIC;
+    std::string middle;                          // universal_middle_mip_seq (mipgen.cpp:199-200)
+    std::string regions_to_scan, project_name, bwa_genome_index, file_dir;
+    std::vector<std::pair<int, int>> arm_pairs;  // (ext, lig) in enumeration order: arm sum desc, list order (mipgen.cpp:431-442)
+    std::set<int> oligo_sizes;
+    int max_arm_sum = 0, min_arm_sum = 0;
+    std::string arg(const std::string& k) const { auto it = args.find(k); return it == args.end() ? std::string() : it->second; }
+    bool has(const std::string& k) const { return args.count(k) != 0; }
+    mipgen_params accel_params() const;
+};
+
+// returns "" on success, else the message the reference would print before `throw 1` (mipgen.cpp:140-145)
+std::string parse_command_line(int argc, char** argv, Options& o);
+// throws int (4 = invalid scoring method) exactly as parse_arg_values does
+void finalize_options(Options& o);
+
+struct Region {                                   // Featurev5
+    std::string chr, label;
+    int start = 0, stop = 0;                      // start_position, stop_position (1-based, unflanked)
+    int start_fl = 0, stop_fl = 0;                // flanked
+    std::string seq, masked;                      // chromosomal_sequence, masked_chromosomal_sequence
+    int seq_start = 0, seq_stop = 0;
+    double lrc[MIPGEN_N_LRC] = {0};
+    // per-region slices of the global lookup tables, laid out as mipgen_region expects
+    std::vector<std::vector<int32_t>> copy_store;
+    std::vector<const int32_t*> copy_ptr;
+    std::vector<uint8_t> unmappable, snp_class;
+    std::string long_range_seq;                   // region +/- 1000 bases (svr / mixed only)
+};
+
+struct Tables {                                   // global lookup tables the input stage fills (mipgen.cpp:81-83)
+    std::map<std::string, std::map<int, std::string>> snps;                  // chr_snp_positions
+    std::map<int, std::map<std::string, std::set<int>>> unmappable;          // unmappable_positions[size][chr]
+    std::map<std::string, std::map<int, std::map<int, int>>> copies;         // copy_chr_start_stop[chr][start][stop]
+    int snp_load_count = 0;
+};
+
+// input stage; each throws int on the reference's error paths
+std::vector<Region> load_regions(const Options& o);                                         // may return empty -> caller throws 6
+bool load_sequences_from_genome_dir(const Options& o, std::vector<Region>& regs);
+bool load_sequences_from_indexed_fasta(const Options& o, std::vector<Region>& regs);       // native faidx, no samtools fork
+bool load_masks(const Options& o, std::vector<Region>& regs);
+void load_snps(const Options& o, const std::vector<Region>& regs, Tables& t);
+std::string check_copy_numbers(const Options& o, const std::vector<Region>& regs, Tables& t);   // "" on failure
+void find_copy(const Options& o, Tables& t);
+void attach_tables(const Options& o, const Tables& t, Region& r);                          // fill copy/unmappable/snp slices
+void fill_accel_region(const Region& r, mipgen_region& out);
+
+// one candidate as the selection stage sees it (the fields of SVMipv4 it reads)
+struct Cand {
+    int scan_start = 0, scan_stop = 0, ext_start = 0, ext_stop = 0, lig_start = 0, lig_stop = 0;
+    int ext_len = 0, lig_len = 0, strand = 0, capture = 0;
+    int ext_copy = 0, lig_copy = 0, snp_count = 0;
+    double masked = 0.0, score = 0.0;
+    char mapping_failed = '0', snp_failed = '0', masking_failed = '0';
+    int scan_size() const { return scan_stop - scan_start + 1; }
+};
+Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t local_index, double score, uint64_t record);
+
+struct Outputs {
+    std::ofstream all, collapsed, picked, snp, progress, gaps, double_gaps, minus_gaps, double_minus_gaps;
+    int all_counter = 0, collapsed_counter = 0, picked_counter = 0, bad_design_count = 0;
+};
+void open_outputs(const Options& o, Outputs& out);       // headers as mipgen.cpp:349-399
+std::string format_record(const Options& o, const Region& r, const Tables& t, const Cand& c, int index, bool minor);
+
+// re-scoring hook for -score_method mixed (mipgen.cpp:1523-1527,1873-1877)
+struct Rescorer { virtual double svr(const Cand& c) = 0; virtual ~Rescorer() {} };
+
+class Selector {
+public:
+    Selector(const Options& o, const Tables& t, Outputs& out) : o_(o), t_(t), out_(out) {}
+    // survivors: 2 per scan position ('+','-'); cand_index is region-local or -1.  scores/records: region-local dense arrays
+    // (only needed for the survivors; pass the values stored in the survivor records)
+    void run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& survivors, Rescorer* rescorer,
+                    double lower, double upper);
+private:
+    using CandPtr = std::shared_ptr<Cand>;
+    const Options& o_; const Tables& t_; Outputs& out_;
+    std::map<std::string, std::map<int, std::set<int>>> used_;             // chr_strand_pos_used_arm_bases (persists across regions)
+    std::map<int, std::map<int, CandPtr>> scan_best_, pos_best_;           // [position][strand 0/1]
+    const Region* r_ = nullptr; Rescorer* rs_ = nullptr; double lower_ = 0, upper_ = 0;
+    void collapse();
+    void output_collapsed();
+    void pick();
+    CandPtr optimize_worst(std::set<int>& positions, int strand_to_use);
+    CandPtr translocate(std::set<int>& positions, int strand_to_use);
+    void manage_picked(CandPtr m, std::set<int>& positions);
+    void print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions);
+    void create_gap(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions);
+    bool arm_used(const Cand& c, int strand) const;
+};
+
+}  // namespace mipgen

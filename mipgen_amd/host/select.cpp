@@ -1,0 +1,398 @@
+// select.cpp — selection stage and record formatting of the drop-in front end.
+// Semantics follow /root/reference/mipgen.cpp: collapse_mips :1616-1649, output_collapsed_mips :1651-1668,
+// pick_mips :1506-1614, optimize_worst_in_region :1748-1820, translocate_down_region :1822-1908,
+// manage_picked_mip :1910-1939, print_gaps / create_gap :1231-1278, print_details :765-794, headers :349-399.
+// The per-(scan start, strand) survivors it starts from (condense_mips, :1670-1746) come from the accelerator.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <sstream>
+
+#include "mipgen_host.hpp"
+
+namespace mipgen {
+
+// ---- candidates and records --------------------------------------------------------------------------------
+
+Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t li, double score, uint64_t rec)
+{
+    (void)r;
+    Cand c;
+    const int A = (int)o.arm_pairs.size();
+    c.strand = (int)(li & 1);
+    const int64_t pr = li >> 1;
+    const int a = (int)(pr % A);
+    const int64_t rest = pr / A;
+    const int ki = (int)(rest % g.n_sizes);
+    const int pi = (int)(rest / g.n_sizes);
+    c.ext_len = o.arm_pairs[(size_t)a].first; c.lig_len = o.arm_pairs[(size_t)a].second;
+    c.capture = o.max_capture - (g.first_size_index + ki) * o.capture_increment;
+    c.scan_start = g.first_pos + pi;
+    c.scan_stop = c.scan_start + c.capture - c.ext_len - c.lig_len - 1;            // mipgen.cpp:449
+    if (c.strand == 0) {                                                           // PlusSVMipv4.cpp:9-12
+        c.ext_start = c.scan_start - c.ext_len; c.ext_stop = c.scan_start - 1;
+        c.lig_start = c.scan_stop + 1; c.lig_stop = c.scan_stop + c.lig_len;
+    } else {                                                                       // MinusSVMipv4.cpp:32-35
+        c.ext_start = c.scan_stop + 1; c.ext_stop = c.scan_stop + c.ext_len;
+        c.lig_start = c.scan_start - c.lig_len; c.lig_stop = c.scan_start - 1;
+    }
+    c.ext_copy = (int)MIPGEN_REC_EXT_COPY(rec); c.lig_copy = (int)MIPGEN_REC_LIG_COPY(rec);
+    c.snp_count = (int)MIPGEN_REC_SNP_COUNT(rec);
+    c.masked = (double)MIPGEN_REC_MASKED_N(rec) / (double)(c.lig_len + c.ext_len);  // mipgen.cpp:610
+    c.score = score;
+    const uint32_t f = MIPGEN_REC_FLAGS(rec);
+    c.mapping_failed = (f & MIPGEN_FLAG_MAPPING) ? '1' : '0';
+    c.snp_failed = (f & MIPGEN_FLAG_SNP) ? '1' : '0';
+    c.masking_failed = (f & MIPGEN_FLAG_MASKING) ? '1' : '0';
+    return c;
+}
+
+static std::string revcomp(const std::string& s)                                   // MinusSVMipv4.cpp:6-29
+{
+    std::string o;
+    o.reserve(s.size());
+    for (size_t i = s.size(); i-- > 0;) {
+        char c = s[i];
+        switch (c) { case 'G': c = 'C'; break; case 'C': c = 'G'; break; case 'A': c = 'T'; break; case 'T': c = 'A'; break; default: break; }
+        o += c;
+    }
+    return o;
+}
+
+static std::string slice(const Region& r, int start, int len)
+{
+    const long rel = (long)start - r.seq_start;
+    if (rel < 0 || rel > (long)r.seq.size()) return std::string();
+    return r.seq.substr((size_t)rel, (size_t)len);
+}
+
+static char comp(char c)
+{
+    switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; default: return 0; }
+}
+
+// alternate-allele arms of a candidate with exactly one usable SNP (design_mip, mipgen.cpp:634-758)
+static void snp_arms(const Region& r, const Tables& t, const Cand& c, std::string& ext, std::string& lig)
+{
+    auto sit = t.snps.find(r.chr);
+    if (sit == t.snps.end()) return;
+    for (int arm = 0; arm < 2; arm++) {
+        const int a0 = arm == 0 ? c.ext_start : c.lig_start, a1 = arm == 0 ? c.ext_stop : c.lig_stop;
+        std::string& seq = arm == 0 ? ext : lig;
+        for (int i = a0; i <= a1; i++) {
+            auto it = sit->second.find(i);
+            if (it == sit->second.end()) continue;
+            const std::string& al = it->second;
+            if (!(al.size() == 2 && al[0] != 'N' && al[1] != 'N' && al[0] != '-' && al[1] != '-')) continue;
+            const int rel = c.strand == 0 ? i - a0 : a1 - i;
+            if (rel < 0 || rel >= (int)seq.size()) continue;
+            if (seq[(size_t)rel] == al[0]) seq[(size_t)rel] = al[1];
+            else if (comp(al[0]) && seq[(size_t)rel] == comp(al[0]) && comp(al[1])) seq[(size_t)rel] = comp(al[1]);
+        }
+    }
+}
+
+// print_details, mipgen.cpp:765-794
+std::string format_record(const Options& o, const Region& r, const Tables& t, const Cand& c, int index, bool minor)
+{
+    std::string ext = slice(r, c.ext_start, c.ext_len), lig = slice(r, c.lig_start, c.lig_len), ins = slice(r, c.scan_start, c.scan_size());
+    if (c.strand == 1) { ext = revcomp(ext); lig = revcomp(lig); ins = revcomp(ins); }
+    if (minor) snp_arms(r, t, c, ext, lig);                                        // the SNP_b record carries the alternate arms (:1916-1919)
+    char sc[64];
+    if (std::isnan(c.score)) snprintf(sc, sizeof sc, "-nan");                      // x86 default NaN of the reference's inf-inf prints as "-nan"
+    else snprintf(sc, sizeof sc, "%g", c.score);                                   // default ostream formatting: 6 significant digits
+    const char* st = c.strand == 0 ? "+" : "-";
+    std::ostringstream ss;
+    ss << r.chr << ":" << (c.strand == 0 ? c.ext_start : c.lig_start) << "-" << (c.strand == 0 ? c.lig_stop : c.ext_stop) << "/"
+       << c.ext_len << "," << c.lig_len << "/" << st << "\t" << sc << "\t" << r.chr << "\t" << c.ext_start << "\t" << c.ext_stop << "\t"
+       << c.ext_copy << "\t" << ext << "\t" << c.lig_start << "\t" << c.lig_stop << "\t" << c.lig_copy << "\t" << lig << "\t"
+       << c.scan_start << "\t" << c.scan_stop << "\t" << ins << "\t" << lig << o.middle << ext << "\t" << r.start - 1 << "\t" << r.stop << "\t"
+       << st << "\t" << c.mapping_failed << c.snp_failed << c.masking_failed << "\t" << r.label << "_";
+    char num[32];
+    snprintf(num, sizeof num, "%04d", index);
+    ss << num << (c.snp_count == 1 ? (std::string("_SNP_") + (minor ? "b" : "a")) : std::string()) << "\n";
+    return ss.str();
+}
+
+static const char* k_cols =
+    "_score\tchr\text_probe_start\text_probe_stop\text_probe_copy\text_probe_sequence\tlig_probe_start\tlig_probe_stop\tlig_probe_copy\t"
+    "lig_probe_sequence\tmip_scan_start_position\tmip_scan_stop_position\tscan_target_sequence\tmip_sequence\tfeature_start_position\t"
+    "feature_stop_position\tprobe_strand\tfailure_flags\tmip_name\n";
+
+// file headers, mipgen.cpp:349-399 (all/collapsed say svr only for svr; picked/snp say logistic only for logistic)
+void open_outputs(const Options& o, Outputs& out)
+{
+    const std::string pn = o.project_name;
+    out.all.open(pn + ".all_mips.txt");
+    if (!out.all.is_open()) { std::cerr << "[mipgen] all mips file could not be opened" << std::endl; throw 12; }
+    out.all << ">mip_key\t" << (o.score_method == MIPGEN_SCORE_SVR ? "svr" : "logistic") << k_cols;
+    out.collapsed.open(pn + ".collapsed_mips.txt");
+    if (!out.collapsed.is_open()) { std::cerr << "[mipgen] file of collapsed mips could not be opened" << std::endl; throw 13; }
+    out.collapsed << ">mip_key\t" << (o.score_method == MIPGEN_SCORE_SVR ? "svr" : "logistic") << k_cols;
+    out.picked.open(pn + ".picked_mips.txt");
+    if (!out.picked.is_open()) throw 14;
+    out.picked << ">mip_key\t" << (o.score_method == MIPGEN_SCORE_LOGISTIC ? "logistic" : "svr") << k_cols;
+    out.snp.open(pn + ".snp_mips.txt");
+    if (!out.snp.is_open()) throw 15;
+    out.snp << ">mip_key\t" << (o.score_method == MIPGEN_SCORE_LOGISTIC ? "logistic" : "svr") << k_cols;
+}
+
+// ---- selection ---------------------------------------------------------------------------------------------
+
+bool Selector::arm_used(const Cand& c, int strand) const
+{
+    auto ci = used_.find(r_->chr);
+    if (ci == used_.end()) return false;
+    auto si = ci->second.find(strand);
+    if (si == ci->second.end()) return false;
+    for (int p = c.ext_start; p <= c.ext_stop; p++) if (si->second.count(p)) return true;
+    for (int p = c.lig_start; p <= c.lig_stop; p++) if (si->second.count(p)) return true;
+    return false;
+}
+
+void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& surv, Rescorer* rs,
+                          double lower, double upper)
+{
+    r_ = &r; rs_ = rs; lower_ = lower; upper_ = upper;
+    scan_best_.clear(); pos_best_.clear();
+    for (int pi = 0; pi < g.n_pos; pi++)
+        for (int s = 0; s < 2; s++) {
+            const mipgen_survivor& sv = surv[(size_t)(2 * pi + s)];
+            if (sv.cand_index < 0) continue;
+            scan_best_[g.first_pos + pi][s] = std::make_shared<Cand>(make_cand(o_, r, g, sv.cand_index, sv.score, sv.record));
+        }
+    collapse();
+    if (!o_.silent) output_collapsed();
+    out_.progress << "mips collapsed! picking mips...\n";
+    if (o_.score_method == MIPGEN_SCORE_MIXED) { lower_ = o_.svr_priority; upper_ = o_.svr_optimal; }     // mipgen.cpp:510-514
+    pick();
+    scan_best_.clear(); pos_best_.clear();
+}
+
+// collapse_mips, mipgen.cpp:1616-1649
+void Selector::collapse()
+{
+    for (auto& ps : scan_best_)
+        for (auto& sm : ps.second) {
+            const CandPtr& m = sm.second;
+            const int strand = sm.first;
+            if ((long)m->ext_copy * m->lig_copy > o_.max_arm_copy || m->ext_copy > o_.target_arm_copy || m->lig_copy > o_.target_arm_copy) continue;
+            if (m->masked > o_.masked_arm_threshold) continue;
+            for (int pos = m->scan_start; pos <= m->scan_stop; pos++) {
+                auto& slot = pos_best_[pos];
+                auto it = slot.find(strand);
+                if (it == slot.end()) slot[strand] = m;
+                else if (m->snp_count < it->second->snp_count) it->second = m;
+                else if (m->score > it->second->score && m->snp_count == it->second->snp_count) it->second = m;
+            }
+        }
+}
+
+// output_collapsed_mips, mipgen.cpp:1651-1668
+void Selector::output_collapsed()
+{
+    for (auto& ps : pos_best_)
+        for (auto& sm : ps.second) {
+            out_.collapsed_counter++;
+            out_.collapsed << format_record(o_, *r_, t_, *sm.second, out_.collapsed_counter, false);
+        }
+}
+
+// optimize_worst_in_region, mipgen.cpp:1748-1820
+Selector::CandPtr Selector::optimize_worst(std::set<int>& positions, int strand_to_use)
+{
+    CandPtr worst;
+    for (int pos : positions) {
+        auto pit = pos_best_.find(pos);
+        if (pit == pos_best_.end()) continue;
+        CandPtr cur, plus, minus;
+        bool plus_set = false, minus_set = false;
+        auto ip = pit->second.find(0);
+        if (ip != pit->second.end() && strand_to_use != 1) {
+            plus = ip->second;
+            plus_set = !arm_used(*plus, 0);
+            if (plus_set) cur = plus;
+        }
+        auto im = pit->second.find(1);
+        if (im != pit->second.end() && strand_to_use != 0) {
+            minus = im->second;
+            minus_set = !arm_used(*minus, 1);
+            if (minus_set) cur = plus_set ? (plus->score > minus->score ? plus : minus) : minus;
+        }
+        if ((plus_set || minus_set) && (!worst || cur->score < worst->score)) worst = cur;
+    }
+    return worst;
+}
+
+// translocate_down_region, mipgen.cpp:1822-1908
+Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_use)
+{
+    if (positions.empty()) return nullptr;                       // the reference dereferences begin() of an empty set here (UB); see DESIGN.md
+    const int latest = *positions.begin();
+    const int to_end = r_->stop_fl - latest;
+    const int min_scan = o_.min_capture - o_.max_arm_sum;
+    int earliest, prelim, dir;
+    if (to_end < min_scan - 10 - o_.starting_mip_overlap) {
+        earliest = r_->stop_fl - min_scan + 1; prelim = earliest; dir = 1;
+        while (scan_best_.find(prelim) == scan_best_.end() && prelim <= latest) prelim++;
+    } else {
+        earliest = latest - o_.max_mip_overlap; prelim = latest - o_.starting_mip_overlap; dir = -1;
+        while (scan_best_.find(prelim) == scan_best_.end() && prelim >= earliest) prelim--;
+    }
+    if (scan_best_.find(prelim) == scan_best_.end()) return nullptr;
+    CandPtr next;
+    int prev_extent = latest + 1;
+    for (int chosen = prelim;
+         (!next && prev_extent > latest && chosen < r_->stop_fl && chosen > r_->start_fl - o_.min_capture) ||
+         (next && ((next->score < upper_ || next->snp_count > 0) && chosen >= earliest && chosen <= latest - o_.starting_mip_overlap &&
+                   (dir == -1 || chosen + next->scan_size() > *positions.rbegin())));
+         chosen += dir) {
+        int strand_index, iterations;
+        if (strand_to_use != -1) { strand_index = 1 - strand_to_use; iterations = 1; }
+        else { strand_index = rand() % 2; iterations = 2; }                       // libc rand(), never seeded (:1863)
+        for (int i = 0; i < iterations; i++) {
+            strand_index = 1 - strand_index;
+            auto& slot = scan_best_[chosen];                                       // operator[]: creates the position, as the reference does (:1869)
+            auto it = slot.find(strand_index);
+            if (it == slot.end()) continue;
+            CandPtr test = it->second;
+            if (o_.score_method == MIPGEN_SCORE_MIXED && rs_) test->score = rs_->svr(*test);      // in place (:1873-1877)
+            prev_extent = test->scan_stop;
+            if (!next || test->score > next->score || test->snp_count < next->snp_count) {
+                const int test_copy = std::max(test->ext_copy, test->lig_copy);
+                if (test_copy > o_.target_arm_copy && next) {
+                    if (test_copy > std::max(next->ext_copy, next->lig_copy)) continue;
+                }
+                if (test->masked > o_.masked_arm_threshold && next) {
+                    if (test->masked > next->masked) continue;
+                }
+                if (arm_used(*test, strand_index)) continue;
+                next = test;
+            }
+        }
+    }
+    return next;
+}
+
+// manage_picked_mip, mipgen.cpp:1910-1939
+void Selector::manage_picked(CandPtr m, std::set<int>& positions)
+{
+    out_.picked_counter++;
+    out_.picked << format_record(o_, *r_, t_, *m, out_.picked_counter, false);
+    if (m->snp_count == 1 && m->snp_failed == '0') out_.snp << format_record(o_, *r_, t_, *m, out_.picked_counter, true);
+    else if (m->snp_failed == '1') out_.snp << ">Alternate MIP(s) could not be generated for SNP in arms of MIP #" << out_.picked_counter << std::endl;
+    const int other = 1 - m->strand;
+    auto& used = used_[r_->chr];
+    if (o_.seal_both) {
+        for (int p = m->ext_start; p <= m->ext_stop; p++) used[other].insert(p);
+        for (int p = m->lig_start; p <= m->lig_stop; p++) used[other].insert(p);
+    } else if (o_.half_seal_both) {
+        used[other].insert((m->ext_stop + m->ext_start) / 2);
+        used[other].insert((m->lig_start + m->lig_stop) / 2);
+    }
+    for (int p = m->ext_start; p <= m->ext_stop; p++) used[m->strand].insert(p);
+    for (int p = m->lig_start; p <= m->lig_stop; p++) used[m->strand].insert(p);
+    for (int p = m->scan_start; p <= m->scan_stop; p++) positions.erase(p);
+}
+
+// print_gaps, mipgen.cpp:1231-1259
+void Selector::print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions)
+{
+    if (positions.empty()) return;
+    if (!f.is_open()) f.open(o_.arg("-project_name") + ext);
+    out_.progress << note << r_->chr << ":\n";
+    int start = *positions.begin(), stop = start - 1;
+    for (int p : positions) {
+        if (p == stop + 1) stop++;
+        else {
+            out_.bad_design_count++;
+            f << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
+            start = p; stop = p;
+        }
+    }
+    out_.bad_design_count++;
+    f << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
+}
+
+// create_gap, mipgen.cpp:1261-1278
+void Selector::create_gap(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions)
+{
+    out_.bad_design_count++;
+    if (!f.is_open()) f.open(o_.arg("-project_name") + ext);
+    out_.progress << note << r_->chr << ":\n";
+    const int start = *positions.begin(), stop = start + o_.max_capture / 2;
+    out_.progress << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
+    for (int i = start; i <= stop; i++) positions.erase(i);
+    f << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
+}
+
+// pick_mips, mipgen.cpp:1506-1614
+void Selector::pick()
+{
+    std::set<int> pos, again, minus, minus_again;
+    const int strand_to_use = o_.double_tile_strands_separately ? 0 : -1;
+    for (int p = r_->start_fl; p <= r_->stop_fl; p++) {
+        pos.insert(p);
+        if (o_.double_tile) again.insert(p);
+        if (o_.double_tile_strands_separately) minus.insert(p);
+        if (o_.double_tile && o_.double_tile_strands_separately) minus_again.insert(p);
+    }
+    const bool mixed = o_.score_method == MIPGEN_SCORE_MIXED && rs_;
+    CandPtr picked = optimize_worst(pos, strand_to_use);
+    if (mixed && picked) picked->score = rs_->svr(*picked);
+    while (!pos.empty() && picked && picked->score < lower_) {
+        manage_picked(picked, pos);
+        picked = optimize_worst(pos, strand_to_use);
+        if (mixed && picked) picked->score = rs_->svr(*picked);
+    }
+    if (o_.double_tile_strands_separately) {
+        picked = optimize_worst(minus, 1);                                         // not re-scored here in the reference (:1541)
+        while (!minus.empty() && picked && picked->score < lower_) {
+            manage_picked(picked, minus);
+            picked = optimize_worst(minus, 1);
+            if (mixed && picked) picked->score = rs_->svr(*picked);
+        }
+    }
+    bool extended;
+    if (!pos.empty()) {
+        do {
+            picked = translocate(pos, strand_to_use);
+            extended = *pos.rbegin() - *pos.begin() > o_.max_capture;
+            if (!picked && extended) create_gap(out_.gaps, ".coverage_failed.bed", "GAP INTRODUCED ON CHROMOSOME ", pos);
+            if (picked) manage_picked(picked, pos);
+        } while (!pos.empty() && (picked || extended));
+    }
+    if (!minus.empty()) {
+        do {
+            picked = translocate(minus, 1);
+            extended = *minus.rbegin() - *minus.begin() > o_.max_capture;
+            if (!picked && extended) create_gap(out_.minus_gaps, ".minus_strand_failed.bed", "GAP INTRODUCED ON MINUS STRAND OF CHROMOSOME ", minus);
+            if (picked) manage_picked(picked, minus);
+        } while (!minus.empty() && (picked || extended));
+    }
+    if (o_.double_tile) {
+        do {
+            picked = translocate(again, strand_to_use);
+            extended = !again.empty() && *again.rbegin() - *again.begin() > o_.max_capture;
+            if (!picked && extended) create_gap(out_.double_gaps, ".double_tile_failed.bed", "GAP INTRODUCED ON DOUBLE TILING OF CHROMOSOME ", again);
+            if (picked) manage_picked(picked, again);
+        } while (!again.empty() && (picked || extended));
+        if (o_.double_tile_strands_separately) {
+            // the reference walks positions_to_scan_again here but manages / terminates on positions_to_scan_minus_again (:1597-1607)
+            do {
+                picked = translocate(again, 1);
+                extended = !again.empty() && *again.rbegin() - *again.begin() > o_.max_capture;
+                if (!picked && extended && !minus_again.empty())
+                    create_gap(out_.double_gaps, ".minus_strand_double_tile_failed.bed", "GAP INTRODUCED ON MINUS STRAND OF DOUBLE TILING OF CHROMOSOME ", minus_again);
+                if (picked) manage_picked(picked, minus_again);
+            } while (!minus_again.empty() && (picked || extended));
+        }
+    }
+    print_gaps(out_.gaps, ".coverage_failed.bed", "BASES NOT COVERED ON CHROMOSOME ", pos);
+    print_gaps(out_.double_gaps, ".double_tile_failed.bed", "BASES NOT DOUBLE TILED ON CHROMOSOME ", again);
+    print_gaps(out_.minus_gaps, ".minus_strand_failed.bed", "BASES NOT COVERED ON MINUS STRAND OF CHROMOSOME ", minus);
+    print_gaps(out_.double_minus_gaps, ".minus_strand_double_tile_failed.bed", "BASES NOT DOUBLE TILED ON MINUS STRAND OF CHROMOSOME ", minus_again);
+}
+
+}  // namespace mipgen
