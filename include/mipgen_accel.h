@@ -132,12 +132,16 @@ typedef struct mipgen_grid {
 } mipgen_grid;
 
 /*
- * Dense-grid candidate index within a region:
- *     idx = (((p - first_pos) * n_sizes + (k - k0)) * n_arm_pairs + a) * 2 + strand        strand 0 = '+', 1 = '-'
- * i.e. exactly the reference's generation order (p asc, C desc, arm sum desc, ext asc, plus then minus).
+ * Dense-grid candidate index within a region (strand-major inside a (position, size) row, so that each strand's scores of a
+ * row are contiguous in memory and every result store of the kernels is a full, coalesced segment):
+ *     idx = ((((p - first_pos) * n_sizes + (k - k0)) * 2 + strand) * n_arm_pairs + a         strand 0 = '+', 1 = '-'
+ * The reference's generation order (p asc, C desc, arm sum desc, ext asc, plus then minus: mipgen.cpp:421-491) is recovered by
+ * visiting, for a = 0 .. n_arm_pairs-1, the pair (idx_plus(a), idx_plus(a) + n_arm_pairs); MIPGEN_PLUS_INDEX / MIPGEN_MINUS_INDEX.
  *
  * Integer record per candidate (uint64), the fields design_mip() produces:
  */
+#define MIPGEN_PLUS_INDEX(pi, n_sizes, ki, n_pairs, a)  (((((int64_t)(pi) * (n_sizes)) + (ki)) * 2 + 0) * (n_pairs) + (a))
+#define MIPGEN_MINUS_INDEX(pi, n_sizes, ki, n_pairs, a) (((((int64_t)(pi) * (n_sizes)) + (ki)) * 2 + 1) * (n_pairs) + (a))
 #define MIPGEN_REC_EXT_COPY(r)   ((uint32_t)((r) & 0xFFFFu))            /* ext_probe_copy, saturated at 65535 */
 #define MIPGEN_REC_LIG_COPY(r)   ((uint32_t)(((r) >> 16) & 0xFFFFu))    /* lig_probe_copy, saturated at 65535 */
 #define MIPGEN_REC_MASKED_N(r)   ((uint32_t)(((r) >> 32) & 0xFFu))      /* #N in masked ext + masked lig (mipgen.cpp:606-610) */

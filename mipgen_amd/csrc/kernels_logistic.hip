@@ -88,8 +88,8 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
         uint32_t in_row = idx - rc * row;
         uint32_t pl = nK == 1 ? rc : fastdiv(rc, M_k);            // the magic constant overflows for divisor 1
         uint32_t ki = rc - pl * (uint32_t)nK;
-        const int a = (int)(in_row >> 1);
-        const bool minus = in_row & 1;
+        const bool minus = in_row >= (uint32_t)A;              // strand-major inside a (position, size) row
+        const int a = (int)(minus ? in_row - (uint32_t)A : in_row);
         const int e = P->arm_ext[a], l = P->arm_lig[a];
         const int C = Cmax - (int)ki * P->inc;
         const int ss = C - e - l;

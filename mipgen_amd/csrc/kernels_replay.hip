@@ -56,11 +56,11 @@ __global__ __launch_bounds__(64) void k_replay_condense(
             bool skip_ahead = false;
             for (; a < a_end; a++) {
                 if (skip_ahead) continue;                                            // :440
-                const int64_t idx = base + ((int64_t)ki * A + a) * 2;
+                const int64_t idx = base + ((int64_t)ki * 2) * A + a, idm = idx + A;     // strand-major rows
                 if (!(MIPGEN_REC_FLAGS(records[idx]) & MIPGEN_FLAG_VALID)) continue; // :443-444
-                emitted[idx] = 1; emitted[idx + 1] = 1;
+                emitted[idx] = 1; emitted[idm] = 1;
                 n_emitted += 2;
-                const double plus = scores[idx], minus = scores[idx + 1];
+                const double plus = scores[idx], minus = scores[idm];
                 if (heuristic && plus < (double)previous_plus_score && minus < (double)previous_minus_score) skip_ahead = true;   // :494
                 previous_best_score = (minus > plus) ? minus : plus;                 // :495
                 previous_minus_score = to_int_x86(minus);                            // :496
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_replay_condense(
         uint64_t best_rec = 0;
         bool skip_ahead = false;
         for (int64_t j = per_pos / 2 - 1; j >= 0 && !skip_ahead; j--) {              // newest first (push_front, :475,489)
-            const int64_t idx = base + 2 * j + s;
+            const int64_t idx = base + ((j / A) * 2 + s) * A + (j % A);              // j = (size, pair) in generation order
             if (!emitted[idx]) continue;
             const uint64_t r = records[idx];
             const int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);

@@ -132,12 +132,17 @@ int run(int argc, char** argv)
             out.progress << "designing all mips for feature #" << feature_counter << std::endl;
             std::cerr << "[mipgen] feature #" << feature_counter << std::endl;
             if (!o.silent) {
-                for (int64_t i = 0; i < g.count; i++) {
-                    if (!mask[(size_t)(g.offset + i)]) continue;
-                    out.all_counter++;
-                    const Cand c = make_cand(o, r, g, i, scores[(size_t)(g.offset + i)], records[(size_t)(g.offset + i)]);
-                    out.all << format_record(o, r, tables, c, out.all_counter, false);
-                }
+                // the reference's generation order: position, size, pair, plus then minus (mipgen.cpp:421-491)
+                const int64_t An = (int64_t)o.arm_pairs.size();
+                for (int64_t row = 0; row < (int64_t)g.n_pos * g.n_sizes; row++)
+                    for (int64_t a = 0; a < An; a++)
+                        for (int s = 0; s < 2; s++) {
+                            const int64_t i = (row * 2 + s) * An + a;
+                            if (!mask[(size_t)(g.offset + i)]) continue;
+                            out.all_counter++;
+                            const Cand c = make_cand(o, r, g, i, scores[(size_t)(g.offset + i)], records[(size_t)(g.offset + i)]);
+                            out.all << format_record(o, r, tables, c, out.all_counter, false);
+                        }
             } else out.all_counter += (int)emitted_n[bi];
             out.progress << "condensing feature #" << feature_counter << "\ncollapsing feature #" << feature_counter << std::endl;
             std::vector<mipgen_survivor> rs(surv.begin() + 2 * pos0, surv.begin() + 2 * (pos0 + g.n_pos));

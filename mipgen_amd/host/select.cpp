@@ -20,10 +20,11 @@ Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t 
     (void)r;
     Cand c;
     const int A = (int)o.arm_pairs.size();
-    c.strand = (int)(li & 1);
-    const int64_t pr = li >> 1;
-    const int a = (int)(pr % A);
-    const int64_t rest = pr / A;
+    // strand-major dense order: li = (((pi * n_sizes) + ki) * 2 + strand) * A + a   (include/mipgen_accel.h)
+    const int a = (int)(li % A);
+    const int64_t row = li / A;
+    c.strand = (int)(row & 1);
+    const int64_t rest = row >> 1;
     const int ki = (int)(rest % g.n_sizes);
     const int pi = (int)(rest / g.n_sizes);
     c.ext_len = o.arm_pairs[(size_t)a].first; c.lig_len = o.arm_pairs[(size_t)a].second;

@@ -651,8 +651,8 @@ int mo_score_region_dense(const mipgen_params* P, const mipgen_region* R, const 
     int64_t idx = 0;
     for (int pi = 0; pi < g.n_pos; pi++)
         for (int ki = 0; ki < g.n_sizes; ki++)
-            for (int a = 0; a < P->n_arm_pairs; a++)
-                for (int s = 0; s < 2; s++, idx++) {
+            for (int s = 0; s < 2; s++)                       /* strand-major inside a (position, size) row */
+                for (int a = 0; a < P->n_arm_pairs; a++, idx++) {
                     mipgen_candidate c = {0, g.first_pos + pi, P->max_capture_size - (g.first_size_index + ki) * inc,
                                           P->arm_ext[a], P->arm_lig[a], s};
                     mo_designed d;
@@ -695,11 +695,11 @@ int64_t mo_replay_region(const mipgen_params* P, const mipgen_region* R, const d
                 int skip_ahead = 0;
                 for (; a < a_end; a++) {
                     if (skip_ahead) continue;                              /* :440 */
-                    int64_t idx = ((((int64_t)pi * g.n_sizes + ki) * A) + a) * 2;
+                    int64_t idx = MIPGEN_PLUS_INDEX(pi, g.n_sizes, ki, A, a), idm = MIPGEN_MINUS_INDEX(pi, g.n_sizes, ki, A, a);
                     if (!(MIPGEN_REC_FLAGS(records[idx]) & MIPGEN_FLAG_VALID)) continue;     /* :443-444 */
-                    emitted[idx] = 1; emitted[idx + 1] = 1;
+                    emitted[idx] = 1; emitted[idm] = 1;
                     n_emitted += 2;
-                    double plus = scores[idx], minus = scores[idx + 1];
+                    double plus = scores[idx], minus = scores[idm];
                     if (P->score_method == MIPGEN_SCORE_LOGISTIC && P->logistic_heuristic &&
                         plus < previous_plus_score && minus < previous_minus_score) skip_ahead = 1;   /* :494 */
                     previous_best_score = (minus > plus) ? minus : plus;   /* :495 */
@@ -728,8 +728,8 @@ int mo_condense_region(const mipgen_params* P, const mipgen_region* R, const dou
             best->cand_index = -1; best->score = 0; best->record = 0;
             int skip_ahead = 0;
             /* the list is newest-first (push_front, :475,489): walk the dense order backwards */
-            for (int64_t j = per_pos / 2 - 1; j >= 0; j--) {
-                int64_t idx = (int64_t)pi * per_pos + 2 * j + s;
+            for (int64_t j = per_pos / 2 - 1; j >= 0; j--) {                /* j = (size index, arm pair) in generation order */
+                int64_t idx = (int64_t)pi * per_pos + ((j / A) * 2 + s) * A + (j % A);
                 if (!emitted[idx]) continue;
                 if (skip_ahead) continue;                                                     /* :1687 */
                 uint64_t r = records[idx];
@@ -818,7 +818,7 @@ int64_t mo_enumerate_region(const mipgen_params* P, const mipgen_region* R, cons
                             o->score = sc[s];
                             o->flags[0] = d.mapping_failed; o->flags[1] = d.snp_failed; o->flags[2] = d.masking_failed; o->flags[3] = 0;
                             int ki = size_index(P, C) - g.first_size_index;
-                            o->dense_index = ((((int64_t)(cur - g.first_pos) * g.n_sizes + ki) * A) + a) * 2 + s;
+                            o->dense_index = s == 0 ? MIPGEN_PLUS_INDEX(cur - g.first_pos, g.n_sizes, ki, A, a) : MIPGEN_MINUS_INDEX(cur - g.first_pos, g.n_sizes, ki, A, a);
                         }
                         n++;
                     }

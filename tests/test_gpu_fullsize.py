@@ -36,9 +36,10 @@ def full():
 
 def _decode(P, g, idx):
     A = P.n_arm_pairs
-    strand = idx & 1
-    a = (idx >> 1) % A
-    rest = (idx >> 1) // A
+    a = idx % A
+    row = idx // A
+    strand = row & 1
+    rest = row >> 1
     ki, pi = rest % g.n_sizes, rest // g.n_sizes
     return pi, ki, a, strand
 
@@ -122,9 +123,10 @@ def test_reverse_complement_symmetry(full, method):
         gf, gm = grids
         A = P.n_arm_pairs
         idx = np.arange(gf.count, dtype=np.int64)
-        strand = idx & 1
-        a = (idx >> 1) % A
-        rest = (idx >> 1) // A
+        a = idx % A
+        row = idx // A
+        strand = row & 1
+        rest = row >> 1
         ki, pi = rest % gf.n_sizes, rest // gf.n_sizes
         e = np.array([P.arm_ext[i] for i in range(A)])[a]
         l = np.array([P.arm_lig[i] for i in range(A)])[a]
@@ -134,7 +136,7 @@ def test_reverse_complement_symmetry(full, method):
         pm = G + 2 - p - ss
         pim = pm - gm.first_pos
         ok = (strand == 0) & (pim >= 0) & (pim < gm.n_pos)
-        midx = (((pim * gm.n_sizes + ki) * A + a) * 2 + 1)[ok]
+        midx = (((pim * gm.n_sizes + ki) * 2 + 1) * A + a)[ok]
         fidx = idx[ok]
         rf, rm = records[gf.offset + fidx], records[gm.offset + midx]
         both = ((capi.rec_flags(rf) & capi.FLAG_VALID) != 0) & ((capi.rec_flags(rm) & capi.FLAG_VALID) != 0)
@@ -159,9 +161,11 @@ def test_replay_condense_invariants_full_size(full):
     valid = (capi.rec_flags(full["records"]) & capi.FLAG_VALID) != 0
     assert not (mask.astype(bool) & ~valid).any()                     # only constructible candidates are emitted
     assert int(mask.sum()) == int(emitted.sum())
-    # emission is by (plus, minus) pairs
-    assert np.array_equal(mask[0::2], mask[1::2])
+    # emission is by (plus, minus) pairs: rows of A plus-strand flags are followed by the same A minus-strand flags
+    A = full["P"].n_arm_pairs
+    m2 = mask.reshape(-1, 2, A)
+    assert np.array_equal(m2[:, 0, :], m2[:, 1, :])
     have = surv["cand_index"] >= 0
     assert mask[surv["cand_index"][have]].all()                       # survivors are emitted candidates
     assert np.array_equal(surv["score"][have], full["scores"][surv["cand_index"][have]])
-    assert (surv["cand_index"][have] % 2 == (np.nonzero(have)[0] % 2)).all()     # slot parity = strand
+    assert (((surv["cand_index"][have] // A) % 2) == (np.nonzero(have)[0] % 2)).all()     # survivor slot parity = strand

@@ -206,9 +206,10 @@ def test_edge_cases(genome):
                 pick = np.unique(np.concatenate([rng.choice(valid, size=min(1500, valid.size), replace=False), special]))
                 A = P.n_arm_pairs
                 for idx in pick:
-                    strand = idx & 1
-                    a = (idx >> 1) % A
-                    rest = (idx >> 1) // A
+                    a = idx % A
+                    row = idx // A
+                    strand = row & 1
+                    rest = row >> 1
                     ki, pi = rest % g.n_sizes, rest // g.n_sizes
                     cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment,
                             P.arm_ext[a], P.arm_lig[a], int(strand))

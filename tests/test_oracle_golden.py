@@ -100,9 +100,9 @@ def test_dense_grid_plus_replay_equals_literal_loop(name):
         n, buf = po.enumerate_region(P, rd, method, model)
         assert n == n_emit
         idx = np.nonzero(mask)[0]
-        lit = np.array([buf[i].dense_index for i in range(n)], dtype=np.int64)
-        assert np.array_equal(idx, lit)
+        lit = np.array([buf[i].dense_index for i in range(n)], dtype=np.int64)      # generation order (plus, minus per pair)
+        assert np.array_equal(idx, np.sort(lit)) and np.unique(lit).size == n        # same set; the dense order is strand-major
         lit_scores = np.array([buf[i].score for i in range(n)])
-        assert np.array_equal(scores[idx], lit_scores, equal_nan=True)
+        assert np.array_equal(scores[lit], lit_scores, equal_nan=True)
         total += n
     assert total == meta["lines"]["all_mips"] - 1
