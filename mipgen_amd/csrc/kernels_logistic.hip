@@ -19,6 +19,7 @@
 #include "logistic_device.h"
 
 // grid = number of tiles; block = LOG_THREADS; dynamic LDS = lds_bytes(span_max)
+#define LOG_RINV 512
 template <bool SCORE>
 __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
     const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, const LogTile* __restrict__ tiles,
@@ -43,8 +44,10 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
     uint64_t* W1 = W0 + (span + 1);
     uint64_t* W2 = W1 + (span + 1);
     uint64_t* scratch = W2 + (span + 1);                       // 8
-    uint8_t* sb = (uint8_t*)(scratch + 8);                     // span
+    double* rinv = (double*)(scratch + 8);                     // LOG_RINV entries: 1.0 / i by true division
+    uint8_t* sb = (uint8_t*)(rinv + LOG_RINV);                 // span
 
+    for (int i = tid; i < LOG_RINV; i += LOG_THREADS) rinv[i] = i > 0 ? 1.0 / (double)i : 0.0;
     // ---- stage bases, per-base indicator words ---------------------------------------------------
     for (int i = tid; i < span; i += LOG_THREADS) {
         int pos = lo + i;
@@ -168,16 +171,18 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
                     const double e_a = minus ? (double)eT : (double)eA, l_a = minus ? (double)lT : (double)lA,
                                  t_a = minus ? (double)tT : (double)tA;
                     const double e_gc = (double)(eC + eG), l_gc = (double)(lC + lG), t_gc = (double)(tC + tG);
-                    x.v[MLV_BPS] = dn / (double)run;
+                    // contents = count * (1/len) with 1/len from the table (the reference divides; the quotients agree to 1 ulp)
+                    const double re = rinv[e], rl = rinv[l], rn = ss < LOG_RINV ? rinv[ss] : 1.0 / dn;
+                    x.v[MLV_BPS] = run < LOG_RINV ? dn * rinv[run] : dn / (double)run;
                     x.v[MLV_TLEN] = ss > 250 ? 250.0 : dn;
                     x.v[MLV_ELEN] = dl; x.v[MLV_LLEN] = ll;
-                    x.v[MLV_EGC] = e_gc / dl; x.v[MLV_LGC] = l_gc / ll; x.v[MLV_TGC] = t_gc / dn;
-                    x.v[MLV_EG] = e_g / dl; x.v[MLV_LG] = l_g / ll; x.v[MLV_TG] = t_g / dn;
-                    x.v[MLV_EA] = e_a / dl; x.v[MLV_LA] = l_a / ll; x.v[MLV_TA] = t_a / dn;
+                    x.v[MLV_EGC] = e_gc * re; x.v[MLV_LGC] = l_gc * rl; x.v[MLV_TGC] = t_gc * rn;
+                    x.v[MLV_EG] = e_g * re; x.v[MLV_LG] = l_g * rl; x.v[MLV_TG] = t_g * rn;
+                    x.v[MLV_EA] = e_a * re; x.v[MLV_LA] = l_a * rl; x.v[MLV_TA] = t_a * rn;
                     x.v[MLV_JS] = jc < 16 ? c_junction_scores[jc] : 0.0;
                     x.v[MLV_LEC] = log_copy_dev(HC, ext_copy);
                     x.v[MLV_LLC] = log_copy_dev(HC, lig_copy);
-                    score = logistic_from_vars(HC, x);
+                    score = logistic_from_exponent_fast(HC, logistic_exponent(x));
                 }
             }
         }
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
 
 extern "C" size_t mipgen_logistic_lds_bytes(int span)
 {
-    return (size_t)(3 * (span + 1) + 8) * sizeof(uint64_t) + (size_t)span + 16;
+    return (size_t)(3 * (span + 1) + 8 + LOG_RINV) * sizeof(uint64_t) + (size_t)span + 16;
 }
 
 extern "C" hipError_t mipgen_launch_records_logistic(

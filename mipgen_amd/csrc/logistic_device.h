@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "common.h"
 #include "../../include/mipgen_logistic_model.h"
+#include "exp2_coef.h"
 
 // constants computed by the HOST libm once per process, so that table-driven values are bit-identical to what the
 // reference's own log10()/log() calls return on the host
@@ -72,6 +73,26 @@ __device__ __forceinline__ double logistic_exponent(const Vars& x)
 __device__ __forceinline__ double logistic_from_vars(const HostConsts* HC, const Vars& x)
 {
     const double y = exp(logistic_exponent(x) * HC->ln_base);
+    return y / (1.0 + y);
+}
+
+// Same value through exp2: y = 2^(ex * log2(2.71828)) with the degree-10 near-minimax polynomial (6.7e-16), no libm call.
+// Non-finite exponents (copy number 0 -> log10 = -inf -> inf - inf) take the libm route so NaN / 0 / NaN come out as in the reference.
+__device__ __forceinline__ double logistic_from_exponent_fast(const HostConsts* HC, double ex)
+{
+    constexpr double c[11] = EXP2_COEF_10;
+    const double t0 = ex * (HC->ln_base * 1.4426950408889634074);
+    if (!(fabs(t0) < 1000.0)) {                                 // also catches NaN
+        const double y = exp(ex * HC->ln_base);
+        return y / (1.0 + y);
+    }
+    const double MAGIC = 6755399441055744.0;
+    const double tm = t0 + MAGIC;
+    const double f = t0 - (tm - MAGIC);
+    double p = c[10];
+#pragma unroll
+    for (int k = 9; k >= 0; k--) p = fma(p, f, c[k]);
+    const double y = __hiloint2double(__double2hiint(p) + (__double2loint(tm) << 20), __double2loint(p));
     return y / (1.0 + y);
 }
 

@@ -1,6 +1,7 @@
 // main.cpp — the drop-in `mipgen` command line: same options, inputs and output files as the reference
 // (/root/reference/mipgen.cpp:2021-2037 main, :293-400 query_sequences, :403-556 tile_regions), with candidate
 // construction + scoring + replay/condense delegated to libmipgen_accel.so (HIP, gfx950) through its C ABI.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -89,7 +90,8 @@ int run(int argc, char** argv)
     Selector selector(o, tables, out);
     AccelRescorer rescorer;
     rescorer.h = accel;
-    const int64_t budget = 48LL << 20;                                       // dense candidates per batch (16 B each on the device)
+    int64_t budget = 48LL << 20;                                             // dense candidates per batch (16 B each on the device)
+    if (const char* e = std::getenv("MIPGEN_BATCH_CANDIDATES")) budget = std::max<int64_t>(1, std::atoll(e));   // tests force several batches
     size_t next = 0;
     int feature_counter = 0;
     while (next < regions.size()) {
