@@ -106,7 +106,7 @@ struct SvrGeom {
 };
 
 #define SVR_MAX_CHUNK 20
-#define SVR_CW_MAX 6           // max prefix-array slots per lane in the fused scans (host checks)
+#define SVR_CW_MAX 4           // max prefix-array slots per lane in the fused scans (host checks)
 #define SVR_TB 2               // table entries per thread per batch
 #define SVR_MAX_LISTS 3        // arm-sum lists a wave's chunk of <= 20 pairs may touch (host checks)
 #define SVR_GROUP 3            // support vectors staged (and interleaved in the candidate loop) per iteration
@@ -179,9 +179,8 @@ static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n
     // scan units: one wavefront per array; the array occupies 16, 32 or 64 lanes (DPP rows)
     for (int k = 0; k < SVR_N_ARR; k++) {
         const int slots = L.arr_len[k] + 1;
-        int lanes = 16;
-        while (lanes < 64 && (slots + lanes - 1) / lanes > SVR_CW_MAX) lanes *= 2;
-        L.chunk[k] = (slots + lanes - 1) / lanes;
+        // all 64 lanes (four DPP rows) take part: the fewest slots per lane, hence the shortest dependent chain
+        L.chunk[k] = (slots + 63) / 64;
     }
     return L;
 }
