@@ -23,7 +23,7 @@ hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, i
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
                                           double*, uint64_t*);
 size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l);
-hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
+hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int cw, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
                                    const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
                                    const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
                                    const uint64_t* records, double* scores);
@@ -99,6 +99,7 @@ struct mipgen_accel {
     DevBuf<SvrTile> svr_tiles;
     int n_log_tiles = 0, n_svr_tiles = 0, log_span_max = 0;
     size_t svr_lds = 0;
+    int svr_cw = 4;                   // prefix-array slots per lane of the scan units (kernel template parameter: 4 or 8)
     DevBuf<double> scores;
     DevBuf<uint64_t> records;
     bool scored = false;
@@ -449,6 +450,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     const int Lmax = std::max(D.e_max, D.l_max);
     int span_max = 0;
     size_t svr_lds = 0;
+    int svr_cw = 4;
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
     for (int i = 0; i < n; i++) {
         const DevRegion& d = h->hregions[i];
@@ -460,29 +462,37 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
             lt.push_back(t);
             span_max = std::max(span_max, t.np + Cmax + Lmax);
         }
-        // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs filling 256 threads
-        const int KC_CAP = 9, NP_CAP = 32;
-        const int nkc = (d.n_sizes + KC_CAP - 1) / KC_CAP;
-        for (int c = 0; c < nkc; c++) {
-            const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
-            const int kc = ki1 - ki0;
-            int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
-            const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
-            const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
-            for (int p0 = 0; p0 < d.n_pos; p0 += np) {
-                const int npt = std::min(np, d.n_pos - p0);
-                for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; st.push_back(t); }
-            }
-            {
+        // SVR tiles: capture sizes in nearly equal runs of <= 9 (fewer when the scan-size range would not fit LDS), positions in runs
+        // that fill the block's lanes
+        const int NP_CAP = 32;
+        for (int kc_cap = 9; kc_cap >= 1; kc_cap--) {
+            std::vector<SvrTile> rt;
+            size_t lds_r = 0;
+            int cw_r = 0;
+            const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
+            for (int c = 0; c < nkc; c++) {
+                const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
+                const int kc = ki1 - ki0;
+                const int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
+                const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
+                const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
+                for (int p0 = 0; p0 < d.n_pos; p0 += np) {
+                    const int npt = std::min(np, d.n_pos - p0);
+                    for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; rt.push_back(t); }
+                }
+                lds_r = std::max(lds_r, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
                 const SvrLayout Lt = svr_layout(np, ssmin, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
-                int cmax = 0;
-                for (int k = 0; k < SVR_N_ARR; k++) cmax = std::max(cmax, Lt.chunk[k]);
-                if (cmax > SVR_CW_MAX)
-                    return fail(MIPGEN_E_INVALID, "capture range too wide for the dense SVR kernel: %d prefix slots per lane (max %d)", cmax, SVR_CW_MAX);
+                for (int k = 0; k < SVR_N_ARR; k++) cw_r = std::max(cw_r, Lt.chunk[k]);
             }
-            svr_lds = std::max(svr_lds, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
+            if (lds_r <= 160 * 1024 || kc_cap == 1) {
+                st.insert(st.end(), rt.begin(), rt.end());
+                svr_lds = std::max(svr_lds, lds_r);
+                svr_cw = std::max(svr_cw, cw_r);
+                break;
+            }
         }
     }
+    if (svr_cw > 8) return fail(MIPGEN_E_INVALID, "capture sizes too large for the dense SVR kernel: %d prefix slots per lane (max 8, i.e. scan sizes up to ~480)", svr_cw);
     if (svr_lds > 160 * 1024) return fail(MIPGEN_E_INVALID, "SVR tile needs %zu bytes of LDS (> 160 KiB): capture range / arm lists too wide", svr_lds);
     if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
         h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
@@ -509,7 +519,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     if (!st.empty()) HIP_TRY(hipMemcpyAsync(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
-    h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds;
+    h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds; h->svr_cw = svr_cw <= 4 ? 4 : 8;
     if (getenv("MIPGEN_ACCEL_VERBOSE"))
         fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates, %d record tiles (LDS %zu B), %d SVR tiles x %d threads (LDS %zu B)\n", n,
                 (long long)cand_total, h->n_log_tiles, mipgen_logistic_lds_bytes(span_max), h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, svr_lds);
@@ -532,7 +542,7 @@ int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     if (method == MIPGEN_SCORE_SVR) {
         const double gamma_l2e = h->gamma * 1.4426950408889634074;
-        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->svr_cw, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
                                         h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard,
                                         h->records.p, h->scores.p));
     }

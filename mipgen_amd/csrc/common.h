@@ -106,7 +106,7 @@ struct SvrGeom {
 };
 
 #define SVR_MAX_CHUNK 20
-#define SVR_CW_MAX 4           // max prefix-array slots per lane in the fused scans (host checks)
+#define SVR_CW_MAX 8           // max prefix-array slots per lane in the fused scans (host checks)
 #define SVR_TB 2               // table entries per thread per batch
 #define SVR_MAX_LISTS 3        // arm-sum lists a wave's chunk of <= 20 pairs may touch (host checks)
 #define SVR_GROUP 3            // support vectors staged (and interleaved in the candidate loop) per iteration

@@ -241,3 +241,28 @@ def test_error_paths(genome):
         capi.Accel(bad)
     acc.close()
     assert lib.mipgen_accel_device_count() >= 1
+
+
+def test_very_wide_capture_range(genome):
+    """capture 120-300 step 20 (scan sizes up to 260, nine sizes spanning 160 bases): the host shortens the capture-size runs
+    until the tile fits LDS and selects the 8-slots-per-lane scan instantiation; sampled candidates still match the oracle."""
+    P = capi.make_params(120, 300, score_method=capi.SCORE_SVR, capture_increment=20)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    rd = capi.build_region(genome, "1", 8000, 8320, P, bwa_mode="hashed", label="wide", lrc=np.full(44, 0.07))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    g = grids[0]
+    valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
+    rng = np.random.default_rng(9)
+    A = P.n_arm_pairs
+    for idx in rng.choice(valid, size=400, replace=False):
+        a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
+        ki, pi = rest % g.n_sizes, rest // g.n_sizes
+        cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
+        sk, d = po.design(P, rd, cand)
+        so, _, _ = po.score_designed(d, capi.SCORE_SVR, np.array(rd.c.long_range_content[:]), om)
+        ok, _ = _close([scores[idx]], [so])
+        assert ok.all(), (cand, scores[idx], so)
+    acc.close()
