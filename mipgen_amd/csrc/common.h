@@ -122,23 +122,42 @@ struct SvrGeom {
 #define SVR_N_ARR 7          // prefix arrays per support vector: insert 1/2/3-mers, upstream arm 1/2-mers, downstream arm 1/2-mers
 struct SvrLayout {
     int NI, rinv, lg10, rows, pf, tb;          // SV-independent: insert norms, reciprocals, log10(0..100); then the buffers
-    int arr[SVR_N_ARR];                        // inside one per-SV PF block: the seven prefix arrays (len+1 slots each)
-    int arr_len[SVR_N_ARR];                    // elements per array (without the trailing total slot)
+    // the seven prefix arrays of a per-SV PF block (len+1 slots each) are described by svr_arr_len / svr_arr_off / svr_arr_chunk
+    // below: plain scalars only, so that the device copy of this struct stays in SGPRs (an indexed member would put it in scratch)
     int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; doubles per SV
     int tu, td, tb_stride;                     // TB block: partial-distance tables; doubles per SV
     int bytes_desc, bytes_ent, bytes_idx, bytes_sb;   // byte offsets: scan descriptors (int), table-entry descriptors (3 x u32),
                                                // per-slot SV-row indices of the scans (u16), bases (u8)
-    int idx_off[SVR_N_ARR];                    // first u16 of each array in the index table
     int n_ent;                                 // partial-distance table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
-    int chunk[SVR_N_ARR];                      // prefix-array slots per lane in that array's scan unit (<= SVR_CW_MAX)
 };
+
+// elements of prefix array k (without the trailing total slot): insert 1/2/3-mers, upstream 1/2-mers, downstream 1/2-mers
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+__attribute__((always_inline)) static inline int svr_arr_len(const SvrLayout& L, int k) { return k < 3 ? +L.ins_len : (k < 5 ? +L.up_cnt : +L.dn_cnt); }   // unary +: select values, not addresses
+// first slot of array k inside a PF block; also its first u16 in the SV-row index table
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+__attribute__((always_inline)) static inline int svr_arr_off(const SvrLayout& L, int k)
+{
+    const int ki = k < 3 ? k : 3, ku = k < 3 ? 0 : (k < 5 ? k - 3 : 2), kd = k < 5 ? 0 : k - 5;
+    return ki * (L.ins_len + 1) + ku * (L.up_cnt + 1) + kd * (L.dn_cnt + 1);
+}
+// prefix-array slots per lane in that array's scan unit (<= SVR_CW_MAX): one wavefront per array, all 64 lanes (four DPP rows)
+// take part, which gives the fewest slots per lane and hence the shortest dependent chain
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+__attribute__((always_inline)) static inline int svr_arr_chunk(const SvrLayout& L, int k) { return (svr_arr_len(L, k) + 1 + 63) / 64; }
 
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group, int n_up, int n_dn)
+__attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group, int n_up, int n_dn)
 {
     SvrLayout L;
     const int ssr = ssmax - ssmin + 1;
@@ -154,11 +173,7 @@ static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n
     L.lg10 = o; o += 102;
     L.n_ent = np * n_up + L.nq * n_dn;
     L.rows = o; o += 3 * group * SV_ROW;
-    int g = 0;
-    for (int k = 0; k < SVR_N_ARR; k++) {
-        L.arr_len[k] = k < 3 ? L.ins_len : (k < 5 ? L.up_cnt : L.dn_cnt);
-        L.arr[k] = g; g += L.arr_len[k] + 1;
-    }
+    int g = 3 * (L.ins_len + 1) + 2 * (L.up_cnt + 1) + 2 * (L.dn_cnt + 1);     // the seven prefix arrays
     L.ku = g; g += n_arm; L.kd = g; g += n_arm;
     L.ci = g; g += 2;
     L.pf_stride = g;
@@ -173,15 +188,9 @@ static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n
     L.bytes_desc = bytes; bytes += SVR_N_ARR * 16 * 4;
     L.bytes_ent = bytes; bytes += 3 * L.n_ent * 4;     // per entry: packed slots, packed fields, f32 window norm
     L.bytes_idx = bytes;
-    { int t = 0; for (int k = 0; k < SVR_N_ARR; k++) { L.idx_off[k] = t; t += L.arr_len[k] + 1; } bytes += 2 * t; bytes = (bytes + 7) & ~7; }
+    bytes += 2 * (3 * (L.ins_len + 1) + 2 * (L.up_cnt + 1) + 2 * (L.dn_cnt + 1)); bytes = (bytes + 7) & ~7;
     L.bytes_sb = bytes; bytes += L.span_b + 8;
     L.total_bytes = (bytes + 15) & ~15;
-    // scan units: one wavefront per array; the array occupies 16, 32 or 64 lanes (DPP rows)
-    for (int k = 0; k < SVR_N_ARR; k++) {
-        const int slots = L.arr_len[k] + 1;
-        // all 64 lanes (four DPP rows) take part: the fewest slots per lane, hence the shortest dependent chain
-        L.chunk[k] = (slots + 63) / 64;
-    }
     return L;
 }
 
