@@ -23,7 +23,7 @@ hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, i
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
                                           double*, uint64_t*);
 size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l);
-hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int cw, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
+hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
                                    const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
                                    const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
                                    const uint64_t* records, double* scores);
@@ -99,7 +99,6 @@ struct mipgen_accel {
     DevBuf<SvrTile> svr_tiles;
     int n_log_tiles = 0, n_svr_tiles = 0, log_span_max = 0;
     size_t svr_lds = 0;
-    int svr_cw = 4;                   // prefix-array slots per lane of the scan units (kernel template parameter: 4 or 8)
     DevBuf<double> scores;
     DevBuf<uint64_t> records;
     bool scored = false;
@@ -221,14 +220,6 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     G.nchunk = (D.n_pairs + SVR_MAX_CHUNK - 1) / SVR_MAX_CHUNK;
     G.chunk_len = (D.n_pairs + G.nchunk - 1) / G.nchunk;
     G.n_e = D.e_max - D.e_min + 1; G.n_l = D.l_max - D.l_min + 1;
-    for (int c = 0; c < G.nchunk; c++) {                     // arm-sum lists touched by one chunk of pairs
-        int lists = 0, prev = -1;
-        for (int i = c * G.chunk_len; i < std::min(D.n_pairs, (c + 1) * G.chunk_len); i++) {
-            const int sum = D.arm_ext[i] + D.arm_lig[i];
-            if (sum != prev) { lists++; prev = sum; }
-        }
-        if (lists > SVR_MAX_LISTS) { delete h; return fail(MIPGEN_E_INVALID, "arm-pair list too fragmented for the dense SVR kernel: %d arm sums within %d consecutive pairs (max %d)", lists, G.chunk_len, SVR_MAX_LISTS); }
-    }
     G.group = SVR_GROUP;
     G.wpc = 4;
     if (const char* e = getenv("MIPGEN_ACCEL_SVR_WPC")) G.wpc = std::max(1, atoi(e));   // tuning knob: waves per arm-pair chunk
@@ -448,7 +439,6 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     const int Lmax = std::max(D.e_max, D.l_max);
     int span_max = 0;
     size_t svr_lds = 0;
-    int svr_cw = 4;
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
     for (int i = 0; i < n; i++) {
         const DevRegion& d = h->hregions[i];
@@ -466,7 +456,6 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         for (int kc_cap = 9; kc_cap >= 1; kc_cap--) {
             std::vector<SvrTile> rt;
             size_t lds_r = 0;
-            int cw_r = 0;
             const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
             for (int c = 0; c < nkc; c++) {
                 const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
@@ -479,18 +468,14 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                     for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; rt.push_back(t); }
                 }
                 lds_r = std::max(lds_r, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
-                const SvrLayout Lt = svr_layout(np, ssmin, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
-                for (int k = 0; k < SVR_N_ARR; k++) cw_r = std::max(cw_r, svr_arr_chunk(Lt, k));
             }
             if (lds_r <= 160 * 1024 || kc_cap == 1) {
                 st.insert(st.end(), rt.begin(), rt.end());
                 svr_lds = std::max(svr_lds, lds_r);
-                svr_cw = std::max(svr_cw, cw_r);
                 break;
             }
         }
     }
-    if (svr_cw > 8) return fail(MIPGEN_E_INVALID, "capture sizes too large for the dense SVR kernel: %d prefix slots per lane (max 8, i.e. scan sizes up to ~480)", svr_cw);
     if (svr_lds > 160 * 1024) return fail(MIPGEN_E_INVALID, "SVR tile needs %zu bytes of LDS (> 160 KiB): capture range / arm lists too wide", svr_lds);
     if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
         h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
@@ -517,7 +502,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     if (!st.empty()) HIP_TRY(hipMemcpyAsync(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
-    h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds; h->svr_cw = svr_cw <= 4 ? 4 : 8;
+    h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds;
     if (getenv("MIPGEN_ACCEL_VERBOSE"))
         fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates, %d record tiles (LDS %zu B), %d SVR tiles x %d threads (LDS %zu B)\n", n,
                 (long long)cand_total, h->n_log_tiles, mipgen_logistic_lds_bytes(span_max), h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, svr_lds);
@@ -540,7 +525,7 @@ int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     if (method == MIPGEN_SCORE_SVR) {
         const double gamma_l2e = h->gamma * 1.4426950408889634074;
-        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->svr_cw, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
                                         h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard,
                                         h->records.p, h->scores.p));
     }

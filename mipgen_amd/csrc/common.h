@@ -106,29 +106,31 @@ struct SvrGeom {
 };
 
 #define SVR_MAX_CHUNK 20
-#define SVR_CW_MAX 8           // max prefix-array slots per lane in the fused scans (host checks)
-#define SVR_TB 2               // table entries per thread per batch
-#define SVR_MAX_LISTS 3        // arm-sum lists a wave's chunk of <= 20 pairs may touch (host checks)
-#define SVR_GROUP 3            // support vectors staged (and interleaved in the candidate loop) per iteration
+#define SVR_GROUP 3            // support vectors staged (and interleaved in every stage) per iteration
 #define SVR_MAX_THREADS 768   // nchunk * wpc * 64 <= 768 (12 waves = 3 per SIMD at <= 168 VGPRs)
 #define LOG_THREADS 256
 
 // LDS layout of one dense-SVR tile (offsets in doubles unless noted); shared by host sizing and the kernel.
-// The SV loop is software pipelined over groups of SVR_GROUP support vectors:
-//     scan(k)    writes PF[k % 2]   (seven prefix arrays + per-length constants + insert constant of each SV of the group)
-//     tables(k)  reads  PF[k % 2], writes TB[k % 2]   (partial distances of the upstream / downstream arm windows)
-//     accumulate(k) reads TB[k % 2]  (and latches its insert partials from PF[k % 2] one barrier earlier)
-// rows[k % 3] holds the group's SV rows.
+// The RBF value of a candidate factorises over the feature blocks, K = 2^U(pl,e) * 2^D(pl+ss,l) * coef 2^I(pl,ss), so a group of
+// SVR_GROUP support vectors goes through two phases (one barrier after each):
+//     X  tables(k):      reads PF[k % 2] and rows[k % 2]; writes the factor tables TB (upstream | downstream arm windows) and IT (inserts)
+//        scan(k+1):      reads rows[(k+1) % 2], writes PF[(k+1) % 2] (the seven prefix arrays + per-length constants + insert
+//                        constant of each SV of the next group) - latency bound, it hides under the VALU-bound table entries
+//     Y  accumulate(k):  reads TB, IT;   rows of group k+2 -> rows[k % 2]
+// PF, TB, IT and rows are SV-interleaved ([slot][SVR_GROUP]): one address register serves the three staged SVs through the
+// instruction's immediate offset.
 #define SVR_N_ARR 7          // prefix arrays per support vector: insert 1/2/3-mers, upstream arm 1/2-mers, downstream arm 1/2-mers
 struct SvrLayout {
-    int NI, rinv, lg10, rows, pf, tb;          // SV-independent: insert norms, reciprocals, log10(0..100); then the buffers
-    // the seven prefix arrays of a per-SV PF block (len+1 slots each) are described by svr_arr_len / svr_arr_off / svr_arr_chunk
+    int rinv, lg10, rows, pf, tb, it;          // SV-independent: reciprocals, log10(0..101); then the buffers
+    // the seven prefix arrays of a PF block (len+1 slots each) are described by svr_arr_len / svr_arr_off / svr_arr_chunk
     // below: plain scalars only, so that the device copy of this struct stays in SGPRs (an indexed member would put it in scratch)
-    int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; doubles per SV
-    int tu, td, tb_stride;                     // TB block: partial-distance tables; doubles per SV
-    int bytes_desc, bytes_ent, bytes_idx, bytes_sb;   // byte offsets: scan descriptors (int), table-entry descriptors (3 x u32),
-                                               // per-slot SV-row indices of the scans (u16), bases (u8)
-    int n_ent;                                 // partial-distance table entries per SV
+    int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; slots per SV
+    int tu, td, tb_stride;                     // TB block: first upstream / downstream slot; slots per SV
+    int ssr_p;                                 // IT row pitch in slots (scan-size range rounded up to odd: bank spread)
+    int bytes_desc, bytes_ent, bytes_idx, bytes_sb, bytes_ni, bytes_psum;   // byte offsets: scan descriptors (int), table-entry
+                                               // descriptors (3 x u32), per-slot SV-row indices of the scans (u16), bases (u8),
+                                               // insert-window norms (f32 [np][ssr]), arm-pair sums (u16)
+    int n_ent;                                 // arm-window table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
 };
@@ -147,12 +149,11 @@ __attribute__((always_inline)) static inline int svr_arr_off(const SvrLayout& L,
     const int ki = k < 3 ? k : 3, ku = k < 3 ? 0 : (k < 5 ? k - 3 : 2), kd = k < 5 ? 0 : k - 5;
     return ki * (L.ins_len + 1) + ku * (L.up_cnt + 1) + kd * (L.dn_cnt + 1);
 }
-// prefix-array slots per lane in that array's scan unit (<= SVR_CW_MAX): one wavefront per array, all 64 lanes (four DPP rows)
-// take part, which gives the fewest slots per lane and hence the shortest dependent chain
+// prefix-array slots per lane in that array's scan unit: one 16-lane DPP row per (array, SV)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-__attribute__((always_inline)) static inline int svr_arr_chunk(const SvrLayout& L, int k) { return (svr_arr_len(L, k) + 1 + 63) / 64; }
+__attribute__((always_inline)) static inline int svr_arr_chunk(const SvrLayout& L, int k) { return (svr_arr_len(L, k) + 1 + 15) / 16; }
 
 #if defined(__HIPCC__)
 __host__ __device__
@@ -168,25 +169,28 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.span_b = np + ssmax + 2 * Lmax + 1;
     L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
     int o = 0;
-    L.NI = o; o += np * ssr;
     L.rinv = o; o += L.rinv_len;
     L.lg10 = o; o += 102;
     L.n_ent = np * n_up + L.nq * n_dn;
-    L.rows = o; o += 3 * group * SV_ROW;
+    L.rows = o; o += 2 * group * SV_ROW;
     int g = 3 * (L.ins_len + 1) + 2 * (L.up_cnt + 1) + 2 * (L.dn_cnt + 1);     // the seven prefix arrays
     L.ku = g; g += n_arm; L.kd = g; g += n_arm;
-    L.ci = g; g += 2;
+    L.ci = g; g += 1;
     L.pf_stride = g;
     // the phase-0 scratch (np * 80 u16 counters) aliases the PF area
-    int pf_doubles = 2 * group * L.pf_stride;
+    int pf_doubles = 2 * group * L.pf_stride;                 // double buffered: scan(k+1) runs beside tables(k)
     const int scratch_doubles = (np * 80 * 2 + 7) / 8;
     if (pf_doubles < scratch_doubles) pf_doubles = scratch_doubles;
     L.pf = o; o += pf_doubles;
     L.tu = 0; L.td = np * n_arm; L.tb_stride = np * n_arm + L.nq * n_arm;
-    L.tb = o; o += 2 * group * L.tb_stride;
+    L.tb = o; o += group * L.tb_stride;
+    L.ssr_p = ssr | 1;
+    L.it = o; o += group * np * L.ssr_p;
     int bytes = o * 8;
     L.bytes_desc = bytes; bytes += SVR_N_ARR * 16 * 4;
     L.bytes_ent = bytes; bytes += 3 * L.n_ent * 4;     // per entry: packed slots, packed fields, f32 window norm
+    L.bytes_ni = bytes; bytes += np * ssr * 4;
+    L.bytes_psum = bytes; bytes += 2 * SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64) + 16;   // + the work counter of the table stage
     L.bytes_idx = bytes;
     bytes += 2 * (3 * (L.ins_len + 1) + 2 * (L.up_cnt + 1) + 2 * (L.dn_cnt + 1)); bytes = (bytes + 7) & ~7;
     L.bytes_sb = bytes; bytes += L.span_b + 8;
