@@ -105,9 +105,9 @@ struct SvrGeom {
     int32_t pad[2];
 };
 
-#define SVR_MAX_CHUNK 20
+#define SVR_MAX_CHUNK 15
 #define SVR_GROUP 3            // support vectors staged (and interleaved in every stage) per iteration
-#define SVR_MAX_THREADS 768   // nchunk * wpc * 64 <= 768 (12 waves = 3 per SIMD at <= 168 VGPRs)
+#define SVR_MAX_THREADS 1024  // nchunk * wpc * 64 <= 1024 (16 waves = 4 per SIMD at <= 128 VGPRs)
 #define LOG_THREADS 256
 
 // LDS layout of one dense-SVR tile (offsets in doubles unless noted); shared by host sizing and the kernel.
