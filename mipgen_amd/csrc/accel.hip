@@ -460,7 +460,9 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
             for (int c = 0; c < nkc; c++) {
                 const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
                 const int kc = ki1 - ki0;
-                const int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
+                int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
+                // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping)
+                { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 8 >= np * 7) np = np_cf; }
                 const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
                 const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
                 for (int p0 = 0; p0 < d.n_pos; p0 += np) {

@@ -133,6 +133,8 @@ struct SvrLayout {
     int n_ent;                                 // arm-window table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
+    int ins_sl, up_sl, dn_sl;                  // slots of one insert / upstream / downstream prefix array: len + 1 rounded up to 16 * 4k
+                                               // (a scan lane owns 4k consecutive slots; the padding gathers the always-zero SV slot)
 };
 
 // elements of prefix array k (without the trailing total slot): insert 1/2/3-mers, upstream 1/2-mers, downstream 1/2-mers
@@ -140,21 +142,24 @@ struct SvrLayout {
 __host__ __device__
 #endif
 __attribute__((always_inline)) static inline int svr_arr_len(const SvrLayout& L, int k) { return k < 3 ? +L.ins_len : (k < 5 ? +L.up_cnt : +L.dn_cnt); }   // unary +: select values, not addresses
-// first slot of array k inside a PF block; also its first u16 in the SV-row index table
+// slots of array k (padded), and its first slot inside a PF block; also its first entry in the scan index table
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+__attribute__((always_inline)) static inline int svr_pad_slots(int len) { return ((len + 1 + 63) / 64) * 64; }
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 __attribute__((always_inline)) static inline int svr_arr_off(const SvrLayout& L, int k)
 {
     const int ki = k < 3 ? k : 3, ku = k < 3 ? 0 : (k < 5 ? k - 3 : 2), kd = k < 5 ? 0 : k - 5;
-    return ki * (L.ins_len + 1) + ku * (L.up_cnt + 1) + kd * (L.dn_cnt + 1);
+    return ki * L.ins_sl + ku * L.up_sl + kd * L.dn_sl;
 }
-// prefix-array slots per lane in that array's scan unit: one 16-lane DPP row per (array, SV)
+// prefix-array slots per lane in that array's scan unit: one 16-lane DPP row per (array, SV); a multiple of 4
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-__attribute__((always_inline)) static inline int svr_arr_chunk(const SvrLayout& L, int k) { return (svr_arr_len(L, k) + 1 + 15) / 16; }
-
+__attribute__((always_inline)) static inline int svr_arr_chunk(const SvrLayout& L, int k) { return (k < 3 ? +L.ins_sl : (k < 5 ? +L.up_sl : +L.dn_sl)) / 16; }
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -166,6 +171,7 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.ins_len = np + ssmax;                 // insert prefix arrays cover positions [p_first, p_first + ins_len)
     L.up_cnt = Lmax + np;
     L.dn_cnt = L.nq + Lmax;
+    L.ins_sl = svr_pad_slots(L.ins_len); L.up_sl = svr_pad_slots(L.up_cnt); L.dn_sl = svr_pad_slots(L.dn_cnt);
     L.span_b = np + ssmax + 2 * Lmax + 1;
     L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
     int o = 0;
@@ -173,7 +179,7 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.lg10 = o; o += 102;
     L.n_ent = np * n_up + L.nq * n_dn;
     L.rows = o; o += 2 * group * SV_ROW;
-    int g = 3 * (L.ins_len + 1) + 2 * (L.up_cnt + 1) + 2 * (L.dn_cnt + 1);     // the seven prefix arrays
+    int g = 3 * L.ins_sl + 2 * L.up_sl + 2 * L.dn_sl;                         // the seven prefix arrays
     L.ku = g; g += n_arm; L.kd = g; g += n_arm;
     L.ci = g; g += 1;
     L.pf_stride = g;
@@ -191,8 +197,9 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.bytes_ent = bytes; bytes += 3 * L.n_ent * 4;     // per entry: packed slots, packed fields, f32 window norm
     L.bytes_ni = bytes; bytes += np * ssr * 4;
     L.bytes_psum = bytes; bytes += 2 * SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64) + 16;   // + the work counter of the table stage
-    L.bytes_idx = bytes;
-    bytes += 2 * (3 * (L.ins_len + 1) + 2 * (L.up_cnt + 1) + 2 * (L.dn_cnt + 1)); bytes = (bytes + 7) & ~7;
+    bytes = (bytes + 15) & ~15;
+    L.bytes_idx = bytes;                               // u32 per slot: byte offsets of the two SV-row slots it gathers
+    bytes += 4 * (3 * L.ins_sl + 2 * L.up_sl + 2 * L.dn_sl);
     L.bytes_sb = bytes; bytes += L.span_b + 8;
     L.total_bytes = (bytes + 15) & ~15;
     return L;
