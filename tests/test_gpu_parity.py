@@ -245,7 +245,7 @@ def test_error_paths(genome):
 
 def test_very_wide_capture_range(genome):
     """capture 120-300 step 20 (scan sizes up to 260, nine sizes spanning 160 bases): the host shortens the capture-size runs
-    until the tile fits LDS and selects the 8-slots-per-lane scan instantiation; sampled candidates still match the oracle."""
+    until the tile fits LDS, the scan units take their long-array path; sampled candidates still match the oracle."""
     P = capi.make_params(120, 300, score_method=capi.SCORE_SVR, capture_increment=20)
     mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
     acc = capi.Accel(P)
@@ -258,6 +258,40 @@ def test_very_wide_capture_range(genome):
     rng = np.random.default_rng(9)
     A = P.n_arm_pairs
     for idx in rng.choice(valid, size=400, replace=False):
+        a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
+        ki, pi = rest % g.n_sizes, rest // g.n_sizes
+        cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
+        sk, d = po.design(P, rd, cand)
+        so, _, _ = po.score_designed(d, capi.SCORE_SVR, np.array(rd.c.long_range_content[:]), om)
+        ok, _ = _close([scores[idx]], [so])
+        assert ok.all(), (cand, scores[idx], so)
+    acc.close()
+
+
+def test_fragmented_arm_pair_order(genome):
+    """Arm pairs in an order where consecutive pairs never share an arm-length sum (every candidate step opens a new insert
+    factor list) and whose count does not fill the last chunk: the dense kernel must not depend on the reference's sum-sorted
+    enumeration order."""
+    base = capi.arm_pairs_of(capi.make_params(140, 160))
+    rng = np.random.default_rng(4)
+    pairs = [base[i] for i in rng.permutation(len(base))][:23]
+    for i in range(1, len(pairs)):                      # break up accidental runs of equal sums
+        if sum(pairs[i]) == sum(pairs[i - 1]):
+            for j in range(i + 1, len(pairs)):
+                if sum(pairs[j]) != sum(pairs[i - 1]) and (i + 1 >= len(pairs) or sum(pairs[j]) != sum(pairs[i + 1])):
+                    pairs[i], pairs[j] = pairs[j], pairs[i]
+                    break
+    P = capi.make_params(140, 160, score_method=capi.SCORE_SVR, arm_pairs=pairs)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    rd = capi.build_region(genome, "1", 12000, 12090, P, bwa_mode="hashed", label="frag", lrc=np.full(44, 0.05))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    g = grids[0]
+    valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
+    A = P.n_arm_pairs
+    for idx in rng.choice(valid, size=min(500, len(valid)), replace=False):
         a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
         ki, pi = rest % g.n_sizes, rest // g.n_sizes
         cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
