@@ -173,8 +173,18 @@ def main() -> None:
                 traffic = json.load(open(tpath)).get("k_svr_dense_bytes_per_launch")
             except Exception:
                 traffic = None
-        # executed FP64 work of the dominant kernel: ~ (2 adds + exp2 + fma) per (candidate, SV)
-        deg = int(os.environ.get("MIPGEN_ACCEL_EXP_DEG", "0")) or None
+        # issue-side counters of the dominant kernel from the committed PMC passes (tools/profile_round.sh), if present
+        util = {}
+        ppath = os.path.join(ROOT, "profiles", "r01d_pmc.json")
+        if os.path.exists(ppath):
+            try:
+                c = json.load(open(ppath))["k_svr_dense"]
+                cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
+                util = {"valu_instr_per_wave_pair": c["SQ_INSTS_VALU"] * 64.0 / (n_cand * n_sv),
+                        "valu_issue_frac": c["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc),
+                        "source": "profiles/r01d_pmc.json (profiled launch, same workload)"}
+            except Exception:
+                util = {}
         out = {
             "metric": "candidate MIPs scored/sec (SVR)", "value": value, "unit": "candidates/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -187,9 +197,9 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_svr_dense", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CAND * n_cand,
-                         "note": "the path is FP64-VALU bound, not HBM bound (SURVEY.md section 8d); see fp64"},
+                         "note": "the path is bound by FP64 VALU issue and LDS, not by HBM (SURVEY.md section 8d); see fp64"},
             "fp64": {"pairs_per_launch": n_cand * n_sv, "pairs_per_s": n_cand * n_sv / (k_ms * 1e-3),
-                     "naive_equiv_tflops": n_cand * n_sv * 600.0 / (k_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS},
+                     "naive_equiv_tflops": n_cand * n_sv * 600.0 / (k_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS, **util},
             "kernels_ms": {"k_svr_dense": k_ms, "k_records": float(np.mean(records_ms)),
                            "k_replay_condense(+memsets)": float(np.mean(replay_ms)) if replay_ms else None},
         }
