@@ -176,7 +176,7 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
     int o = 0;
     L.rinv = o; o += L.rinv_len;
-    L.lg10 = o; o += 102;
+    L.lg10 = o; o += 102 + 44;                          // + the region's 44 long-range frequencies (read per SV by the constants unit)
     L.n_ent = np * n_up + L.nq * n_dn;
     L.rows = o; o += 2 * group * SV_ROW;
     int g = 3 * L.ins_sl + 2 * L.up_sl + 2 * L.dn_sl;                         // the seven prefix arrays
