@@ -300,3 +300,31 @@ def test_fragmented_arm_pair_order(genome):
         ok, _ = _close([scores[idx]], [so])
         assert ok.all(), (cand, scores[idx], so)
     acc.close()
+
+
+@pytest.mark.parametrize("n_pairs", [3, 9, 70, 130])
+def test_arm_pair_counts(genome, n_pairs):
+    """Thread geometry of the dense SVR kernel: 3 and 9 pairs take the 5- and 10-step instantiations, 70 and 130 pairs need
+    more chunks than 16 wavefronts hold at four waves per chunk (3 resp. 1 waves per chunk, fewer positions per tile)."""
+    grid = sorted(((e, l) for e in range(16, 31) for l in range(18, 31)), key=lambda t: (-(t[0] + t[1]), t[0]))
+    pairs = grid[20:20 + n_pairs]
+    P = capi.make_params(150, 165, score_method=capi.SCORE_SVR, arm_pairs=pairs)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    rd = capi.build_region(genome, "1", 15000, 15060, P, bwa_mode="hashed", label="geom", lrc=np.full(44, 0.03))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    g = grids[0]
+    valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
+    rng = np.random.default_rng(n_pairs)
+    A = P.n_arm_pairs
+    for idx in rng.choice(valid, size=min(300, len(valid)), replace=False):
+        a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
+        ki, pi = rest % g.n_sizes, rest // g.n_sizes
+        cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
+        sk, d = po.design(P, rd, cand)
+        so, _, _ = po.score_designed(d, capi.SCORE_SVR, np.array(rd.c.long_range_content[:]), om)
+        ok, _ = _close([scores[idx]], [so])
+        assert ok.all(), (n_pairs, cand, scores[idx], so)
+    acc.close()
