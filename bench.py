@@ -189,8 +189,8 @@ def main() -> None:
             "metric": "candidate MIPs scored/sec (SVR)", "value": value, "unit": "candidates/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "practice62 (62 exon-like regions, synthetic stand-in for practice_genes.bed), capture 140-180 step 5, "
-                                   "57 arm pairs, SVR scoring, synthetic libsvm model",
+            "config": {"workload": f"practice62 (62 exon-like regions, synthetic stand-in for practice_genes.bed), capture {args.min_capture}-{args.max_capture} step 5, "
+                                   f"{P.n_arm_pairs} arm pairs, SVR scoring, synthetic libsvm model",
                        "n_sv": n_sv, "regions_per_gpu": len(regions), "dense_candidates_per_gpu": n_cand,
                        "emitted_candidates_rank0": emitted_total, "replay_condense_in_step": not args.no_replay,
                        "survivors_gathered": survivors_gathered},

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <array>
+#include <map>
 
 #include "mipgen_host.hpp"
 
@@ -14,12 +16,31 @@ using namespace mipgen;
 
 namespace {
 
+// -score_method mixed re-scores candidates with the SVR while picking (mipgen.cpp:1523-1527,1873-1877).  Every candidate the
+// selection stage can reach is a survivor of the batch's replay + condense, so all of them are scored in ONE accelerator
+// call per batch and served from a cache; a candidate that is not in the cache falls back to a single-candidate call.
 struct AccelRescorer : Rescorer {
     mipgen_accel* h = nullptr;
     int region_in_batch = 0;
+    typedef std::array<int32_t, 6> Key;                      // region in batch, scan start, capture, ext, lig, strand
+    std::map<Key, double> cache;
+    static Key key(int region, const mipgen_candidate& c) { return Key{region, c.scan_start, c.capture_size, c.ext_len, c.lig_len, c.strand}; }
+    void prefetch(const std::vector<mipgen_candidate>& cands)
+    {
+        cache.clear();
+        if (cands.empty()) return;
+        std::vector<double> sc(cands.size());
+        if (mipgen_accel_score_candidates(h, cands.data(), (int64_t)cands.size(), MIPGEN_SCORE_SVR, sc.data(), nullptr, nullptr, nullptr)) {
+            std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
+            throw 20;
+        }
+        for (size_t i = 0; i < cands.size(); i++) cache[key(cands[i].region, cands[i])] = sc[i];
+    }
     double svr(const Cand& c) override
     {
         mipgen_candidate mc = {region_in_batch, c.scan_start, c.capture, c.ext_len, c.lig_len, c.strand};
+        auto it = cache.find(key(region_in_batch, mc));
+        if (it != cache.end()) return it->second;
         double s = 0.0;
         if (mipgen_accel_score_candidates(h, &mc, 1, MIPGEN_SCORE_SVR, &s, nullptr, nullptr, nullptr)) {
             std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
@@ -126,6 +147,21 @@ int run(int argc, char** argv)
             accel_check(mipgen_accel_download_results(accel, scores.data(), records.data(), 0, n_cand), 19);
         }
         accel_check(mipgen_accel_download_replay(accel, emitted_n.data(), surv.data(), (int64_t)surv.size(), o.silent ? nullptr : mask.data(), (int64_t)mask.size()), 19);
+        if (o.score_method == MIPGEN_SCORE_MIXED) {
+            // every survivor of the batch through the SVR in one call
+            std::vector<mipgen_candidate> cands;
+            int64_t q0 = 0;
+            for (size_t bi = 0; bi < batch.size(); bi++) {
+                const mipgen_grid& g = grids[bi];
+                for (int64_t q = 2 * q0; q < 2 * (q0 + g.n_pos); q++) {
+                    if (surv[(size_t)q].cand_index < 0) continue;
+                    const Cand c = make_cand(o, regions[first + bi], g, surv[(size_t)q].cand_index - g.offset, surv[(size_t)q].score, surv[(size_t)q].record);
+                    cands.push_back(mipgen_candidate{(int32_t)bi, c.scan_start, c.capture, c.ext_len, c.lig_len, c.strand});
+                }
+                q0 += g.n_pos;
+            }
+            rescorer.prefetch(cands);
+        }
         int64_t pos0 = 0;
         for (size_t bi = 0; bi < batch.size(); bi++) {
             const Region& r = regions[first + bi];
