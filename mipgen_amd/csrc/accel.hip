@@ -225,6 +225,19 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     if (const char* e = getenv("MIPGEN_ACCEL_SVR_WPC")) G.wpc = std::max(1, atoi(e));   // tuning knob: waves per arm-pair chunk
     while (G.wpc > 1 && G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) G.wpc--;
     if (G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) { delete h; return fail(MIPGEN_E_INVALID, "too many arm pairs for the dense SVR kernel (max %d)", SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64)); }
+    {
+        const int n_arm = std::max(G.n_e, G.n_l) | 1;            // table row pitch in slots (as in the kernel)
+        for (int strand = 0; strand < 2; strand++) {
+            const int up_min = strand ? D.l_min : D.e_min, dn_min = strand ? D.e_min : D.l_min;
+            for (int i = 0; i < MIPGEN_MAX_ARM_PAIRS + 16; i++) {
+                const int a = std::min(i, D.n_pairs - 1);
+                const int e = D.arm_ext[a], l = D.arm_lig[a];
+                const uint32_t uU = (uint32_t)(((strand ? l : e) - up_min) * SVR_GROUP * 8);
+                const uint32_t uD = (uint32_t)(((D.max_sum - (e + l)) * n_arm + ((strand ? e : l) - dn_min)) * SVR_GROUP * 8);
+                D.pair_prog[strand][i] = uU | (uD << 16);
+            }
+        }
+    }
 
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {

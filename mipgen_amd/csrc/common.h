@@ -77,6 +77,9 @@ struct DevParams {
     uint8_t arm_lig[MIPGEN_MAX_ARM_PAIRS];
     int8_t len_slot[MIPGEN_MAX_OLIGO + 1];      // oligo length -> slot in the copy table, -1 unused
     uint16_t group_end[MIPGEN_MAX_ARM_PAIRS];    // for pair a: index one past the last pair of a's arm-sum list
+    // dense SVR kernel, per strand and pair (the tail repeats the last pair: chunks are padded): the pair's part of the factor-table
+    // byte offsets, upstream | downstream << 16; a lane adds its own (position, capture size) part with ONE 32-bit add
+    uint32_t pair_prog[2][MIPGEN_MAX_ARM_PAIRS + 16];
 };
 
 // one workgroup of the logistic / records kernel: a run of scan-start positions of one region
