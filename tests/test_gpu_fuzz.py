@@ -1,0 +1,75 @@
+"""Seeded randomized parity: the dense GPU path against the oracle over parameter sets the fixed tests do not reach
+(capture increments other than 5, narrow and wide capture ranges, arm-pair subsets in random order, short and long regions,
+N runs, hashed copy tables).  Records bit-exact on every candidate; scores within 1e-5 on a sample (SVR) / everywhere (logistic).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mipgen_amd import capi
+from oracle import pyoracle as po
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _configs():
+    rng = np.random.default_rng(20240607)
+    grid = [(e, l) for e in range(16, 31) for l in range(18, 31) if 38 <= e + l <= 48]
+    out = []
+    for i in range(10):
+        inc = int(rng.choice([1, 2, 3, 5, 7, 10]))
+        lo = int(rng.integers(110, 170))
+        hi = lo + inc * int(rng.integers(0, 12))
+        n_pairs = int(rng.integers(1, 40))
+        idx = rng.permutation(len(grid))[:n_pairs]
+        pairs = [grid[j] for j in (sorted(idx, key=lambda j: (-(grid[j][0] + grid[j][1]), grid[j][0])) if i % 2 == 0 else idx)]
+        length = int(rng.choice([1, 7, 40, 120, 260]))
+        start = int(rng.integers(2000, 17000))
+        out.append((i, lo, hi, inc, pairs, start, length))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: f"cfg{c[0]}_C{c[1]}-{c[2]}x{c[3]}_A{len(c[4])}_L{c[6]}")
+def test_random_configuration(cfg):
+    i, lo, hi, inc, pairs, start, length = cfg
+    genome = bytearray(H.golden_genome())
+    rng = np.random.default_rng(1000 + i)
+    if i % 3 == 0:                                   # an N run inside the region's reach (guard / masked-N paths)
+        p0 = start + int(rng.integers(-100, 100))
+        genome[p0:p0 + 6] = b"NNNNNN"
+    genome = bytes(genome)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    om = po.Model(mp)
+    for method in (capi.SCORE_LOGISTIC, capi.SCORE_SVR):
+        P = capi.make_params(lo, hi, score_method=method, capture_increment=inc, arm_pairs=pairs)
+        acc = capi.Accel(P)
+        if method == capi.SCORE_SVR:
+            acc.load_model_file(mp)
+        rd = capi.build_region(genome, "1", start, start + length, P, bwa_mode="hashed" if i % 2 else "unique", label=f"f{i}",
+                               lrc=np.full(44, 0.01 * (i + 1)))
+        grids, scores, records = acc.score_regions([rd], method)
+        g = grids[0]
+        og, os_, or_ = po.score_region_dense(P, rd, method, om if method == capi.SCORE_SVR else None) if g.count <= 400000 else (None, None, None)
+        if og is not None:
+            assert (g.first_pos, g.n_pos, g.first_size_index, g.n_sizes, g.count) == (og.first_pos, og.n_pos, og.first_size_index, og.n_sizes, og.count)
+            bad = np.nonzero(records[:g.count] != or_)[0]
+            assert bad.size == 0, (cfg[:4], "record", int(bad[0]))
+            a, b = np.asarray(scores[:g.count]), np.asarray(os_)
+            both_nan = np.isnan(a) & np.isnan(b)
+            with np.errstate(invalid="ignore"):
+                d = np.where(both_nan | (np.isinf(a) & (a == b)), 0.0, np.abs(a - b))
+            assert np.nanmax(d) <= TOL and not np.isnan(d).any(), (cfg[:4], method, int(np.nanargmax(d)), float(np.nanmax(d)))
+        else:                                        # large grids: sampled candidates through the per-candidate oracle
+            valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
+            A = P.n_arm_pairs
+            for idx in rng.choice(valid, size=min(300, len(valid)), replace=False):
+                a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
+                ki, pi = rest % g.n_sizes, rest // g.n_sizes
+                cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
+                sk, dsg = po.design(P, rd, cand)
+                so, _, _ = po.score_designed(dsg, method, np.array(rd.c.long_range_content[:]), om if method == capi.SCORE_SVR else None)
+                assert abs(scores[idx] - so) <= TOL or (np.isnan(scores[idx]) and np.isnan(so)), (cfg[:4], cand, scores[idx], so)
+        acc.close()
