@@ -23,7 +23,7 @@ hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, i
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
                                           double*, uint64_t*);
 size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l);
-hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
+hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
                                    const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
                                    const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
                                    const uint64_t* records, double* scores);
@@ -302,9 +302,11 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
     if (h->model.reserve(rows.size())) return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho; h->sum_abs_coef = sum_abs;
-    // The dense kernel takes its exponentials once per table entry (the RBF value factorises over the feature blocks), so the
-    // degree-10 polynomial (relative error 6.7e-16) costs nothing measurable and holds for any sum|coef|.
-    h->exp_deg = 10;
+    // The dense kernel takes its exponentials once per table entry (the RBF value factorises over the feature blocks); a kernel value
+    // is the product of three of them.  Degree 8 (relative error 1.1e-12 per factor) while 3.2e-12 * sum|coef| stays below 1e-7 (the
+    // score gate is 1e-5), else degree 10 (6.7e-16).
+    h->exp_deg = sum_abs * 3.2e-12 <= 1e-7 ? 8 : 10;
+    if (const char* f = getenv("MIPGEN_ACCEL_EXP_DEG")) { const int d = atoi(f); if (d == 8 || d == 10) h->exp_deg = d; }   // tests force both
     return MIPGEN_OK;
 }
 
@@ -541,7 +543,7 @@ int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     if (method == MIPGEN_SCORE_SVR) {
         const double gamma_l2e = h->gamma * 1.4426950408889634074;
-        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
                                         h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard,
                                         h->records.p, h->scores.p));
     }

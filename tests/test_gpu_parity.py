@@ -328,3 +328,23 @@ def test_arm_pair_counts(genome, n_pairs):
         ok, _ = _close([scores[idx]], [so])
         assert ok.all(), (n_pairs, cand, scores[idx], so)
     acc.close()
+
+
+@pytest.mark.parametrize("deg", ["8", "10"])
+def test_exp2_degree_variants(genome, monkeypatch, deg):
+    """The table stage's exp2 polynomial is degree 8 or 10 depending on sum|coef| (chosen when the model is set); both
+    instantiations are forced here and checked on every dense-grid candidate of a golden design."""
+    monkeypatch.setenv("MIPGEN_ACCEL_EXP_DEG", deg)
+    meta = H.load_design("svr_small")
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    mp = _model_path(meta)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    grids, scores, records = acc.score_regions(regions, capi.SCORE_SVR)
+    for rd, g in zip(regions, grids):
+        og, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+        ok, mx = _close(scores[g.offset:g.offset + g.count], os_)
+        assert ok.all(), (deg, mx)
+    acc.close()
