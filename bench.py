@@ -175,14 +175,14 @@ def main() -> None:
                 traffic = None
         # issue-side counters of the dominant kernel from the committed PMC passes (tools/profile_round.sh), if present
         util = {}
-        ppath = os.path.join(ROOT, "profiles", "r01f_pmc.json")
+        ppath = os.path.join(ROOT, "profiles", "r01g_pmc.json")
         if os.path.exists(ppath):
             try:
                 c = json.load(open(ppath))["k_svr_dense"]
                 cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
                 util = {"valu_instr_per_wave_pair": c["SQ_INSTS_VALU"] * 64.0 / (n_cand * n_sv),
                         "valu_issue_frac": c["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc),
-                        "source": "profiles/r01f_pmc.json (profiled launch, same workload)"}
+                        "source": "profiles/r01g_pmc.json (profiled launch, same workload)"}
             except Exception:
                 util = {}
         out = {
