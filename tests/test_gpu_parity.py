@@ -348,3 +348,21 @@ def test_exp2_degree_variants(genome, monkeypatch, deg):
         ok, mx = _close(scores[g.offset:g.offset + g.count], os_)
         assert ok.all(), (deg, mx)
     acc.close()
+
+
+@pytest.mark.parametrize("n_sv", [1, 2, 4, 7])
+def test_tiny_models(genome, tmp_path, n_sv):
+    """One to a few support vectors: a single (partial) SV group, two groups, and the prologue / loop boundaries of the kernel."""
+    from mipgen_amd import workloads
+    mp = workloads.svr_model_path(str(tmp_path), genome, n_sv, seed=11)
+    P = capi.make_params(152, 162, score_method=capi.SCORE_SVR)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    rd = capi.build_region(genome, "1", 9000, 9040, P, bwa_mode="hashed", label="tiny", lrc=np.full(44, 0.02))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    og, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+    assert (records[:og.count] == or_).all()
+    ok, mx = _close(scores[:og.count], os_)
+    assert ok.all(), (n_sv, mx)
+    acc.close()
