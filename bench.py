@@ -1,92 +1,259 @@
 #!/usr/bin/env python3
-"""bench.py — candidate MIPs scored / second (SVR) on MI355X, BASELINE.json metric.
+"""bench.py — candidate MIPs scored / second on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config practice62|regions5k|exome|exome_snp] [--regions R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one resident batch: the dense candidate grid of every region of the
-workload is constructed (integer records of design_mip), scored with the libsvm RBF-SVR, and the reference's
-score-dependent enumeration is replayed + condensed on the device.  Inputs are resident in HBM before the timed
-region starts.  Workload at N=1: BASELINE.json configs[1] (practice_genes-shaped design, capture 140-180, SVR) on
-the synthetic stand-in `practice62` with a synthetic 1024-SV model (no real genome / BED / trained model exists
-offline: SURVEY.md section 8d).  For N>1 every rank scores its own `practice62` instance (weak scaling, regions are
-independent) and the per-position survivors are gathered to rank 0 with one RCCL gather.
+A "step" is one pass of the hot path over the resident batch, the way a -silent_mode design runs it (mipgen_accel_score_condense_all):
+for every region the dense candidate grid is constructed (integer records of design_mip), scored (libsvm RBF-SVR or logistic), and the
+reference's score-dependent enumeration is replayed + condensed on the device; only 2 survivors per scan position remain.  Inputs are
+resident in HBM before the timed region starts.
+
+Workloads (mipgen_amd/workloads.py; no real genome / BED / trained model exists offline):
+  practice62 (default)  BASELINE configs[1]: 62 exon-like regions, capture 140-180, SVR, synthetic 1024-SV libsvm model
+  regions5k             configs[2] shape: --regions R of the 1,000 x 5 kb regions, capture 120-250; scan method logistic (mixed designs scan
+                        with the logistic score) or --method svr
+  exome / exome_snp     configs[3] / [4] shape: --regions R of the 200,000 exon-like intervals, capture 150-170 / 120-250, SVR
+
+N > 1: one process per GPU (`--gpus N` without a launcher starts `torch.distributed.run` itself, before anything touches a GPU).
+The BED is sharded over the ranks by dense-grid size (contiguous region ranges, no data-path collective while scoring); every step ends
+with ONE gather of the condensed survivors to rank 0 (RCCL over xGMI), where the sequential pick stage consumes them.
+  --scaling weak (default)   the BED grows with N: N practice62-sized instances (one per rank's worth of regions)
+  --scaling strong           one fixed BED (--regions) cut N ways
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mipgen_amd import capi, synth, workloads  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (spec)
+FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 ALG_BYTES_PER_CAND = 16          # 8 B score + 8 B integer record written per candidate
 
+CONFIGS = {
+    #             capture      method      default regions
+    "practice62": ((140, 180), "svr", 62),
+    "regions5k": ((120, 250), "logistic", 24),
+    "exome": ((150, 170), "svr", 8192),
+    "exome_snp": ((120, 250), "svr", 4096),
+}
 
-def cpu_baseline(genome: bytes, ivs, model_path: str, P_args: dict, n_sv: int) -> dict:
-    """Reference CPU path timed on this box's host cores on a bounded sample of the same workload.
-    kind 'reference' = the real reference binary (oracle/_ref/mipgen_ref, prebuilt from /root/reference);
-    falls back to the oracle restatement ('port') if the binary did not travel."""
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="practice62")
+    ap.add_argument("--regions", type=int, default=0, help="regions of the workload to use (0 = the config's default)")
+    ap.add_argument("--method", choices=["svr", "logistic"], default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--nsv", type=int, default=1024)
+    ap.add_argument("--min-capture", type=int, default=0)
+    ap.add_argument("--max-capture", type=int, default=0)
+    ap.add_argument("--window-candidates", type=int, default=0, help="cap on the candidates of one result window (0 = what fits in HBM)")
+    ap.add_argument("--sv-split", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the nSV sweep and the logistic line")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the multi-core CPU baseline (0 = all host cores, at most 64)")
+    return ap.parse_args()
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` without a launcher: start N ranks as a CHILD process before this one touches a GPU
+    (a GPU-initialised process must never exec; this parent never initialises one)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# workload assembly
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def assemble(args, rank: int, world: int):
+    """(describe, build) for this rank: `build(acc)` returns the rank's region records; describe is the workload string."""
+    import numpy as np
+    from mipgen_amd import capi, workloads, dist as mdist
+
+    (c0, c1), method, n_default = CONFIGS[args.config]
+    if args.min_capture:
+        c0 = args.min_capture
+    if args.max_capture:
+        c1 = args.max_capture
+    method = args.method or method
+    n_regions = args.regions or n_default
+    P = capi.make_params(c0, c1, score_method=capi.SCORE_SVR if method == "svr" else capi.SCORE_LOGISTIC)
+    model_genome = workloads.practice62()[0]                       # support vectors are drawn from this genome for every workload
+    if args.config == "practice62":
+        # weak scaling: the BED is N practice62 instances (chromosomes "7", "7b", ...), sharded by dense-grid size
+        inst = list(range(world)) if args.scaling == "weak" else [0]
+        parts = []
+        for k in inst:
+            genome, ivs = workloads.practice62(seed=20140101 + k, n_regions=n_regions)
+            parts.append((genome, ivs))
+        all_ivs = [(k, iv) for k, (_, ivs) in enumerate(parts) for iv in ivs]
+        weights = workloads.dense_candidates([iv for _, iv in all_ivs], P)
+        lo, hi = mdist.shard_regions(weights.tolist(), world)[rank]
+        mine = all_ivs[lo:hi]
+
+        def build(acc):
+            out = []
+            for k in sorted({k for k, _ in mine}):
+                out += workloads.build_regions(acc, parts[k][0], [iv for kk, iv in mine if kk == k], P)
+            return out
+        desc = f"practice62 x{len(inst)} ({len(all_ivs)} exon-like regions, synthetic stand-in for practice_genes.bed)"
+    elif args.config == "regions5k":
+        total = n_regions * (world if args.scaling == "weak" else 1)
+        ivs = workloads.regions5k_intervals(min(total, 1000))
+        weights = workloads.dense_candidates(ivs, P)
+        lo, hi = mdist.shard_regions(weights.tolist(), world)[rank]
+
+        def build(acc):
+            return workloads.build_regions5k(acc, workloads.regions5k_genome(), ivs[lo:hi], P, with_lrc=method == "svr")
+        desc = f"regions5k: {len(ivs)} of the 1,000 x 5,000 bp regions (12 Mb chromosome, N runs of 50, 98/1.5/0.5 % copy table)"
+    else:
+        total = n_regions * (world if args.scaling == "weak" else 1)
+        chrom_len, all_iv = workloads.exome_layout()
+        ivs = all_iv[:min(total, len(all_iv))]
+        weights = workloads.dense_candidates(ivs, P)
+        lo, hi = mdist.shard_regions(weights.tolist(), world)[rank]
+
+        def build(acc):
+            return workloads.build_exome(acc, chrom_len, ivs[lo:hi], P, snps=args.config == "exome_snp", with_lrc=method == "svr")
+        desc = (f"exome200k{'+SNPs (1/300 bp) +tags 4,4' if args.config == 'exome_snp' else ''}: the first {len(ivs)} of 200,000 exon-like intervals "
+                f"(24 chromosomes, 300 Mb, 41 % GC)")
+    desc += f", capture {c0}-{c1} step {P.capture_increment}, {P.n_arm_pairs} arm pairs, {method} scoring"
+    return P, method, model_genome, build, desc, int(weights.sum())
+
+
+def table_entries_min(P, grids) -> int:
+    """Distinct factor-table entries the window-separable SVR form needs per support vector, independent of any tiling: per strand the
+    (position, upstream arm length), (downstream start, downstream arm length) and (position, scan size) windows of a region."""
+    from mipgen_amd import capi
+    pairs = capi.arm_pairs_of(P)
+    n_e, n_l = len({e for e, _ in pairs}), len({l for _, l in pairs})
+    sums = sorted({e + l for e, l in pairs})
+    total = 0
+    for g in grids:
+        sizes = [P.max_capture_size - (g.first_size_index + k) * P.capture_increment for k in range(g.n_sizes)]
+        ss = sorted({C - s for C in sizes for s in sums})
+        if not ss:
+            continue
+        nq = g.n_pos + (ss[-1] - ss[0])
+        total += (g.n_pos * n_e + nq * n_l + g.n_pos * len(ss)) + (g.n_pos * n_l + nq * n_e + g.n_pos * len(ss))      # '+' strand, '-' strand
+    return total
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the real reference binary on this box's host cores
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
+    """The reference CPU path (oracle/_ref/mipgen_ref, the real reference compiled -O2 from /root/reference by oracle/Makefile) timed on
+    this box: one process alone, then C processes at once (the reference is single-threaded and not re-entrant: multi-core = independent
+    processes on BED shards).  Bounded sample of the practice62 / capture 140-180 / SVR workload: regions of
+    ~120-135 bp, where 2-4 capture sizes survive the static skip (~10-25 s of single-core work each)."""
     import shutil
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from mipgen_amd import capi, synth, workloads
     from oracle import run_reference as rr
-    cores = 1                                         # the reference is single-threaded
-    # bounded sample (~10-20 s of single-core work): the three shortest intervals (the static size skip leaves few capture sizes there)
-    sample = sorted(ivs, key=lambda v: v.bed_end - v.bed_start)[:3]
-    iv = sample[0]
+
+    genome, ivs = workloads.practice62()
+    try:
+        cores_avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores_avail = os.cpu_count() or 1
+    cores = args.cpu_cores or min(cores_avail, 64)
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    pool = sorted(ivs, key=lambda v: abs((v.bed_end - v.bed_start) - 128))[:8]
     work = tempfile.mkdtemp(prefix="mipgen_cpu_")
+
+    def run_one(i: int):
+        iv = pool[i % len(pool)]
+        w = os.path.join(work, f"p{i}")
+        os.makedirs(os.path.join(w, "genome"))
+        synth.write_fasta(os.path.join(w, "genome", f"chr{iv.chrom}.fa"), f"chr{iv.chrom}", genome)
+        synth.write_bed(os.path.join(w, "one.bed"), [iv])
+        r = rr.run_reference(w, os.path.join(w, "genome"), os.path.join(w, "one.bed"), "cpu", 140, 180, score_method="svr", model_path=model_path,
+                             bwa_mode="unique", silent=False, timeout=900)
+        if r["returncode"] != 0:
+            raise RuntimeError(r["stderr"][-500:])
+        with open(r["all_mips"], "rb") as fh:
+            n = fh.read().count(b"\n") - 1
+        shutil.rmtree(w, ignore_errors=True)
+        return n, r["seconds"], iv.bed_end - iv.bed_start
+
     try:
         if rr.have_reference():
-            os.makedirs(os.path.join(work, "genome"))
-            synth.write_fasta(os.path.join(work, "genome", f"chr{iv.chrom}.fa"), f"chr{iv.chrom}", genome)
-            synth.write_bed(os.path.join(work, "one.bed"), sample)
-            r = rr.run_reference(work, os.path.join(work, "genome"), os.path.join(work, "one.bed"), "cpu", P_args["minC"], P_args["maxC"],
-                                 score_method="svr", model_path=model_path, bwa_mode="unique", silent=False, timeout=600)
-            if r["returncode"] == 0:
-                with open(r["all_mips"], "rb") as fh:
-                    n = fh.read().count(b"\n") - 1
-                return {"value": n / r["seconds"], "unit": "candidates/s", "cores": cores, "kind": "reference",
-                        "sample": f"reference binary (-O2) end-to-end on {len(sample)} of {len(ivs)} regions ({'+'.join(str(v.bed_end - v.bed_start) for v in sample)} bp, "
-                                  f"{n} emitted candidates, {r['seconds']:.1f} s wall incl. its FASTQ/shim I/O), n_sv={n_sv}"}
-        # port: the oracle's C restatement (same arithmetic as the reference, no text hop, -O2)
+            n1, t1, len1 = run_one(0)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                res = list(ex.map(run_one, range(cores)))
+            wall = time.perf_counter() - t0
+            n_all = sum(r[0] for r in res)
+            return {"value": n_all / wall, "unit": "candidates/s", "cores": cores, "kind": "reference",
+                    "single_core_value": n1 / t1, "cpu_model": cpu_model, "host_cores_available": cores_avail,
+                    "scope": "reference binary end to end per region (enumeration + scoring + its FASTQ / stand-in bwa I/O and selection); "
+                             "the GPU figure covers the resident hot path only",
+                    "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2), one region each from the "
+                              f"{len(pool)} regions closest to 128 bp ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp; 2-4 capture sizes survive the static skip), "
+                              f"{n_all} emitted candidates in {wall:.1f} s wall; alone: {len1}-bp region, {n1} candidates in {t1:.1f} s"}
+        # port: the oracle's C restatement (same arithmetic as the reference, no text hop, -O2), one core
         from oracle import pyoracle as po
-        P = capi.make_params(P_args["minC"], P_args["maxC"], score_method=capi.SCORE_SVR)
+        P = capi.make_params(140, 180, score_method=capi.SCORE_SVR)
+        iv = pool[0]
         rd = capi.build_region(genome, iv.chrom, iv.bed_start, iv.bed_end, P, label=iv.label)
         om = po.Model(model_path)
         t0 = time.perf_counter()
         n, _ = po.enumerate_region(P, rd, capi.SCORE_SVR, om, capacity=1)
         dt = time.perf_counter() - t0
-        return {"value": n / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+        return {"value": n / dt, "unit": "candidates/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
                 "sample": f"oracle C restatement on 1 of {len(ivs)} regions ({n} emitted candidates, {dt:.1f} s), n_sv={n_sv}"}
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nsv", type=int, default=1024)
-    ap.add_argument("--min-capture", type=int, default=140)
-    ap.add_argument("--max-capture", type=int, default=180)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-replay", action="store_true", help="time scoring only (kernel studies)")
-    args = ap.parse_args()
+def newest_profile(pattern: str):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
 
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
+    from mipgen_amd import capi, workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,26 +265,46 @@ def main() -> None:
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if distributed else 1
 
-    # ---- workload (per rank: same shape, different seed -> weak scaling over independent regions) ----------
-    genome, ivs = workloads.practice62(seed=20140101 + rank)
-    cache = os.path.join(ROOT, "gpurun_out", "bench_cache")
-    model_genome, _ = (genome, None) if rank == 0 else workloads.practice62(seed=20140101)
-    model_path = workloads.svr_model_path(cache if rank == 0 else cache + f"_r{rank}", model_genome, args.nsv)
-    P = capi.make_params(args.min_capture, args.max_capture, score_method=capi.SCORE_SVR)
+    P, method, model_genome, build, desc, global_dense = assemble(args, rank, world)
+    cache = os.path.join(ROOT, "gpurun_out", "bench_cache") + ("" if rank == 0 else f"_r{rank}")
     stream = torch.cuda.current_stream().cuda_stream
     acc = capi.Accel(P, device=local_rank, stream=stream)
-    acc.load_model_file(model_path)
-    regions = workloads.build_regions(acc, genome, ivs, P)
-    acc.upload(regions)                                   # inputs resident in HBM before the timed region
+    m = capi.SCORE_SVR if method == "svr" else capi.SCORE_LOGISTIC
+    model_path = None
+    if method == "svr":
+        model_path = workloads.svr_model_path(cache, model_genome, args.nsv)
+        acc.load_model_file(model_path)
+    regions = build(acc)
+    if args.window_candidates:
+        acc.set_window_candidates(args.window_candidates)
+    if args.sv_split:
+        acc.set_sv_split(args.sv_split)
+    grids = acc.upload(regions)                            # inputs resident in HBM before the timed region
     n_cand = acc.batch_candidates()
     acc.set_timing(True)
+    surv_ptr, n_surv = acc.survivors_device_ptr()
+
+    class _DevView:                                        # the library's survivor array as a torch tensor (no copy): the gather's send buffer
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    send = torch.as_tensor(_DevView(surv_ptr, max(n_surv, 1) * 24), device=f"cuda:{local_rank}") if distributed else None
+    recv = None
+    if distributed:
+        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([n_surv * 24], dtype=torch.int64, device="cuda"))
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(max(sizes), 24)
+        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            recv = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
 
     def step() -> None:
-        acc.score_resident(capi.SCORE_SVR)
-        if not args.no_replay:
-            acc.replay_condense()
+        acc.score_condense_all(m)
+        if distributed:
+            # the one exchange step of the path: condensed survivors -> rank 0 (RCCL gather; direct peer -> root transfers over xGMI)
+            pad[: n_surv * 24].copy_(send[: n_surv * 24])
+            dist.gather(pad, recv, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -125,24 +312,13 @@ def main() -> None:
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
-    records_ms = []
-    replay_ms = []
+    kernel_ms, records_ms, replay_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(acc.last_kernel_ms(0))          # HIP events on the launch stream around k_svr_dense
+        kernel_ms.append(acc.last_kernel_ms(0 if method == "svr" else 2))      # HIP events on the launch stream around the scoring kernel
         records_ms.append(acc.last_kernel_ms(2))
-        if not args.no_replay:
-            replay_ms.append(acc.last_kernel_ms(3))
-    survivors_gathered = 0
-    if distributed and not args.no_replay:
-        # the one exchange step of the path: per-position survivors -> rank 0 (RCCL gather over xGMI)
-        from mipgen_amd import dist as mdist
-        emitted, surv, _ = acc.download_replay(want_mask=False)
-        allsurv = mdist.gather_to_rank0(surv, device=f"cuda:{local_rank}")
-        if rank == 0:
-            survivors_gathered = int(allsurv.shape[0])
+        replay_ms.append(acc.last_kernel_ms(3))
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -159,53 +335,106 @@ def main() -> None:
         total_cand = n_cand
 
     if rank == 0:
-        emitted_total = None
-        if not args.no_replay:
-            emitted, _, _ = acc.download_replay(want_mask=False)
-            emitted_total = int(emitted.sum())
+        emitted, surv = acc.download_survivors()
+        survivors_gathered = 0
+        if distributed:
+            survivors_gathered = sum(sizes) // 24
+            head = recv[0][:sizes[0]].cpu().numpy().view(capi.SURVIVOR_DTYPE)
+            assert np.array_equal(head["cand_index"], surv["cand_index"]), "rank 0's own slice of the gather differs from its survivors"
         value = total_cand * args.steps / dt
         k_ms = float(np.mean(kernel_ms))
-        n_sv, gamma, rho = acc.model_info()
-        achieved = ALG_BYTES_PER_CAND * n_cand / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
+        n_sv = acc.model_info()[0] if method == "svr" else 0
+        alg_bytes = ALG_BYTES_PER_CAND * n_cand
+        hbm = {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": alg_bytes}
+        hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
+        traffic, traffic_src = None, None
+        tpath = newest_profile("r*_hbm_traffic.json")
+        if tpath and args.config == "practice62" and method == "svr" and not distributed:
             try:
                 traffic = json.load(open(tpath)).get("k_svr_dense_bytes_per_launch")
+                traffic_src = os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
-        # issue-side counters of the dominant kernel from the committed PMC passes (tools/profile_round.sh), if present
-        util = {}
-        ppath = os.path.join(ROOT, "profiles", "r01g_pmc.json")
-        if os.path.exists(ppath):
+        kern = "k_svr_dense" if method == "svr" else "k_records_logistic<true>"
+        if method == "svr":
+            ent = table_entries_min(P, grids)
+            # FP64 operations the window-separable algorithm needs per support vector: 3 per candidate (multiply + FMA on table factors)
+            # + ~45 per distinct table entry (window-sum arithmetic and one full-precision exp2)
+            flops = float(n_sv) * (3.0 * n_cand + 45.0 * ent)
+            ach = flops / (k_ms * 1e-3) / 1e12
+            roof = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                    "traffic": traffic, "kernel": kern, "kernel_ms": k_ms,
+                    "algorithmic_flops_per_launch": flops, "table_entries_per_sv": ent,
+                    "note": "the dense SVR kernel is bound by FP64 VALU issue + LDS, not by HBM (SURVEY.md section 8d); achieved = algorithmic FP64 flops of the "
+                            "window-separable form / HIP-event kernel time; the HBM view of the same launch is in `hbm`",
+                    "hbm": hbm}
+        else:
+            roof = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
+                    "kernel": kern, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        if traffic_src:
+            roof["traffic_from_profile"] = traffic_src
+            roof["traffic_measured_in_this_run"] = False
+        out = {
+            "metric": f"candidate MIPs scored/sec ({'SVR' if method == 'svr' else 'logistic'})", "value": value, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "n_sv": n_sv, "regions_rank0": len(regions), "dense_candidates_rank0": n_cand,
+                       "dense_candidates_all_ranks": total_cand, "result_windows_rank0": acc.window_count(),
+                       "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()),
+                       "survivors_gathered_per_step": survivors_gathered},
+            "roofline": roof,
+            "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},
+        }
+        if method == "svr":
+            out["fp64"] = {"pairs_per_launch": n_cand * n_sv, "pairs_per_s": n_cand * n_sv / (k_ms * 1e-3),
+                           "naive_equiv_tflops": n_cand * n_sv * 600.0 / (k_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS}
+        ppath = newest_profile("r*_pmc.json")
+        if ppath and args.config == "practice62" and method == "svr" and not distributed:
             try:
                 c = json.load(open(ppath))["k_svr_dense"]
                 cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
-                util = {"valu_instr_per_wave_pair": c["SQ_INSTS_VALU"] * 64.0 / (n_cand * n_sv),
-                        "valu_issue_frac": c["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc),
-                        "source": "profiles/r01g_pmc.json (profiled launch, same workload)"}
+                out["pmc_from_profile"] = {"file": os.path.relpath(ppath, ROOT), "measured_in_this_run": False,
+                                           "valu_instr_per_wave_pair": c["SQ_INSTS_VALU"] * 64.0 / (15541734.0 * 1024.0),
+                                           "valu_issue_frac": c["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)}
             except Exception:
-                util = {}
-        out = {
-            "metric": "candidate MIPs scored/sec (SVR)", "value": value, "unit": "candidates/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"practice62 (62 exon-like regions, synthetic stand-in for practice_genes.bed), capture {args.min_capture}-{args.max_capture} step 5, "
-                                   f"{P.n_arm_pairs} arm pairs, SVR scoring, synthetic libsvm model",
-                       "n_sv": n_sv, "regions_per_gpu": len(regions), "dense_candidates_per_gpu": n_cand,
-                       "emitted_candidates_rank0": emitted_total, "replay_condense_in_step": not args.no_replay,
-                       "survivors_gathered": survivors_gathered},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_svr_dense", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_CAND * n_cand,
-                         "note": "the path is bound by FP64 VALU issue and LDS, not by HBM (SURVEY.md section 8d); see fp64"},
-            "fp64": {"pairs_per_launch": n_cand * n_sv, "pairs_per_s": n_cand * n_sv / (k_ms * 1e-3),
-                     "naive_equiv_tflops": n_cand * n_sv * 600.0 / (k_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS, **util},
-            "kernels_ms": {"k_svr_dense": k_ms, "k_records": float(np.mean(records_ms)),
-                           "k_replay_condense(+memsets)": float(np.mean(replay_ms)) if replay_ms else None},
-        }
-        if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(genome, ivs, model_path, {"minC": args.min_capture, "maxC": args.max_capture}, n_sv)
+                pass
+        # ---- extras (N = 1, default workload): throughput vs nSV, and the logistic scorer on the same batch -------------------------
+        if not args.no_extras and not distributed and args.config == "practice62" and method == "svr":
+            extra = []
+            for nsv in (256, 4096):
+                acc.load_model_file(workloads.svr_model_path(cache, model_genome, nsv))
+                acc.score_condense_all(capi.SCORE_SVR)
+                torch.cuda.synchronize()
+                reps = 3
+                t1 = time.perf_counter()
+                ks = []
+                for _ in range(reps):
+                    acc.score_condense_all(capi.SCORE_SVR)
+                    ks.append(acc.last_kernel_ms(0))
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                extra.append({"what": f"same batch, n_sv={nsv}", "value": n_cand * reps / d1, "unit": "candidates/s", "ms_per_step": d1 / reps * 1e3,
+                              "k_svr_dense_ms": float(np.mean(ks)), "pairs_per_s": n_cand * nsv / (float(np.mean(ks)) * 1e-3)})
+            acc.score_condense_all(capi.SCORE_LOGISTIC)
+            torch.cuda.synchronize()
+            reps = 10
+            t1 = time.perf_counter()
+            ks = []
+            for _ in range(reps):
+                acc.score_condense_all(capi.SCORE_LOGISTIC)
+                ks.append(acc.last_kernel_ms(2))
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            lk = float(np.mean(ks))
+            extra.append({"what": "same batch, logistic scoring (k_records_logistic<true> + replay/condense)", "value": n_cand * reps / d1, "unit": "candidates/s",
+                          "ms_per_step": d1 / reps * 1e3, "k_records_logistic_ms": lk,
+                          "roofline": {"bound": "hbm", "achieved": alg_bytes / (lk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": alg_bytes / (lk * 1e-3) / 1e9 / HBM_PEAK_GBS}})
+            out["extra"] = extra
+            acc.load_model_file(model_path)
+        if not args.no_cpu_baseline and not distributed:
+            mp = model_path or workloads.svr_model_path(cache, model_genome, args.nsv)
+            out["cpu_baseline"] = cpu_baseline(args, mp, args.nsv)
         print(json.dumps(out))
     acc.close()
     if distributed:

@@ -20,6 +20,8 @@
  *   mipgen.cpp:1525-1526,1535-1536,1548-1549,1875-1876  mixed-mode re-score        mipgen_accel_score_candidates()
  *   mipgen.cpp:426-437,494-497  score-dependent early exits (replay)               mipgen_accel_replay_condense()
  *   mipgen.cpp:1670-1746 condense_mips                                             mipgen_accel_replay_condense()
+ *   mipgen.cpp:412-524   tile_regions in -silent_mode (enumerate + score + condense of    mipgen_accel_score_condense_all()
+ *                        every region, nothing kept per candidate)
  *
  * Conventions
  *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary.
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MIPGEN_ACCEL_ABI_VERSION 1
+#define MIPGEN_ACCEL_ABI_VERSION 1   /* additions since the first release are new entry points only; struct layouts are unchanged */
 
 #define MIPGEN_MAX_ARM_PAIRS 256     /* flattened (ext,lig) list, enumeration order */
 #define MIPGEN_N_FEATURES 192        /* SVMipv4.cpp:14 TOTAL_FEATURES */
@@ -142,8 +144,8 @@ typedef struct mipgen_grid {
  */
 #define MIPGEN_PLUS_INDEX(pi, n_sizes, ki, n_pairs, a)  (((((int64_t)(pi) * (n_sizes)) + (ki)) * 2 + 0) * (n_pairs) + (a))
 #define MIPGEN_MINUS_INDEX(pi, n_sizes, ki, n_pairs, a) (((((int64_t)(pi) * (n_sizes)) + (ki)) * 2 + 1) * (n_pairs) + (a))
-#define MIPGEN_REC_EXT_COPY(r)   ((uint32_t)((r) & 0xFFFFu))            /* ext_probe_copy, saturated at 65535 */
-#define MIPGEN_REC_LIG_COPY(r)   ((uint32_t)(((r) >> 16) & 0xFFFFu))    /* lig_probe_copy, saturated at 65535 */
+#define MIPGEN_REC_EXT_COPY(r)   ((uint32_t)((r) & 0xFFFFu))            /* ext_probe_copy, saturated at 65535: a field that reads 65535 */
+#define MIPGEN_REC_LIG_COPY(r)   ((uint32_t)(((r) >> 16) & 0xFFFFu))    /* lig_probe_copy,  means "look the count up in mipgen_region.copy" */
 #define MIPGEN_REC_MASKED_N(r)   ((uint32_t)(((r) >> 32) & 0xFFu))      /* #N in masked ext + masked lig (mipgen.cpp:606-610) */
 #define MIPGEN_REC_SNP_COUNT(r)  ((uint32_t)(((r) >> 40) & 0xFFu))      /* snp_count, saturated at 255 */
 #define MIPGEN_REC_FLAGS(r)      ((uint32_t)(((r) >> 48) & 0xFFu))
@@ -181,7 +183,7 @@ typedef struct mipgen_candidate_ints {
 
 /* Per (scan-start, strand) survivor of the reference's replay + condense_mips fold (mipgen.cpp:1670-1746). */
 typedef struct mipgen_survivor {
-    int64_t cand_index;              /* dense-grid index within the batch, or -1 if no candidate survived */
+    int64_t cand_index;              /* dense-grid index within the batch (mipgen_grid.offset + index in the region), or -1 if none survived */
     double score;
     uint64_t record;
 } mipgen_survivor;
@@ -208,20 +210,39 @@ int mipgen_accel_model_info(const mipgen_accel* h, int32_t* n_sv, double* gamma,
 /* ---- region batch: host -> HBM -------------------------------------------------------------------- */
 /* Copies the batch into device memory (sequence bytes, masked bytes, copy tables, SNP / mappability maps,
  * long-range content) and lays out the dense grids.  grids_out (n entries, caller-allocated) may be NULL.
- * Replaces any previously resident batch. */
+ * Replaces any previously resident batch.
+ *
+ * Result windows.  The inputs of EVERY region of the batch stay resident (they are small: ~16-70 bytes per base of region).
+ * The dense results (8 B score + 8 B record + 1 B emitted flag per candidate) are what fills HBM, so the batch is cut into
+ * windows of consecutive regions whose dense results fit the result arrays; windows are scored one after the other into the
+ * same arrays.  A batch that fits is one window (the usual case: 288 GB hold ~1.4e10 candidates).  mipgen_grid.offset stays
+ * batch-wide; a region is never split. */
 int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, mipgen_grid* grids_out);
 /* total dense-grid candidates of the resident batch */
 int64_t mipgen_accel_batch_candidates(const mipgen_accel* h);
+/* upper bound on the candidates of one result window for the following uploads (0 = whatever fits in free device memory) */
+int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates);
+int32_t mipgen_accel_window_count(const mipgen_accel* h);
+/* regions [first_region, +n_regions), candidates [first_candidate, +n_candidates) and scan positions of window w; any output may be NULL */
+int mipgen_accel_window_info(const mipgen_accel* h, int32_t w, int32_t* first_region, int32_t* n_regions, int64_t* first_candidate,
+                             int64_t* n_candidates, int64_t* first_position, int64_t* n_positions);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* Scores the resident batch's dense grid with `method` (MIPGEN_SCORE_LOGISTIC or MIPGEN_SCORE_SVR) into
  * library-owned device arrays (double scores[], uint64 records[], both batch_candidates long).
  * Asynchronous on the handle's stream. */
-int mipgen_accel_score_resident(mipgen_accel* h, int32_t method);
-/* device pointers of the result arrays of the last mipgen_accel_score_resident (valid until the next upload) */
+int mipgen_accel_score_resident(mipgen_accel* h, int32_t method);       /* single-window batches; else MIPGEN_E_STATE */
+/* the same for result window w of a larger batch; the window's results replace the previous window's */
+int mipgen_accel_score_window(mipgen_accel* h, int32_t w, int32_t method);
+/* device pointers of the result arrays (element 0 = first candidate of the window scored last; valid until the next upload) */
 int mipgen_accel_result_device_ptrs(const mipgen_accel* h, void** scores_dev, void** records_dev);
-/* blocks until the stream is idle, then copies results to host arrays (either may be NULL) */
+/* blocks until the stream is idle, then copies results to host arrays (either may be NULL); [first, first+count) are batch-wide
+ * candidate indices and must lie inside the window scored last */
 int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* records, int64_t first, int64_t count);
+/* The whole batch the way a -silent_mode design needs it (mipgen.cpp:412-524 without the all_mips / collapsed files): every window is
+ * scored, replayed and condensed back to back on the stream; only the survivors (2 per scan position) and the per-region emitted
+ * counts are kept.  Asynchronous; fetch with mipgen_accel_download_survivors. */
+int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method);
 /* upload + score + download in one call: the literal replacement for the loop body of mipgen.cpp:446-497 */
 int mipgen_accel_score_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, int32_t method,
                                mipgen_grid* grids_out, double* scores, uint64_t* records, int64_t capacity);
@@ -235,18 +256,34 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
  * (mipgen.cpp:1125-1128,1225); denominator = chrom_seq_stop - chrom_seq_start + 2001 (Featurev5.cpp:49,53). */
 int mipgen_accel_long_range_content(mipgen_accel* h, const char* extended_seq, int32_t len,
                                     int32_t chrom_seq_start, int32_t chrom_seq_stop, double* out44);
+/* the same for n regions in one launch (one workgroup per region); out is [n][44] */
+int mipgen_accel_long_range_content_batch(mipgen_accel* h, int32_t n, const char* const* extended_seqs, const int32_t* lens,
+                                          const int32_t* chrom_seq_starts, const int32_t* chrom_seq_stops, double* out);
 
 /* Replays the reference's score-dependent enumeration control flow (mipgen.cpp:426-437,494-497) over the
  * scored dense grid on the device and folds condense_mips (mipgen.cpp:1670-1746) per (scan start, strand).
  * emitted_dev/ survivors are library-owned device arrays; results are fetched with the calls below. */
 int mipgen_accel_replay_condense(mipgen_accel* h);
-/* per-region emitted-candidate counts (int64[n_regions]) and survivors (2 per scan position: '+','-') */
+/* results of the window replayed last: per-region emitted-candidate counts (int64[regions of the window]), survivors (2 per scan
+ * position of the window: '+','-') and the emitted mask (one byte per candidate of the window).  Any pointer may be NULL. */
 int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors,
                                  int64_t survivor_capacity, uint8_t* emitted_mask, int64_t mask_capacity);
+/* after mipgen_accel_score_condense_all: emitted counts of every region (int64[n_regions]) and the survivors of every scan position
+ * of the batch (2 per position, region order) */
+int mipgen_accel_download_survivors(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity);
+/* device pointer of that survivor array (mipgen_survivor[n_survivors], batch order): the send buffer of the multi-GPU gather */
+int mipgen_accel_survivors_device_ptr(const mipgen_accel* h, void** survivors_dev, int64_t* n_survivors);
+
+/* ---- tuning ---------------------------------------------------------------------------------------- */
+/* A dense SVR launch with few tiles is split along the support-vector list so that it still fills the chip (partial sums are added
+ * in a fixed order: results are deterministic for a given split).  0 = chosen per launch from the tile count (default), n >= 1 forces
+ * n parts - e.g. to compare two differently sized batches bit for bit. */
+int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
 
 /* ---- instrumentation ------------------------------------------------------------------------------ */
-/* HIP-event time (ms) of the dominant kernel of the last mipgen_accel_score_resident call, measured on the
- * handle's stream; negative if unavailable.  which: 0 = scoring kernel, 1 = all kernels of the call. */
+/* HIP-event time (ms) of the kernels of the last scoring call (summed over its windows), measured on the handle's stream;
+ * negative if unavailable.  which: 0 = dense SVR kernel, 1 = records + scoring kernels, 2 = records / logistic kernel,
+ * 3 = replay + condense. */
 double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which);
 /* enable/disable per-call event timing (it inserts two hipEventRecord per call) */
 int mipgen_accel_set_timing(mipgen_accel* h, int32_t enabled);

@@ -1,0 +1,94 @@
+/*
+ * mipgen_host.h — C ABI of the host side of the drop-in `mipgen` front end (libmipgen_host.so, C++17 inside):
+ * the stages either side of the accelerated hot path.
+ *
+ *   reference (citations into /root/reference)                          here
+ *   -------------------------------------------------------------------  ------------------------------------------------
+ *   mipgen::parse_command_line / parse_arg_values  mipgen.cpp:190-276,1280-1501   mipgen_design_open (options)
+ *   mipgen::query_sequences                        mipgen.cpp:293-400             mipgen_design_open (input stage: BED sort/merge,
+ *       get_features_to_scan :981-1043, get_chr_fasta_sequence_* :1087-1229,          FASTA slices, TRF masks, SNPs, bwa copy tables,
+ *       get_masked_features_to_scan :1045-1084, load_snps :875-978,                    output files + headers)
+ *       check_copy_numbers :796-873, find_copy :558-596
+ *   mipgen::tile_regions per-region tail           mipgen.cpp:503-555             mipgen_design_select_region (all_mips records,
+ *       print_details :765-794, collapse_mips :1616-1668, pick_mips :1506-1614,        collapse, pick, SNP re-design, gap files)
+ *       optimize_worst_in_region :1748-1820, translocate_down_region :1822-1908,
+ *       manage_picked_mip :1910-1939, print_gaps / create_gap :1231-1278
+ *   mipgen::tile_regions as a whole                mipgen.cpp:403-556             mipgen_design_run (drives libmipgen_accel on one
+ *                                                                                  or several GPUs, consumes results in region order)
+ *
+ * The selection stage is sequential by construction: picked MIPs are numbered globally, the libc rand() stream and the used-arm
+ * sets persist across regions (mipgen.cpp:97,1863,1912).  mipgen_design_select_region must therefore be called for region
+ * 0, 1, 2, ... in order, by one thread: in a multi-GPU run that thread is rank 0, fed with the survivors every rank's
+ * accelerator condensed (2 per scan position) - gathered over RCCL in the torch.distributed harness, or handed over in host
+ * memory by the per-device worker threads of mipgen_design_run.
+ *
+ * Conventions: plain C; 0 on success, negative on failure with a message in mipgen_host_last_error(); a design is single-owner.
+ */
+#ifndef MIPGEN_HOST_H
+#define MIPGEN_HOST_H
+
+#include "mipgen_accel.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPGEN_HOST_E_USAGE (-101)     /* command line rejected; the message is what the reference prints before exit 1 */
+#define MIPGEN_HOST_E_INPUT (-102)     /* input stage failed ("unable to tile sequences due to circumstance N", mipgen.cpp:2029-2032) */
+#define MIPGEN_HOST_E_ORDER (-103)     /* regions must be selected in order */
+#define MIPGEN_HOST_E_ACCEL (-104)     /* an accelerator call failed */
+
+typedef struct mipgen_design mipgen_design;
+
+const char* mipgen_host_last_error(void);
+/* the reference's `throw <int>` code of the last failure (mipgen.cpp:2029-2035), 0 if none */
+int mipgen_host_last_circumstance(void);
+
+/* argv as main() receives it (argv[0] locates mipgen_svr.model, mipgen.cpp:137-138,409).  Parses the options, runs the input stage
+ * (shelling out to bwa / tabix / trf exactly as the reference does) and opens <project>.all_mips/collapsed_mips/picked_mips/snp_mips.txt. */
+int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out);
+/* closes the output files, writes the tail of <project>.progress.txt */
+int mipgen_design_close(mipgen_design* d);
+
+int mipgen_design_params(const mipgen_design* d, mipgen_params* out);          /* what mipgen_accel_create needs */
+int32_t mipgen_design_score_method(const mipgen_design* d);                    /* MIPGEN_SCORE_* as requested (mixed stays mixed) */
+int32_t mipgen_design_silent(const mipgen_design* d);                          /* -silent_mode on */
+const char* mipgen_design_model_path(const mipgen_design* d);                  /* dirname(argv[0]) + "mipgen_svr.model" */
+int32_t mipgen_design_region_count(const mipgen_design* d);
+/* Region i (after sort + merge) in the accelerator's input layout; the pointers stay valid until mipgen_design_close. */
+int mipgen_design_region(const mipgen_design* d, int32_t i, mipgen_region* out);
+/* region +/- 1000 bases for Featurev5::get_long_range_content (svr / mixed designs; empty otherwise) */
+int mipgen_design_long_range_seq(const mipgen_design* d, int32_t i, const char** seq, int32_t* len);
+int mipgen_design_set_long_range_content(mipgen_design* d, int32_t i, const double* lrc44);
+
+/* SVR score of one candidate of region `region` for -score_method mixed (mipgen.cpp:1523-1527,1873-1877) */
+typedef double (*mipgen_rescore_fn)(void* ctx, int32_t region, const mipgen_candidate* cand);
+
+/*
+ * The per-region tail of tile_regions for region i (call with i = 0, 1, 2, ...):
+ *   grid        the region's dense-grid geometry as the accelerator laid it out
+ *   survivors   2 * grid->n_pos records ('+','-' per scan position) from replay + condense; cand_index is batch-wide
+ *               (grid->offset + index inside the region) or -1
+ *   emitted     number of candidates the reference would have constructed in this region (numbers the records)
+ *   scores / records / emitted_mask   the region's dense results (grid->count entries each) for the all_mips file; all three may
+ *               be NULL in -silent_mode
+ *   rescore     SVR re-score hook, used only by mixed designs; may be NULL otherwise
+ */
+int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors,
+                                int64_t emitted, const double* scores, const uint64_t* records, const uint8_t* emitted_mask,
+                                mipgen_rescore_fn rescore, void* ctx);
+/* counters after the regions selected so far: all / collapsed / picked records written, gaps reported */
+int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps);
+
+/*
+ * tile_regions on the accelerator: one libmipgen_accel handle per device, regions sharded over the devices in contiguous ranges
+ * balanced by dense-grid size, each device scoring / replaying / condensing its result windows on its own thread while the calling
+ * thread consumes the windows in region order through mipgen_design_select_region.  n_devices <= 0: every visible HIP device
+ * (or $MIPGEN_GPUS).  devices beyond the visible count wrap around (two handles on one GPU: a functional test of the sharding).
+ */
+int mipgen_design_run(mipgen_design* d, int32_t n_devices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPGEN_HOST_H */

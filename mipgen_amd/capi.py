@@ -274,9 +274,22 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_last_kernel_ms.argtypes = [vp, C.c_int32]
     lib.mipgen_accel_last_kernel_ms.restype = C.c_double
     lib.mipgen_accel_set_timing.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_set_window_candidates.argtypes = [vp, C.c_int64]
+    lib.mipgen_accel_window_count.argtypes = [vp]
+    lib.mipgen_accel_window_count.restype = C.c_int32
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    lib.mipgen_accel_window_info.argtypes = [vp, C.c_int32, i32p, i32p, i64p, i64p, i64p, i64p]
+    lib.mipgen_accel_score_window.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.mipgen_accel_score_condense_all.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_download_survivors.argtypes = [vp, i64p, C.POINTER(Survivor), C.c_int64]
+    lib.mipgen_accel_survivors_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
+    lib.mipgen_accel_set_sv_split.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
     for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
-                 "long_range_content", "replay_condense", "download_replay", "set_timing"):
+                 "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
+                 "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
+                 "set_sv_split", "long_range_content_batch"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -290,6 +303,9 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_result_device_ptrs", "mipgen_accel_download_results", "mipgen_accel_score_regions",
     "mipgen_accel_score_candidates", "mipgen_accel_long_range_content", "mipgen_accel_replay_condense",
     "mipgen_accel_download_replay", "mipgen_accel_last_kernel_ms", "mipgen_accel_set_timing",
+    "mipgen_accel_set_window_candidates", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
+    "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
+    "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch",
 ]
 
 
@@ -352,12 +368,50 @@ class Accel:
     def score_resident(self, method: int) -> None:
         self._check(self.lib.mipgen_accel_score_resident(self.h, method))
 
+    # result windows (batches whose dense results exceed the result arrays)
+    def set_window_candidates(self, max_candidates: int) -> None:
+        self._check(self.lib.mipgen_accel_set_window_candidates(self.h, max_candidates))
+
+    def window_count(self) -> int:
+        return int(self.lib.mipgen_accel_window_count(self.h))
+
+    def window_info(self, w: int) -> Dict[str, int]:
+        r0, nr = C.c_int32(), C.c_int32()
+        c0, nc, p0, np_ = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.mipgen_accel_window_info(self.h, w, C.byref(r0), C.byref(nr), C.byref(c0), C.byref(nc), C.byref(p0), C.byref(np_)))
+        return {"first_region": r0.value, "n_regions": nr.value, "first_candidate": c0.value, "n_candidates": nc.value,
+                "first_position": p0.value, "n_positions": np_.value}
+
+    def score_window(self, w: int, method: int) -> None:
+        self._check(self.lib.mipgen_accel_score_window(self.h, w, method))
+
+    def score_condense_all(self, method: int) -> None:
+        self._check(self.lib.mipgen_accel_score_condense_all(self.h, method))
+
+    def download_survivors(self):
+        nreg = len(self.grids)
+        emitted = np.zeros(nreg, dtype=np.int64)
+        npos = sum(g.n_pos for g in self.grids)
+        surv = np.zeros(2 * npos, dtype=SURVIVOR_DTYPE)
+        self._check(self.lib.mipgen_accel_download_survivors(self.h, emitted.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                             surv.ctypes.data_as(C.POINTER(Survivor)), 2 * npos))
+        return emitted, surv
+
+    def survivors_device_ptr(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.mipgen_accel_survivors_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def set_sv_split(self, n_split: int) -> None:
+        self._check(self.lib.mipgen_accel_set_sv_split(self.h, n_split))
+
     def result_device_ptrs(self) -> Tuple[int, int]:
         a, b = C.c_void_p(), C.c_void_p()
         self._check(self.lib.mipgen_accel_result_device_ptrs(self.h, C.byref(a), C.byref(b)))
         return a.value or 0, b.value or 0
 
     def download(self, first: int = 0, count: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """Dense results of the window scored last ([first, first+count) are batch-wide candidate indices inside it)."""
         n = self.batch_candidates() - first if count is None else count
         scores = np.empty(n, dtype=np.float64)
         records = np.empty(n, dtype=np.uint64)
@@ -366,10 +420,30 @@ class Accel:
         return scores, records
 
     def score_regions(self, regions: Sequence[RegionData], method: int) -> Tuple[List[Grid], np.ndarray, np.ndarray]:
+        """Upload, score every result window, dense results of the whole batch to the host."""
         self.upload(regions)
-        self.score_resident(method)
-        s, r = self.download()
-        return self.grids, s, r
+        total = self.batch_candidates()
+        scores = np.empty(total, dtype=np.float64)
+        records = np.empty(total, dtype=np.uint64)
+        for w in range(self.window_count()):
+            wi = self.window_info(w)
+            self.score_window(w, method)
+            c0, n = wi["first_candidate"], wi["n_candidates"]
+            scores[c0:c0 + n], records[c0:c0 + n] = self.download(c0, n)
+        return self.grids, scores, records
+
+    def score_regions_one_call(self, regions: Sequence[RegionData], method: int, capacity: int):
+        """mipgen_accel_score_regions itself (upload + score + download behind one C call)."""
+        arr = region_array(regions)
+        grids = (Grid * len(regions))()
+        scores = np.empty(capacity, dtype=np.float64)
+        records = np.empty(capacity, dtype=np.uint64)
+        self._check(self.lib.mipgen_accel_score_regions(self.h, arr, len(regions), method, grids, scores.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        records.ctypes.data_as(C.POINTER(C.c_uint64)), capacity))
+        self.grids = list(grids)
+        self._regions = regions
+        n = self.batch_candidates()
+        return self.grids, scores[:n], records[:n]
 
     def score_candidates(self, cands: Sequence[Tuple[int, int, int, int, int, int]], method: int,
                          want_features: bool = False, want_ints: bool = False):
@@ -388,6 +462,20 @@ class Accel:
             ints if ints is not None else None))
         return scores, records, feats, ints
 
+    def long_range_content_batch(self, seqs: Sequence[bytes], starts: Sequence[int], stops: Sequence[int]) -> np.ndarray:
+        n = len(seqs)
+        out = np.empty((n, N_LRC), dtype=np.float64)
+        if n == 0:
+            return out
+        arr = (C.c_char_p * n)(*seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.int32)
+        st = np.ascontiguousarray(starts, dtype=np.int32)
+        sp = np.ascontiguousarray(stops, dtype=np.int32)
+        i32p = C.POINTER(C.c_int32)
+        self._check(self.lib.mipgen_accel_long_range_content_batch(self.h, n, arr, lens.ctypes.data_as(i32p), st.ctypes.data_as(i32p),
+                                                                   sp.ctypes.data_as(i32p), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def long_range_content(self, extended_seq: bytes, chrom_seq_start: int, chrom_seq_stop: int) -> np.ndarray:
         out = np.empty(N_LRC, dtype=np.float64)
         self._check(self.lib.mipgen_accel_long_range_content(self.h, extended_seq, len(extended_seq), chrom_seq_start,
@@ -397,12 +485,15 @@ class Accel:
     def replay_condense(self) -> None:
         self._check(self.lib.mipgen_accel_replay_condense(self.h))
 
-    def download_replay(self, want_mask: bool = True):
-        nreg = len(self.grids)
+    def download_replay(self, want_mask: bool = True, window: Optional[int] = None):
+        """Replay / condense results of the window replayed last (a single-window batch: the whole batch)."""
+        if window is None and self.window_count() == 1:
+            nreg, npos, total = len(self.grids), sum(g.n_pos for g in self.grids), self.batch_candidates()
+        else:
+            wi = self.window_info(window if window is not None else 0)
+            nreg, npos, total = wi["n_regions"], wi["n_positions"], wi["n_candidates"]
         emitted = np.zeros(nreg, dtype=np.int64)
-        npos = sum(g.n_pos for g in self.grids)
         surv = np.zeros(2 * npos, dtype=SURVIVOR_DTYPE)
-        total = self.batch_candidates()
         mask = np.zeros(total if want_mask else 0, dtype=np.uint8)
         self._check(self.lib.mipgen_accel_download_replay(
             self.h, emitted.ctypes.data_as(C.POINTER(C.c_int64)), surv.ctypes.data_as(C.POINTER(Survivor)), 2 * npos,

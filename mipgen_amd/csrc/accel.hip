@@ -23,18 +23,19 @@ hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, i
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
                                           double*, uint64_t*);
 size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l);
-hipError_t mipgen_launch_svr_dense(hipStream_t, int deg, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
+hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
                                    const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
                                    const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
-                                   const uint64_t* records, double* scores);
+                                   const uint64_t* records, double* scores, int64_t n_cand, int n_split, double* partials);
 hipError_t mipgen_launch_candidates(hipStream_t, int n, const DevParams*, const DevRegion*, const mipgen_candidate*, const uint8_t*,
                                     const int32_t*, const uint8_t*, const HostConsts*, const double* model, int n_sv, double gamma,
                                     double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*);
-hipError_t mipgen_launch_long_range(hipStream_t, const char*, int len, int denom, const LrcMers*, double*);
+hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
+                                    const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, const DevRegion*,
                                          const int32_t* pos_region, const int32_t* pos_local, const double* scores,
-                                         const uint64_t* records, uint8_t* emitted, mipgen_survivor* survivors,
-                                         unsigned long long* emitted_per_region);
+                                         const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
+                                         mipgen_survivor* survivors, unsigned long long* emitted_per_region);
 }
 
 // ---- errors ----------------------------------------------------------------------------------------------
@@ -53,6 +54,14 @@ static int fail(int code, const char* fmt, ...)
         if (e__ != hipSuccess) return fail(MIPGEN_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
+// consecutive regions whose dense results share the result arrays at one time
+struct Window {
+    int r0 = 0, r1 = 0;              // regions [r0, r1)
+    int64_t cand0 = 0, n_cand = 0;   // batch-wide candidate index of the first candidate; candidates
+    int64_t pos0 = 0, n_pos = 0;     // batch-wide scan-position index; positions
+    int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0;
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -62,7 +71,7 @@ struct DevBuf {
         if (n <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        size_t want = n + n / 8 + 64;
+        size_t want = n + std::min<size_t>(n / 8, (size_t)1 << 20) + 64;
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e != hipSuccess) return fail(MIPGEN_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
         cap = want;
@@ -83,9 +92,12 @@ struct mipgen_accel {
     SvrGeom geom;
     // model
     int n_sv = 0;
-    double gamma = 0, rho = 0, s_guard = 0, sum_abs_coef = 0;
-    int exp_deg = 10;
+    double gamma = 0, rho = 0, s_guard = 0;
     DevBuf<double> model;
+    std::string svr_geometry_error;  // why the dense SVR kernel cannot run this parameter set ("" = it can); reported when SVR is requested
+    std::string svr_batch_error;     // same, for the resident batch (tile does not fit LDS)
+    int sv_split = 0;                // 0 = chosen per launch from the tile count; > 0 forced
+    int n_cu = 256;
     // batch
     int n_regions = 0;
     int64_t n_cand = 0;
@@ -97,9 +109,14 @@ struct mipgen_accel {
     DevBuf<int32_t> copy;
     DevBuf<LogTile> log_tiles;
     DevBuf<SvrTile> svr_tiles;
-    int n_log_tiles = 0, n_svr_tiles = 0, log_span_max = 0;
+    int log_span_max = 0;
     size_t svr_lds = 0;
-    DevBuf<double> scores;
+    // result windows: the inputs of every region stay resident; the dense result arrays (16 B per candidate) hold one window of
+    // consecutive regions at a time
+    int64_t window_cap = 0;          // max candidates per window; 0 = as many as fit in free device memory
+    std::vector<Window> windows;
+    int cur_window = -1;
+    DevBuf<double> scores, partials;
     DevBuf<uint64_t> records;
     bool scored = false;
     // replay
@@ -115,10 +132,12 @@ struct mipgen_accel {
     DevBuf<mipgen_candidate_ints> cand_ints;
     DevBuf<char> lrc_seq;
     DevBuf<double> lrc_out;
-    // timing
+    DevBuf<int64_t> lrc_offs;
+    DevBuf<int32_t> lrc_lens, lrc_denoms;
+    // timing: four events per window (records | svr | replay), summed over the windows of the last call
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<uint8_t> ev_used;    // per window: bit 0 scored, bit 1 replayed in the last call
 };
 
 // ---- small helpers ----------------------------------------------------------------------------------------
@@ -204,7 +223,9 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
         D.l_min = std::min(D.l_min, l); D.l_max = std::max(D.l_max, l);
         D.len_slot[e] = 0; D.len_slot[l] = 0;
     }
-    if (params->min_capture_size - D.max_sum < 3) { delete h; return fail(MIPGEN_E_INVALID, "min_capture_size leaves a scan size < 3"); }
+    if (params->min_capture_size - D.max_sum < 1) { delete h; return fail(MIPGEN_E_INVALID, "min_capture_size leaves no scan target (capture size <= arm length sum)"); }
+    // limits of the dense SVR kernel are reported when an SVR launch is requested: logistic designs are not bound by them
+    if (params->min_capture_size - D.max_sum < 3) h->svr_geometry_error = "min_capture_size leaves a scan size < 3 (insert 3-mer frequencies are undefined)";
     int slot = 0;
     for (int i = 0; i <= MIPGEN_MAX_OLIGO; i++) if (D.len_slot[i] == 0) D.len_slot[i] = (int8_t)slot++;
     D.n_len_slots = slot;
@@ -221,10 +242,14 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     G.chunk_len = (D.n_pairs + G.nchunk - 1) / G.nchunk;
     G.n_e = D.e_max - D.e_min + 1; G.n_l = D.l_max - D.l_min + 1;
     G.group = SVR_GROUP;
-    G.wpc = 4;
-    if (const char* e = getenv("MIPGEN_ACCEL_SVR_WPC")) G.wpc = std::max(1, atoi(e));   // tuning knob: waves per arm-pair chunk
+    G.wpc = 4;                                                   // waves per arm-pair chunk
     while (G.wpc > 1 && G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) G.wpc--;
-    if (G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) { delete h; return fail(MIPGEN_E_INVALID, "too many arm pairs for the dense SVR kernel (max %d)", SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64)); }
+    if (G.nchunk * G.wpc * 64 > SVR_MAX_THREADS) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "too many arm pairs for the dense SVR kernel (max %d)", SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64));
+        h->svr_geometry_error = msg;
+        G.wpc = 1;
+    }
     {
         const int n_arm = std::max(G.n_e, G.n_l) | 1;            // table row pitch in slots (as in the kernel)
         for (int strand = 0; strand < 2; strand++) {
@@ -250,9 +275,10 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     hipError_t e1 = hipMalloc((void**)&h->dp, sizeof(DevParams));
     hipError_t e2 = hipMalloc((void**)&h->dconsts, sizeof(HostConsts));
     if (e1 != hipSuccess || e2 != hipSuccess) { mipgen_accel_destroy(h); return fail(MIPGEN_E_NOMEM, "hipMalloc failed"); }
-    HIP_TRY(hipMemcpy(h->dp, &D, sizeof D, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->dconsts, &h->hconsts, sizeof(HostConsts), hipMemcpyHostToDevice));
-    for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[i]));
+    hipError_t e3 = hipMemcpy(h->dp, &D, sizeof D, hipMemcpyHostToDevice);
+    if (e3 == hipSuccess) e3 = hipMemcpy(h->dconsts, &h->hconsts, sizeof(HostConsts), hipMemcpyHostToDevice);
+    if (e3 != hipSuccess) { mipgen_accel_destroy(h); return fail(MIPGEN_E_HIP, "hipMemcpy of the run parameters: %s", hipGetErrorString(e3)); }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cu = cus; }
     *out = h;
     return MIPGEN_OK;
 }
@@ -266,10 +292,10 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->log_tiles.release(); h->svr_tiles.release(); h->scores.release(); h->records.release();
     h->emitted.release(); h->survivors.release(); h->emitted_per_region.release(); h->pos_region.release(); h->pos_local.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
-    h->lrc_seq.release(); h->lrc_out.release();
+    h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();
     if (h->dp) (void)hipFree(h->dp);
     if (h->dconsts) (void)hipFree(h->dconsts);
-    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (hipEvent_t e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -280,7 +306,7 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
     if (!h || n_sv < 0 || (n_sv > 0 && (!coef || !sv))) return fail(MIPGEN_E_INVALID, "bad model arguments");
     HIP_TRY(hipSetDevice(h->device));
     std::vector<double> rows((size_t)std::max(n_sv, 1) * SV_ROW, 0.0);
-    double s_guard = 0.0, sum_abs = 0.0;
+    double s_guard = 0.0;
     for (int i = 0; i < n_sv; i++) {
         double* r = &rows[(size_t)i * SV_ROW];
         const double* x = sv + (size_t)i * MIPGEN_N_FEATURES;
@@ -297,16 +323,10 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
         r[SVR_COEF] = coef[i]; r[SVR_N_EXT] = ne; r[SVR_N_INS] = ni; r[SVR_N_LIG] = nl; r[SVR_N_JUNC] = nj;
         r[SVR_N_TOTAL] = tot; r[SVR_N_EXTRA] = 0.0;
         s_guard += coef[i] * exp(-gamma * tot);
-        sum_abs += fabs(coef[i]);
     }
     if (h->model.reserve(rows.size())) return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
-    h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho; h->sum_abs_coef = sum_abs;
-    // The dense kernel takes its exponentials once per table entry (the RBF value factorises over the feature blocks); a kernel value
-    // is the product of three of them.  Degree 8 (relative error 1.1e-12 per factor) while 3.2e-12 * sum|coef| stays below 1e-7 (the
-    // score gate is 1e-5), else degree 10 (6.7e-16).
-    h->exp_deg = sum_abs * 3.2e-12 <= 1e-7 ? 8 : 10;
-    if (const char* f = getenv("MIPGEN_ACCEL_EXP_DEG")) { const int d = atoi(f); if (d == 8 || d == 10) h->exp_deg = d; }   // tests force both
+    h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho;
     return MIPGEN_OK;
 }
 
@@ -391,16 +411,31 @@ int mipgen_accel_model_info(const mipgen_accel* h, int32_t* n_sv, double* gamma,
 }
 
 // ---- region batch ---------------------------------------------------------------------------------------------
+int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates)
+{
+    if (!h || max_candidates < 0) return fail(MIPGEN_E_INVALID, "bad arguments");
+    h->window_cap = max_candidates;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split)
+{
+    if (!h || n_split < 0 || n_split > 64) return fail(MIPGEN_E_INVALID, "n_split must be in [0, 64] (0 = automatic)");
+    h->sv_split = n_split;
+    return MIPGEN_OK;
+}
+
 int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, mipgen_grid* grids_out)
 {
     if (!h || n < 0 || (n > 0 && !regions)) return fail(MIPGEN_E_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(h->device));
     const mipgen_params& P = h->params;
     const DevParams& D = h->hp;
-    h->scored = false; h->replayed = false;
+    h->cur_window = -1;
+    h->windows.clear();
     h->hregions.assign((size_t)n, DevRegion());
     h->grids.assign((size_t)n, mipgen_grid());
-    int64_t seq_total = 0, copy_total = 0, unmap_total = 0, cand_total = 0, pos_total = 0;
+    int64_t seq_total = 0, copy_total = 0, unmap_total = 0, cand_total = 0, pos_total = 0, cand_max = 0;
     for (int i = 0; i < n; i++) {
         const mipgen_region& R = regions[i];
         if (!R.seq || R.seq_len <= 0) return fail(MIPGEN_E_INVALID, "region %d has no sequence", i);
@@ -409,7 +444,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         mipgen_grid& g = h->grids[i];
         grid_of(P, D, R, &g);
         g.offset = cand_total;
-        d.out_off = cand_total; d.seq_off = seq_total;
+        d.seq_off = seq_total;
         d.seq_len = R.seq_len; d.seq_start = R.seq_start; d.seq_stop = R.seq_stop;
         d.start_fl = R.start_flanked; d.stop_fl = R.stop_flanked;
         d.first_pos = g.first_pos; d.n_pos = g.n_pos; d.k0 = g.first_size_index; d.n_sizes = g.n_sizes;
@@ -421,7 +456,9 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         if (R.unmappable) unmap_total += (int64_t)D.n_sizes_all * R.seq_len;
         cand_total += g.count;
         pos_total += g.n_pos;
+        cand_max = std::max(cand_max, g.count);
     }
+    if (pos_total > INT32_MAX) return fail(MIPGEN_E_INVALID, "batch has %lld scan positions (max %d): split the design", (long long)pos_total, INT32_MAX);
     // encode + pack on the host
     std::vector<uint8_t> hb((size_t)std::max<int64_t>(seq_total, 1));
     std::vector<int32_t> hc((size_t)std::max<int64_t>(copy_total, 1));
@@ -448,60 +485,92 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         }
         if (R.unmappable) memcpy(&hu[(size_t)d.unmap_off], R.unmappable, (size_t)D.n_sizes_all * R.seq_len);
     }
-    // tiles
+    // inputs -> HBM (everything the kernels read stays resident for the whole batch)
+    if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
+        h->survivors.reserve((size_t)std::max<int64_t>(2 * pos_total, 1)) || h->emitted_per_region.reserve((size_t)std::max(n, 1)) ||
+        h->pos_region.reserve((size_t)std::max<int64_t>(pos_total, 1)) || h->pos_local.reserve((size_t)std::max<int64_t>(pos_total, 1)))
+        return MIPGEN_E_NOMEM;
+
+    // ---- result windows: consecutive regions, at most `cap` candidates each (17 B per candidate: score, record, emitted flag) ----
+    int64_t cap = h->window_cap;
+    if (cap <= 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const int64_t have = (int64_t)(h->scores.cap * 8 + h->records.cap * 8 + h->emitted.cap) + (int64_t)free_b;   // what the result arrays may grow into
+        cap = std::max<int64_t>(1, (int64_t)((double)have * 0.85) / 17);
+    }
+    if (cand_max > cap && h->window_cap > 0) cap = cand_max;       // a region is never split: one oversized region is its own window
+    if (cand_max > cap) return fail(MIPGEN_E_NOMEM, "a single region has %lld dense candidates; device memory holds %lld", (long long)cand_max, (long long)cap);
+    {
+        Window w;
+        for (int i = 0; i < n; i++) {
+            const mipgen_grid& g = h->grids[i];
+            if (w.r1 > w.r0 && w.n_cand + g.count > cap) {
+                h->windows.push_back(w);
+                Window nw; nw.r0 = nw.r1 = i; nw.cand0 = w.cand0 + w.n_cand; nw.pos0 = w.pos0 + w.n_pos;
+                w = nw;
+            }
+            h->hregions[i].out_off = w.n_cand;                     // window-relative: the result arrays are reused window after window
+            w.n_cand += g.count; w.n_pos += g.n_pos; w.r1 = i + 1;
+        }
+        h->windows.push_back(w);                                   // an empty batch is one empty window
+    }
+    int64_t win_cand_max = 0;
+    for (const Window& w : h->windows) win_cand_max = std::max(win_cand_max, w.n_cand);
+
+    // ---- tiles, window by window ----
     std::vector<LogTile> lt;
     std::vector<SvrTile> st;
     const int Lmax = std::max(D.e_max, D.l_max);
     int span_max = 0;
     size_t svr_lds = 0;
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
-    for (int i = 0; i < n; i++) {
-        const DevRegion& d = h->hregions[i];
-        if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
-        const int Cmax = D.max_capture - d.k0 * D.inc;
-        int NPL = 8;        // 8 positions per records tile: ~10 resident blocks per CU hide the per-candidate gathers (32: 2.6 waves/SIMD, 45 % slower)
-        if (const char* e = getenv("MIPGEN_ACCEL_NPL")) NPL = std::max(1, atoi(e));   // tuning knob: positions per records tile
-        for (int p0 = 0; p0 < d.n_pos; p0 += NPL) {
-            LogTile t = {i, p0, std::min(NPL, d.n_pos - p0), 0};
-            lt.push_back(t);
-            span_max = std::max(span_max, t.np + Cmax + Lmax);
-        }
-        // SVR tiles: capture sizes in nearly equal runs of <= 9 (fewer when the scan-size range would not fit LDS), positions in runs
-        // that fill the block's lanes
-        const int NP_CAP = 32;
-        for (int kc_cap = 9; kc_cap >= 1; kc_cap--) {
-            std::vector<SvrTile> rt;
-            size_t lds_r = 0;
-            const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
-            for (int c = 0; c < nkc; c++) {
-                const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
-                const int kc = ki1 - ki0;
-                int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
-                // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping)
-                { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 8 >= np * 7) np = np_cf; }
-                const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
-                const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
-                for (int p0 = 0; p0 < d.n_pos; p0 += np) {
-                    const int npt = std::min(np, d.n_pos - p0);
-                    for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; rt.push_back(t); }
+    const bool svr_possible = h->svr_geometry_error.empty();
+    for (Window& w : h->windows) {
+        w.log_tile0 = (int)lt.size(); w.svr_tile0 = (int)st.size();
+        for (int i = w.r0; i < w.r1; i++) {
+            const DevRegion& d = h->hregions[i];
+            if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
+            const int Cmax = D.max_capture - d.k0 * D.inc;
+            const int NPL = 8;  // 8 positions per records tile: ~10 resident blocks per CU hide the per-candidate gathers (32: 2.6 waves/SIMD, 45 % slower)
+            for (int p0 = 0; p0 < d.n_pos; p0 += NPL) {
+                LogTile t = {i, p0, std::min(NPL, d.n_pos - p0), 0};
+                lt.push_back(t);
+                span_max = std::max(span_max, t.np + Cmax + Lmax);
+            }
+            if (!svr_possible) continue;
+            // SVR tiles: capture sizes in nearly equal runs of <= 9 (fewer when the scan-size range would not fit LDS), positions in runs
+            // that fill the block's lanes
+            const int NP_CAP = 32;
+            for (int kc_cap = 9; kc_cap >= 1; kc_cap--) {
+                const size_t st_mark = st.size();
+                size_t lds_r = 0;
+                const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
+                for (int c = 0; c < nkc; c++) {
+                    const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
+                    const int kc = ki1 - ki0;
+                    int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
+                    // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping)
+                    { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 8 >= np * 7) np = np_cf; }
+                    const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
+                    const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
+                    for (int p0 = 0; p0 < d.n_pos; p0 += np) {
+                        const int npt = std::min(np, d.n_pos - p0);
+                        for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; st.push_back(t); }
+                    }
+                    lds_r = std::max(lds_r, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
                 }
-                lds_r = std::max(lds_r, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
-            }
-            if (lds_r <= 160 * 1024 || kc_cap == 1) {
-                st.insert(st.end(), rt.begin(), rt.end());
-                svr_lds = std::max(svr_lds, lds_r);
-                break;
+                if (lds_r <= 160 * 1024 || kc_cap == 1) { svr_lds = std::max(svr_lds, lds_r); break; }
+                st.resize(st_mark);
             }
         }
+        w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0;
     }
-    if (svr_lds > 160 * 1024) return fail(MIPGEN_E_INVALID, "SVR tile needs %zu bytes of LDS (> 160 KiB): capture range / arm lists too wide", svr_lds);
-    if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
-        h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
-        h->scores.reserve((size_t)std::max<int64_t>(cand_total, 1)) || h->records.reserve((size_t)std::max<int64_t>(cand_total, 1)))
-        return MIPGEN_E_NOMEM;
-    if (h->emitted.reserve((size_t)std::max<int64_t>(cand_total, 1)) || h->survivors.reserve((size_t)std::max<int64_t>(2 * pos_total, 1)) ||
-        h->emitted_per_region.reserve((size_t)std::max(n, 1)) || h->pos_region.reserve((size_t)std::max<int64_t>(pos_total, 1)) ||
-        h->pos_local.reserve((size_t)std::max<int64_t>(pos_total, 1)))
+    h->svr_batch_error.clear();
+    if (svr_lds > 160 * 1024) { h->svr_batch_error = "an SVR tile needs more than 160 KiB of LDS: capture range / arm lists too wide"; st.clear(); for (Window& w : h->windows) { w.svr_tile0 = 0; w.n_svr_tiles = 0; } svr_lds = 0; }
+    if (h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
+        h->scores.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) || h->records.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) ||
+        h->emitted.reserve((size_t)std::max<int64_t>(win_cand_max, 1)))
         return MIPGEN_E_NOMEM;
     std::vector<int32_t> pr((size_t)pos_total), pl((size_t)pos_total);
     {
@@ -520,35 +589,137 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     if (!st.empty()) HIP_TRY(hipMemcpyAsync(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
-    h->n_log_tiles = (int)lt.size(); h->n_svr_tiles = (int)st.size(); h->log_span_max = span_max; h->svr_lds = svr_lds;
-    if (getenv("MIPGEN_ACCEL_VERBOSE"))
-        fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates, %d record tiles (LDS %zu B), %d SVR tiles x %d threads (LDS %zu B)\n", n,
-                (long long)cand_total, h->n_log_tiles, mipgen_logistic_lds_bytes(span_max), h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, svr_lds);
+    h->log_span_max = span_max; h->svr_lds = svr_lds;
+    h->scored = false; h->replayed = false;
+    h->ev_used.assign(h->windows.size(), 0);
+#ifdef MIPGEN_DIAG
+    fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates in %zu window(s), %zu record tiles (LDS %zu B), %zu SVR tiles x %d threads (LDS %zu B)\n", n,
+            (long long)cand_total, h->windows.size(), lt.size(), mipgen_logistic_lds_bytes(span_max), st.size(), h->geom.nchunk * h->geom.wpc * 64, svr_lds);
+#endif
     if (grids_out) memcpy(grids_out, h->grids.data(), (size_t)n * sizeof(mipgen_grid));
     return MIPGEN_OK;
 }
 
 int64_t mipgen_accel_batch_candidates(const mipgen_accel* h) { return h ? h->n_cand : 0; }
+int32_t mipgen_accel_window_count(const mipgen_accel* h) { return h ? (int32_t)h->windows.size() : 0; }
 
-int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
+int mipgen_accel_window_info(const mipgen_accel* h, int32_t w, int32_t* first_region, int32_t* n_regions, int64_t* first_candidate,
+                             int64_t* n_candidates, int64_t* first_position, int64_t* n_positions)
+{
+    if (!h || w < 0 || w >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "window %d out of range", w);
+    const Window& W = h->windows[(size_t)w];
+    if (first_region) *first_region = W.r0;
+    if (n_regions) *n_regions = W.r1 - W.r0;
+    if (first_candidate) *first_candidate = W.cand0;
+    if (n_candidates) *n_candidates = W.n_cand;
+    if (first_position) *first_position = W.pos0;
+    if (n_positions) *n_positions = W.n_pos;
+    return MIPGEN_OK;
+}
+
+// Support-vector split of a dense SVR launch: a batch with few tiles is cut along the SV list so that it still fills the chip.
+// Cost model in units of one SV-group iteration of a tile: a work unit pays the tile set-up (PH0) plus its share of the groups;
+// units are dispatched to n_cu compute units in rounds.
+static int pick_sv_split(int n_tiles, int n_sv, int n_cu)
+{
+    const int groups = (n_sv + SVR_GROUP - 1) / SVR_GROUP;
+    const double PH0 = 6.0;
+    int best = 1;
+    double best_cost = 0;
+    for (int s = 1; s <= 8; s++) {
+        if (s > 1 && groups / s < 32) break;
+        const int64_t units = (int64_t)n_tiles * s, rounds = (units + n_cu - 1) / n_cu;
+        const double cost = (double)rounds * (PH0 + (double)((groups + s - 1) / s));
+        if (s == 1 || cost < best_cost * 0.98) { best = s; best_cost = cost; }
+    }
+    return best;
+}
+
+static int ensure_events(mipgen_accel* h)
+{
+    const size_t want = 4 * h->windows.size();
+    while (h->ev.size() < want) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    return 0;
+}
+
+static int score_window_impl(mipgen_accel* h, int w, int32_t method)
+{
+    const Window& W = h->windows[(size_t)w];
+    if (method == MIPGEN_SCORE_SVR && !h->svr_geometry_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_geometry_error.c_str());
+    if (method == MIPGEN_SCORE_SVR && !h->svr_batch_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_batch_error.c_str());
+    hipEvent_t* ev = nullptr;
+    if (h->timing) { if (ensure_events(h)) return MIPGEN_E_HIP; ev = &h->ev[4 * (size_t)w]; }
+    if (ev) HIP_TRY(hipEventRecord(ev[0], h->stream));
+    HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
+                                           h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], h->stream));
+    if (method == MIPGEN_SCORE_SVR) {
+        const double gamma_l2e = h->gamma * 1.4426950408889634074;
+        int split = h->sv_split > 0 ? h->sv_split : pick_sv_split(W.n_svr_tiles, h->n_sv, h->n_cu);
+        split = std::max(1, std::min(split, (h->n_sv + SVR_GROUP - 1) / SVR_GROUP));
+        if (split > 1 && h->partials.reserve((size_t)(split - 1) * (size_t)std::max<int64_t>(W.n_cand, 1))) return MIPGEN_E_NOMEM;
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, W.n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p,
+                                        h->svr_tiles.p + W.svr_tile0, h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */,
+                                        h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, split, h->partials.p));
+    }
+    if (ev) { HIP_TRY(hipEventRecord(ev[2], h->stream)); h->ev_used[(size_t)w] |= 1; }
+    h->cur_window = w; h->scored = true; h->replayed = false;
+    return MIPGEN_OK;
+}
+
+static int replay_window_impl(mipgen_accel* h)
+{
+    const int w = h->cur_window;
+    const Window& W = h->windows[(size_t)w];
+    // asynchronous on the handle's stream; buffers and the position map were laid out at upload
+    if (W.r1 > W.r0) HIP_TRY(hipMemsetAsync(h->emitted_per_region.p + W.r0, 0, (size_t)(W.r1 - W.r0) * sizeof(unsigned long long), h->stream));
+    if (W.n_cand) HIP_TRY(hipMemsetAsync(h->emitted.p, 0, (size_t)W.n_cand, h->stream));
+    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)W.n_pos, h->dp, h->regions.p, h->pos_region.p + W.pos0, h->pos_local.p + W.pos0,
+                                          h->scores.p, h->records.p, h->copy.p, W.cand0, h->emitted.p, h->survivors.p + 2 * W.pos0, h->emitted_per_region.p));
+    if (h->timing && h->ev.size() >= 4 * ((size_t)w + 1)) { HIP_TRY(hipEventRecord(h->ev[4 * (size_t)w + 3], h->stream)); h->ev_used[(size_t)w] |= 2; }
+    h->replayed = true;
+    return MIPGEN_OK;
+}
+
+static int check_scoring_args(mipgen_accel* h, int32_t method)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
     if (method != MIPGEN_SCORE_LOGISTIC && method != MIPGEN_SCORE_SVR) return fail(MIPGEN_E_INVALID, "method must be logistic or svr");
-    if (h->n_regions <= 0 && h->n_cand == 0 && h->regions.p == nullptr) return fail(MIPGEN_E_STATE, "no resident region batch");
+    if (h->windows.empty()) return fail(MIPGEN_E_STATE, "no resident region batch");
     if (method == MIPGEN_SCORE_SVR && h->n_sv <= 0 && h->model.p == nullptr) return fail(MIPGEN_E_MODEL, "SVR scoring requested but no model is loaded");
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_score_window(mipgen_accel* h, int32_t w, int32_t method)
+{
+    if (int rc = check_scoring_args(h, method)) return rc;
+    if (w < 0 || w >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "window %d out of range (%zu windows)", w, h->windows.size());
     HIP_TRY(hipSetDevice(h->device));
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, h->n_log_tiles, h->log_span_max, h->dp, h->regions.p,
-                                           h->log_tiles.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    if (method == MIPGEN_SCORE_SVR) {
-        const double gamma_l2e = h->gamma * 1.4426950408889634074;
-        HIP_TRY(mipgen_launch_svr_dense(h->stream, h->exp_deg, h->n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, h->svr_tiles.p,
-                                        h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard,
-                                        h->records.p, h->scores.p));
+    std::fill(h->ev_used.begin(), h->ev_used.end(), 0);
+    return score_window_impl(h, w, method);
+}
+
+int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
+{
+    if (int rc = check_scoring_args(h, method)) return rc;
+    if (h->windows.size() != 1)
+        return fail(MIPGEN_E_STATE, "the resident batch spans %zu result windows: use mipgen_accel_score_window / mipgen_accel_score_condense_all", h->windows.size());
+    return mipgen_accel_score_window(h, 0, method);
+}
+
+int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
+{
+    if (int rc = check_scoring_args(h, method)) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    std::fill(h->ev_used.begin(), h->ev_used.end(), 0);
+    for (int w = 0; w < (int)h->windows.size(); w++) {
+        if (int rc = score_window_impl(h, w, method)) return rc;
+        if (int rc = replay_window_impl(h)) return rc;
     }
-    if (h->timing) { HIP_TRY(hipEventRecord(h->ev[2], h->stream)); h->ev_valid = true; }
-    h->scored = true; h->replayed = false;
     return MIPGEN_OK;
 }
 
@@ -563,12 +734,15 @@ int mipgen_accel_result_device_ptrs(const mipgen_accel* h, void** scores_dev, vo
 int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* records, int64_t first, int64_t count)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
-    if (!h->scored) return fail(MIPGEN_E_STATE, "nothing scored yet");
-    if (first < 0 || count < 0 || first + count > h->n_cand) return fail(MIPGEN_E_INVALID, "range [%lld,+%lld) outside the batch (%lld)", (long long)first, (long long)count, (long long)h->n_cand);
+    if (!h->scored || h->cur_window < 0) return fail(MIPGEN_E_STATE, "nothing scored yet");
+    const Window& W = h->windows[(size_t)h->cur_window];
+    if (first < W.cand0 || count < 0 || first + count > W.cand0 + W.n_cand)
+        return fail(MIPGEN_E_INVALID, "range [%lld,+%lld) outside the scored window [%lld,+%lld)", (long long)first, (long long)count, (long long)W.cand0, (long long)W.n_cand);
     HIP_TRY(hipSetDevice(h->device));
     if (count == 0) { HIP_TRY(hipStreamSynchronize(h->stream)); return MIPGEN_OK; }
-    if (scores) HIP_TRY(hipMemcpyAsync(scores, h->scores.p + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (records) HIP_TRY(hipMemcpyAsync(records, h->records.p + first, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    const int64_t off = first - W.cand0;
+    if (scores) HIP_TRY(hipMemcpyAsync(scores, h->scores.p + off, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (records) HIP_TRY(hipMemcpyAsync(records, h->records.p + off, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MIPGEN_OK;
 }
@@ -579,9 +753,14 @@ int mipgen_accel_score_regions(mipgen_accel* h, const mipgen_region* regions, in
     int rc = mipgen_accel_upload_regions(h, regions, n, grids_out);
     if (rc) return rc;
     if (h->n_cand > capacity) return fail(MIPGEN_E_INVALID, "result capacity %lld < %lld candidates", (long long)capacity, (long long)h->n_cand);
-    rc = mipgen_accel_score_resident(h, method);
-    if (rc) return rc;
-    return mipgen_accel_download_results(h, scores, records, 0, h->n_cand);
+    for (int w = 0; w < (int)h->windows.size(); w++) {
+        const Window& W = h->windows[(size_t)w];
+        rc = mipgen_accel_score_window(h, w, method);
+        if (rc) return rc;
+        rc = mipgen_accel_download_results(h, scores ? scores + W.cand0 : nullptr, records ? records + W.cand0 : nullptr, W.cand0, W.n_cand);
+        if (rc) return rc;
+    }
+    return MIPGEN_OK;
 }
 
 int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands, int32_t n, int32_t method, double* scores,
@@ -609,13 +788,9 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
     return MIPGEN_OK;
 }
 
-int mipgen_accel_long_range_content(mipgen_accel* h, const char* extended_seq, int32_t len, int32_t chrom_seq_start,
-                                    int32_t chrom_seq_stop, double* out44)
+static void lrc_mers(LrcMers& M)
 {
-    if (!h || !extended_seq || len < 0 || !out44) return fail(MIPGEN_E_INVALID, "bad arguments");
-    HIP_TRY(hipSetDevice(h->device));
     static const char* mers[MIPGEN_N_LRC] = MIPGEN_FEATURE_MERS;
-    LrcMers M;
     auto code = [](char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
     for (int i = 0; i < MIPGEN_N_LRC; i++) {
         const int k = (int)strlen(mers[i]);
@@ -624,34 +799,79 @@ int mipgen_accel_long_range_content(mipgen_accel* h, const char* extended_seq, i
         for (int j = k - 1; j >= 0; j--) rc = rc * 4 + (3 - code(mers[i][j]));
         M.k[i] = (int8_t)k; M.code[i] = (int8_t)cd; M.rc[i] = (int8_t)(rc == cd ? -1 : rc);
     }
-    if (h->lrc_seq.reserve((size_t)std::max(len, 1)) || h->lrc_out.reserve(MIPGEN_N_LRC)) return MIPGEN_E_NOMEM;
-    if (len) HIP_TRY(hipMemcpyAsync(h->lrc_seq.p, extended_seq, (size_t)len, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(mipgen_launch_long_range(h->stream, h->lrc_seq.p, len, chrom_seq_stop - chrom_seq_start + 2001, &M, h->lrc_out.p));
-    HIP_TRY(hipMemcpyAsync(out44, h->lrc_out.p, MIPGEN_N_LRC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+}
+
+int mipgen_accel_long_range_content_batch(mipgen_accel* h, int32_t n, const char* const* extended_seqs, const int32_t* lens,
+                                          const int32_t* chrom_seq_starts, const int32_t* chrom_seq_stops, double* out)
+{
+    if (!h || n < 0 || (n > 0 && (!extended_seqs || !lens || !chrom_seq_starts || !chrom_seq_stops || !out))) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (n == 0) return MIPGEN_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    LrcMers M;
+    lrc_mers(M);
+    std::vector<int64_t> offs((size_t)n);
+    std::vector<int32_t> denoms((size_t)n);
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (lens[i] < 0 || (lens[i] > 0 && !extended_seqs[i])) return fail(MIPGEN_E_INVALID, "long-range sequence %d is missing", i);
+        offs[(size_t)i] = total; total += lens[i];
+        denoms[(size_t)i] = chrom_seq_stops[i] - chrom_seq_starts[i] + 2001;          // Featurev5.cpp:49,53
+    }
+    std::vector<char> packed((size_t)std::max<int64_t>(total, 1));
+    for (int i = 0; i < n; i++) if (lens[i]) memcpy(&packed[(size_t)offs[(size_t)i]], extended_seqs[i], (size_t)lens[i]);
+    if (h->lrc_seq.reserve(packed.size()) || h->lrc_out.reserve((size_t)n * MIPGEN_N_LRC) || h->lrc_offs.reserve((size_t)n) ||
+        h->lrc_lens.reserve((size_t)n) || h->lrc_denoms.reserve((size_t)n))
+        return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(h->lrc_seq.p, packed.data(), packed.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->lrc_offs.p, offs.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->lrc_lens.p, lens, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->lrc_denoms.p, denoms.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(mipgen_launch_long_range(h->stream, n, h->lrc_seq.p, h->lrc_offs.p, h->lrc_lens.p, h->lrc_denoms.p, &M, h->lrc_out.p));
+    HIP_TRY(hipMemcpyAsync(out, h->lrc_out.p, (size_t)n * MIPGEN_N_LRC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MIPGEN_OK;
+}
+
+int mipgen_accel_long_range_content(mipgen_accel* h, const char* extended_seq, int32_t len, int32_t chrom_seq_start,
+                                    int32_t chrom_seq_stop, double* out44)
+{
+    if (!h || !extended_seq || len < 0 || !out44) return fail(MIPGEN_E_INVALID, "bad arguments");
+    return mipgen_accel_long_range_content_batch(h, 1, &extended_seq, &len, &chrom_seq_start, &chrom_seq_stop, out44);
 }
 
 int mipgen_accel_replay_condense(mipgen_accel* h)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
-    if (!h->scored) return fail(MIPGEN_E_STATE, "replay requested before scoring");
+    if (!h->scored || h->cur_window < 0) return fail(MIPGEN_E_STATE, "replay requested before scoring");
     HIP_TRY(hipSetDevice(h->device));
-    // asynchronous on the handle's stream; buffers and the position map were laid out at upload
-    HIP_TRY(hipMemsetAsync(h->emitted_per_region.p, 0, (size_t)std::max(h->n_regions, 1) * sizeof(unsigned long long), h->stream));
-    HIP_TRY(hipMemsetAsync(h->emitted.p, 0, (size_t)std::max<int64_t>(h->n_cand, 1), h->stream));
-    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)h->total_pos, h->dp, h->regions.p, h->pos_region.p, h->pos_local.p,
-                                          h->scores.p, h->records.p, h->emitted.p, h->survivors.p, h->emitted_per_region.p));
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[3], h->stream));
-    h->replayed = true;
-    return MIPGEN_OK;
+    return replay_window_impl(h);
 }
 
 int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity,
                                  uint8_t* emitted_mask, int64_t mask_capacity)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
-    if (!h->replayed) return fail(MIPGEN_E_STATE, "mipgen_accel_replay_condense has not run on these scores");
+    if (!h->replayed || h->cur_window < 0) return fail(MIPGEN_E_STATE, "mipgen_accel_replay_condense has not run on these scores");
+    const Window& W = h->windows[(size_t)h->cur_window];
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (emitted_per_region && W.r1 > W.r0)
+        HIP_TRY(hipMemcpy(emitted_per_region, h->emitted_per_region.p + W.r0, (size_t)(W.r1 - W.r0) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (survivors) {
+        if (survivor_capacity < 2 * W.n_pos) return fail(MIPGEN_E_INVALID, "survivor capacity too small");
+        if (W.n_pos) HIP_TRY(hipMemcpy(survivors, h->survivors.p + 2 * W.pos0, (size_t)(2 * W.n_pos) * sizeof(mipgen_survivor), hipMemcpyDeviceToHost));
+    }
+    if (emitted_mask) {
+        if (mask_capacity < W.n_cand) return fail(MIPGEN_E_INVALID, "mask capacity too small");
+        if (W.n_cand) HIP_TRY(hipMemcpy(emitted_mask, h->emitted.p, (size_t)W.n_cand, hipMemcpyDeviceToHost));
+    }
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_download_survivors(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (!h->replayed || h->cur_window != (int)h->windows.size() - 1) return fail(MIPGEN_E_STATE, "mipgen_accel_score_condense_all has not run on this batch");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (emitted_per_region && h->n_regions)
@@ -660,32 +880,50 @@ int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, m
         if (survivor_capacity < 2 * h->total_pos) return fail(MIPGEN_E_INVALID, "survivor capacity too small");
         if (h->total_pos) HIP_TRY(hipMemcpy(survivors, h->survivors.p, (size_t)(2 * h->total_pos) * sizeof(mipgen_survivor), hipMemcpyDeviceToHost));
     }
-    if (emitted_mask) {
-        if (mask_capacity < h->n_cand) return fail(MIPGEN_E_INVALID, "mask capacity too small");
-        if (h->n_cand) HIP_TRY(hipMemcpy(emitted_mask, h->emitted.p, (size_t)h->n_cand, hipMemcpyDeviceToHost));
-    }
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_survivors_device_ptr(const mipgen_accel* h, void** survivors_dev, int64_t* n_survivors)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (survivors_dev) *survivors_dev = h->survivors.p;
+    if (n_survivors) *n_survivors = 2 * h->total_pos;
     return MIPGEN_OK;
 }
 
 double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which)
 {
-    if (!h || !h->ev_valid) return -1.0;
+    if (!h || !h->timing) return -1.0;
     if (hipSetDevice(h->device) != hipSuccess) return -1.0;
-    if (hipEventSynchronize(h->ev[2]) != hipSuccess) return -1.0;
-    float ms = -1.f;
-    hipError_t e;
-    if (which == 0) e = hipEventElapsedTime(&ms, h->ev[1], h->ev[2]);       // SVR kernel (or ~0 for logistic)
-    else if (which == 2) e = hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);  // records/logistic kernel
-    else if (which == 3) { if (hipEventSynchronize(h->ev[3]) != hipSuccess) return -1.0; e = hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); }  // replay+condense
-    else e = hipEventElapsedTime(&ms, h->ev[0], h->ev[2]);
-    return e == hipSuccess ? (double)ms : -1.0;
+    double total = 0.0;
+    bool any = false;
+    for (size_t w = 0; w < h->windows.size() && 4 * (w + 1) <= h->ev.size(); w++) {
+        const uint8_t used = h->ev_used[w];
+        if (!(used & 1)) continue;
+        hipEvent_t* ev = &h->ev[4 * w];
+        float ms = 0.f;
+        hipError_t e = hipSuccess;
+        if (which == 3) {                                                        // replay + condense (incl. its memsets)
+            if (!(used & 2)) continue;
+            if (hipEventSynchronize(ev[3]) != hipSuccess) return -1.0;
+            e = hipEventElapsedTime(&ms, ev[2], ev[3]);
+        } else {
+            if (hipEventSynchronize(ev[2]) != hipSuccess) return -1.0;
+            if (which == 0) e = hipEventElapsedTime(&ms, ev[1], ev[2]);          // SVR kernel (~0 for logistic)
+            else if (which == 2) e = hipEventElapsedTime(&ms, ev[0], ev[1]);     // records / logistic kernel
+            else e = hipEventElapsedTime(&ms, ev[0], ev[2]);
+        }
+        if (e != hipSuccess) return -1.0;
+        total += ms; any = true;
+    }
+    return any ? total : -1.0;
 }
 
 int mipgen_accel_set_timing(mipgen_accel* h, int32_t enabled)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
     h->timing = enabled != 0;
-    h->ev_valid = false;
+    std::fill(h->ev_used.begin(), h->ev_used.end(), 0);
     return MIPGEN_OK;
 }
 

@@ -125,14 +125,15 @@ struct SvrGeom {
 #define SVR_N_ARR 7          // prefix arrays per support vector: insert 1/2/3-mers, upstream arm 1/2-mers, downstream arm 1/2-mers
 struct SvrLayout {
     int rinv, lg10, rows, pf, tb, it;          // SV-independent: reciprocals, log10(0..101); then the buffers
+    int ent_n, ni;                             // window norms (f64, pre-scaled by -gamma*log2 e): arm-window entries [n_ent], inserts [np][ssr]
     // the seven prefix arrays of a PF block (len+1 slots each) are described by svr_arr_len / svr_arr_off / svr_arr_chunk
     // below: plain scalars only, so that the device copy of this struct stays in SGPRs (an indexed member would put it in scratch)
     int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; slots per SV
     int tu, td, tb_stride;                     // TB block: first upstream / downstream slot; slots per SV
     int ssr_p;                                 // IT row pitch in slots (scan-size range rounded up to odd: bank spread)
-    int bytes_desc, bytes_ent, bytes_idx, bytes_sb, bytes_ni, bytes_psum;   // byte offsets: scan descriptors (int), table-entry
-                                               // descriptors (3 x u32), per-slot SV-row indices of the scans (u16), bases (u8),
-                                               // insert-window norms (f32 [np][ssr]), arm-pair sums (u16)
+    int bytes_desc, bytes_ent, bytes_idx, bytes_sb, bytes_psum;   // byte offsets: scan descriptors (int), table-entry
+                                               // descriptors (2 x u32), per-slot SV-row indices of the scans (2 x u16), bases (u8),
+                                               // arm-pair sums (u16)
     int n_ent;                                 // arm-window table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
@@ -195,10 +196,11 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.tb = o; o += group * L.tb_stride;
     L.ssr_p = ssr | 1;
     L.it = o; o += group * np * L.ssr_p;
+    L.ent_n = o; o += L.n_ent;                          // window norms stay in f64: no precision is given away before the exponentials
+    L.ni = o; o += np * ssr;
     int bytes = o * 8;
     L.bytes_desc = bytes; bytes += SVR_N_ARR * 16 * 4;
-    L.bytes_ent = bytes; bytes += 3 * L.n_ent * 4;     // per entry: packed slots, packed fields, f32 window norm
-    L.bytes_ni = bytes; bytes += np * ssr * 4;
+    L.bytes_ent = bytes; bytes += 2 * L.n_ent * 4;     // per entry: packed slots, packed fields
     L.bytes_psum = bytes; bytes += 2 * SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64) + 16;   // + the work counter of the table stage
     bytes = (bytes + 15) & ~15;
     L.bytes_idx = bytes;                               // u32 per slot: byte offsets of the two SV-row slots it gathers

@@ -261,10 +261,15 @@ struct LrcMers {
     int8_t rc[MIPGEN_N_LRC];       // base-4 code of its reverse complement, -1 if palindromic
 };
 
-__global__ __launch_bounds__(256) void k_long_range(const char* __restrict__ seq, int len, int denom, LrcMers M, double* __restrict__ out)
+// one workgroup per region: LDS histogram of the 1/2/3-mers of its extended sequence, then the 44 frequencies
+__global__ __launch_bounds__(256) void k_long_range(const char* __restrict__ seqs, const int64_t* __restrict__ offs, const int32_t* __restrict__ lens,
+                                                    const int32_t* __restrict__ denoms, LrcMers M, double* __restrict__ out_all)
 {
     __shared__ int c1[4], c2[16], c3[64];
     const int tid = threadIdx.x;
+    const char* seq = seqs + offs[blockIdx.x];
+    const int len = lens[blockIdx.x], denom = denoms[blockIdx.x];
+    double* out = out_all + (int64_t)blockIdx.x * MIPGEN_N_LRC;
     if (tid < 4) c1[tid] = 0;
     if (tid < 16) c2[tid] = 0;
     if (tid < 64) c3[tid] = 0;
@@ -293,8 +298,10 @@ __global__ __launch_bounds__(256) void k_long_range(const char* __restrict__ seq
     }
 }
 
-extern "C" hipError_t mipgen_launch_long_range(hipStream_t stream, const char* seq_dev, int len, int denom, const LrcMers* M, double* out_dev)
+extern "C" hipError_t mipgen_launch_long_range(hipStream_t stream, int n, const char* seqs, const int64_t* offs, const int32_t* lens,
+                                               const int32_t* denoms, const LrcMers* M, double* out_dev)
 {
-    hipLaunchKernelGGL(k_long_range, dim3(1), dim3(256), 0, stream, seq_dev, len, denom, *M, out_dev);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_long_range, dim3(n), dim3(256), 0, stream, seqs, offs, lens, denoms, *M, out_dev);
     return hipGetLastError();
 }

@@ -29,8 +29,8 @@ __device__ __forceinline__ int to_int_x86(double v)
 __global__ __launch_bounds__(64) void k_replay_condense(
     int total_pos, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions,
     const int32_t* __restrict__ pos_region, const int32_t* __restrict__ pos_local, const double* __restrict__ scores,
-    const uint64_t* __restrict__ records, uint8_t* __restrict__ emitted, mipgen_survivor* __restrict__ survivors,
-    unsigned long long* __restrict__ emitted_per_region)
+    const uint64_t* __restrict__ records, const int32_t* __restrict__ copy, int64_t cand_base, uint8_t* __restrict__ emitted,
+    mipgen_survivor* __restrict__ survivors, unsigned long long* __restrict__ emitted_per_region)
 {
     const int gp = blockIdx.x * blockDim.x + threadIdx.x;
     if (gp >= total_pos) return;
@@ -82,10 +82,23 @@ __global__ __launch_bounds__(64) void k_replay_condense(
             const int64_t idx = base + ((j / A) * 2 + s) * A + (j % A);              // j = (size, pair) in generation order
             if (!emitted[idx]) continue;
             const uint64_t r = records[idx];
-            const int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+            int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+            const int a = (int)(j % A);
+            if (ext_copy == 65535 || lig_copy == 65535) {
+                // the record's 16-bit fields saturate; the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,1692,1709):
+                // fetch the true values from the copy table
+                const int e = P->arm_ext[a], l = P->arm_lig[a];
+                const int C = P->max_capture - (R.k0 + (int)(j / A)) * P->inc, p = R.first_pos + pi, ss = C - e - l;
+                const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
+                const int se = P->len_slot[e], sl = P->len_slot[l];
+                const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
+                if (R.copy_off >= 0) {
+                    ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
+                    lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
+                }
+            }
             if ((int64_t)ext_copy * lig_copy > P->max_arm_copy_product) continue;     // :1689
             if (MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING) continue;                  // :1690
-            const int a = (int)(j % A);
             const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
             const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / (double)(P->arm_lig[a] + P->arm_ext[a]);
             const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
@@ -111,19 +124,19 @@ __global__ __launch_bounds__(64) void k_replay_condense(
             }
         }
         mipgen_survivor out;
-        out.cand_index = best_idx; out.score = best_score; out.record = best_rec;
+        out.cand_index = best_idx < 0 ? -1 : best_idx + cand_base; out.score = best_score; out.record = best_rec;
         survivors[2 * (int64_t)gp + s] = out;
     }
 }
 
 extern "C" hipError_t mipgen_launch_replay_condense(
     hipStream_t stream, int n_regions, int total_pos, const DevParams* P, const DevRegion* regions, const int32_t* pos_region,
-    const int32_t* pos_local, const double* scores, const uint64_t* records, uint8_t* emitted, mipgen_survivor* survivors,
-    unsigned long long* emitted_per_region)
+    const int32_t* pos_local, const double* scores, const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
+    mipgen_survivor* survivors, unsigned long long* emitted_per_region)
 {
     (void)n_regions;
     if (total_pos <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_replay_condense, dim3((total_pos + 63) / 64), dim3(64), 0, stream, total_pos, P, regions, pos_region,
-                       pos_local, scores, records, emitted, survivors, emitted_per_region);
+                       pos_local, scores, records, copy, cand_base, emitted, survivors, emitted_per_region);
     return hipGetLastError();
 }

@@ -1,0 +1,437 @@
+// design.cpp — libmipgen_host.so: the C ABI of include/mipgen_host.h over the host front end, and the accelerated tile_regions
+// driver (one libmipgen_accel handle per GPU, sequential selection stage on the calling thread).
+// Reference: /root/reference/mipgen.cpp:2021-2037 main, :293-400 query_sequences, :403-556 tile_regions.
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+#include "../../include/mipgen_host.h"
+#include "mipgen_host.hpp"
+
+using namespace mipgen;
+
+namespace {
+
+thread_local char g_err[768] = "";
+thread_local int g_circumstance = 0;
+
+int fail(int code, int circumstance, const std::string& msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg.c_str());
+    g_circumstance = circumstance;
+    return code;
+}
+
+struct FnRescorer : Rescorer {
+    mipgen_rescore_fn fn = nullptr;
+    void* ctx = nullptr;
+    int region = 0;
+    double svr(const Cand& c) override
+    {
+        mipgen_candidate mc = {region, c.scan_start, c.capture, c.ext_len, c.lig_len, c.strand};
+        return fn(ctx, region, &mc);
+    }
+};
+
+}  // namespace
+
+struct mipgen_design {
+    Options o;
+    std::vector<Region> regions;
+    Tables tables;
+    Outputs out;
+    std::unique_ptr<Selector> selector;
+    std::string model_path;
+    int next_region = 0;
+    bool closed = false;
+};
+
+extern "C" {
+
+const char* mipgen_host_last_error(void) { return g_err; }
+int mipgen_host_last_circumstance(void) { return g_circumstance; }
+
+int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
+{
+    if (!out_d || argc < 1 || !argv) return fail(MIPGEN_HOST_E_USAGE, 1, "null argument");
+    *out_d = nullptr;
+    g_err[0] = 0; g_circumstance = 0;
+    std::unique_ptr<mipgen_design> d(new mipgen_design());
+    try {
+        Options& o = d->o;
+        const std::string status = parse_command_line(argc, const_cast<char**>(argv), o);
+        if (!status.empty()) return fail(MIPGEN_HOST_E_USAGE, 1, status);
+        if (std::system(o.arg("-bwa").c_str()) != 256) { std::cerr << "load bwa" << std::endl; throw 2; }            // mipgen.cpp:146-151
+        if (o.arg("-trf") != "off" && std::system(o.arg("-trf").c_str()) != 65280) { std::cerr << "TRF directory invalid" << std::endl; throw 3; }
+        finalize_options(o);
+        d->model_path = o.file_dir + "mipgen_svr.model";                                                              // mipgen.cpp:409
+        Outputs& out = d->out;
+        out.progress.open(o.project_name + ".progress.txt");
+        if (!out.progress.is_open()) { std::cerr << "progress file could not be opened" << std::endl; throw 5; }
+        out.progress << "mipgen (MI355X accelerated hot path; libmipgen_accel ABI " << mipgen_accel_abi_version() << ")\n";
+        for (auto& kv : o.args) out.progress << kv.first << " " << kv.second << std::endl;
+        // ---- query_sequences ---------------------------------------------------------------------------------
+        d->regions = load_regions(o);
+        if (d->regions.empty()) { std::cerr << "[mipgen] region file could not be opened" << std::endl; throw 6; }
+        out.progress << "successfully loaded features for mip design; retrieving chromosomal sequence\n";
+        std::cerr << "[mipgen] features loaded; retrieving chromosomal sequence\n";
+        if (o.has("-genome_dir")) { if (!load_sequences_from_genome_dir(o, d->regions)) { std::cerr << "[mipgen] chromosome fasta not acquired" << std::endl; throw 7; } }
+        else if (!load_sequences_from_indexed_fasta(o, d->regions)) { std::cerr << "[mipgen] chromosome fasta not acquired" << std::endl; throw 9; }
+        if (!load_masks(o, d->regions)) std::cerr << "[mipgen] masked chromosome fasta not acquired; no repetitive bases?" << std::endl;
+        out.progress << "successfully acquired chromosomal data for mip design; accessing snp file ...\n";
+        std::cerr << "[mipgen] regions ready; accessing snp file\n";
+        load_snps(o, d->regions, d->tables);
+        out.progress << "all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
+        std::cerr << "[mipgen] all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
+        const std::string copy_status = check_copy_numbers(o, d->regions, d->tables);
+        if (copy_status.empty()) { std::cerr << "error with copy number analysis" << std::endl; throw 11; }
+        out.progress << copy_status;
+        find_copy(o, d->tables);
+        out.progress << "bwa copy number analysis finished\n";
+        std::cerr << "[mipgen] bwa copy number analysis finished\n";
+        open_outputs(o, out);
+        for (Region& r : d->regions) attach_tables(o, d->tables, r);
+        d->selector.reset(new Selector(d->o, d->tables, d->out));
+    } catch (int e) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);                             // mipgen.cpp:2029-2032
+        return fail(e == 1 ? MIPGEN_HOST_E_USAGE : MIPGEN_HOST_E_INPUT, e, msg);
+    } catch (std::exception& e) {
+        return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
+    }
+    *out_d = d.release();
+    return 0;
+}
+
+int mipgen_design_close(mipgen_design* d)
+{
+    if (!d) return 0;
+    if (!d->closed) {
+        Outputs& out = d->out;
+        const Options& o = d->o;
+        out.all.close(); out.collapsed.close(); out.picked.close(); out.snp.close();
+        out.progress << "mip picking complete:\n" << o.project_name << ".picked_mips.txt\n and \n" << o.project_name << ".snps_mips.txt\n";
+        std::cerr << "[mipgen] mip picking complete:\n" << o.project_name << ".picked_mips.txt\n and \n" << o.project_name << ".snp_mips.txt\n";
+        if (out.bad_design_count > 0) {
+            out.progress << "WARNING: There are " << out.bad_design_count << " gaps in covering supplied regions\n";
+            std::cerr << "[mipgen] WARNING: There are " << out.bad_design_count << " gaps in covering supplied regions\n";
+        }
+        out.progress.close();
+    }
+    delete d;
+    return 0;
+}
+
+int mipgen_design_params(const mipgen_design* d, mipgen_params* out)
+{
+    if (!d || !out) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
+    try { *out = d->o.accel_params(); } catch (std::exception& e) { return fail(MIPGEN_HOST_E_USAGE, 0, e.what()); }
+    return 0;
+}
+int32_t mipgen_design_score_method(const mipgen_design* d) { return d ? d->o.score_method : -1; }
+int32_t mipgen_design_silent(const mipgen_design* d) { return d && d->o.silent ? 1 : 0; }
+const char* mipgen_design_model_path(const mipgen_design* d) { return d ? d->model_path.c_str() : ""; }
+int32_t mipgen_design_region_count(const mipgen_design* d) { return d ? (int32_t)d->regions.size() : 0; }
+
+int mipgen_design_region(const mipgen_design* d, int32_t i, mipgen_region* out)
+{
+    if (!d || !out || i < 0 || i >= (int32_t)d->regions.size()) return fail(MIPGEN_HOST_E_USAGE, 0, "region index out of range");
+    fill_accel_region(d->regions[(size_t)i], *out);
+    return 0;
+}
+
+int mipgen_design_long_range_seq(const mipgen_design* d, int32_t i, const char** seq, int32_t* len)
+{
+    if (!d || !seq || !len || i < 0 || i >= (int32_t)d->regions.size()) return fail(MIPGEN_HOST_E_USAGE, 0, "region index out of range");
+    *seq = d->regions[(size_t)i].long_range_seq.data();
+    *len = (int32_t)d->regions[(size_t)i].long_range_seq.size();
+    return 0;
+}
+
+int mipgen_design_set_long_range_content(mipgen_design* d, int32_t i, const double* lrc44)
+{
+    if (!d || !lrc44 || i < 0 || i >= (int32_t)d->regions.size()) return fail(MIPGEN_HOST_E_USAGE, 0, "region index out of range");
+    memcpy(d->regions[(size_t)i].lrc, lrc44, sizeof(double) * MIPGEN_N_LRC);
+    return 0;
+}
+
+int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors, int64_t emitted,
+                                const double* scores, const uint64_t* records, const uint8_t* emitted_mask, mipgen_rescore_fn rescore, void* ctx)
+{
+    if (!d || !grid || (!survivors && grid->n_pos > 0)) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
+    if (i != d->next_region) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "regions are selected in order: expected region %d, got %d", d->next_region, i);
+        return fail(MIPGEN_HOST_E_ORDER, 0, msg);
+    }
+    if (i >= (int32_t)d->regions.size()) return fail(MIPGEN_HOST_E_USAGE, 0, "region index out of range");
+    const Options& o = d->o;
+    const Region& r = d->regions[(size_t)i];
+    Outputs& out = d->out;
+    try {
+        out.progress << "designing all mips for feature #" << i + 1 << std::endl;
+        std::cerr << "[mipgen] feature #" << i + 1 << std::endl;
+        if (!o.silent && scores && records && emitted_mask) {
+            // the reference's generation order: position, size, pair, plus then minus (mipgen.cpp:421-491)
+            const int64_t An = (int64_t)o.arm_pairs.size();
+            std::string buf;
+            for (int64_t row = 0; row < (int64_t)grid->n_pos * grid->n_sizes; row++)
+                for (int64_t a = 0; a < An; a++)
+                    for (int s = 0; s < 2; s++) {
+                        const int64_t k = (row * 2 + s) * An + a;
+                        if (!emitted_mask[k]) continue;
+                        out.all_counter++;
+                        const Cand c = make_cand(o, r, *grid, k, scores[k], records[k]);
+                        buf += format_record(o, r, d->tables, c, out.all_counter, false);
+                        if (buf.size() > (1u << 20)) { out.all << buf; buf.clear(); }
+                    }
+            out.all << buf;
+        } else out.all_counter += (int)emitted;
+        out.progress << "condensing feature #" << i + 1 << "\ncollapsing feature #" << i + 1 << std::endl;
+        std::vector<mipgen_survivor> rs(survivors, survivors + 2 * (size_t)grid->n_pos);
+        for (auto& s : rs) if (s.cand_index >= 0) s.cand_index -= grid->offset;       // region-local for make_cand
+        const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;   // mixed scans with logistic (:467)
+        const double lower = method == MIPGEN_SCORE_SVR ? o.svr_priority : o.logistic_priority;
+        const double upper = method == MIPGEN_SCORE_SVR ? o.svr_optimal : o.logistic_optimal;
+        FnRescorer rs_fn;
+        rs_fn.fn = rescore; rs_fn.ctx = ctx; rs_fn.region = i;
+        if (o.score_method == MIPGEN_SCORE_MIXED && !rescore) return fail(MIPGEN_HOST_E_USAGE, 0, "a mixed design needs the SVR re-score hook");
+        d->selector->run_region(r, *grid, rs, o.score_method == MIPGEN_SCORE_MIXED ? &rs_fn : nullptr, lower, upper);
+    } catch (int e) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);
+        return fail(MIPGEN_HOST_E_INPUT, e, msg);
+    } catch (std::exception& e) {
+        return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
+    }
+    d->next_region = i + 1;
+    return 0;
+}
+
+int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps)
+{
+    if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
+    if (all_mips) *all_mips = d->out.all_counter;
+    if (collapsed) *collapsed = d->out.collapsed_counter;
+    if (picked) *picked = d->out.picked_counter;
+    if (gaps) *gaps = d->out.bad_design_count;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- tile_regions on the accelerator ---------------------------------------------------------------------------------------------
+namespace {
+
+struct WindowResult {
+    int r0 = 0, r1 = 0;                          // design-wide region range of the window
+    std::vector<mipgen_grid> grids;              // one per region; offsets relative to the window's first candidate
+    std::vector<int64_t> emitted;
+    std::vector<mipgen_survivor> surv;           // cand_index relative to the window's first candidate
+    std::vector<double> svr;                     // mixed designs: SVR score of every survivor (parallel to surv; NaN where none)
+    std::vector<double> scores;
+    std::vector<uint64_t> records;
+    std::vector<uint8_t> mask;
+    bool last = false;
+    int error = 0;
+    std::string msg;
+};
+
+struct Channel {                                 // worker -> consumer, at most two windows in flight per device
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<WindowResult>> q;
+    bool abort = false;
+    void push(std::unique_ptr<WindowResult> r)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return q.size() < 2 || abort; });
+        q.push_back(std::move(r));
+        cv.notify_all();
+    }
+    std::unique_ptr<WindowResult> pop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !q.empty(); });
+        auto r = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return r;
+    }
+    void stop() { std::lock_guard<std::mutex> lk(m); abort = true; cv.notify_all(); }
+};
+
+struct SurvivorRescorer {                        // the SVR scores the worker computed for every survivor of the region
+    const WindowResult* w = nullptr;
+    int64_t pos0 = 0;
+    const mipgen_grid* g = nullptr;
+    static double fn(void* ctx, int32_t, const mipgen_candidate* c)
+    {
+        auto* self = (SurvivorRescorer*)ctx;
+        const int64_t k = 2 * (self->pos0 + (c->scan_start - self->g->first_pos)) + c->strand;
+        if (c->scan_start < self->g->first_pos || c->scan_start >= self->g->first_pos + self->g->n_pos || self->w->surv[(size_t)k].cand_index < 0) {
+            std::cerr << "[mipgen] re-score of a candidate that did not survive condense" << std::endl;
+            throw 20;
+        }
+        return self->w->svr[(size_t)k];
+    }
+};
+
+void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch)
+{
+    auto fail_out = [&](int code, const std::string& msg) {
+        std::unique_ptr<WindowResult> r(new WindowResult());
+        r->error = code; r->msg = msg; r->last = true;
+        ch->push(std::move(r));
+    };
+    const Options& o = d->o;
+    mipgen_accel* h = nullptr;
+    mipgen_params ap;
+    try { ap = o.accel_params(); } catch (std::exception& e) { fail_out(17, e.what()); return; }
+    if (mipgen_accel_create(&ap, device, nullptr, &h)) { fail_out(17, mipgen_accel_last_error()); return; }
+    auto bail = [&](int code) { std::string m = mipgen_accel_last_error(); mipgen_accel_destroy(h); fail_out(code, m); };
+    if (o.score_method != MIPGEN_SCORE_LOGISTIC && mipgen_accel_load_model_file(h, d->model_path.c_str())) { bail(18); return; }
+    const int n = r1 - r0;
+    if (o.score_method != MIPGEN_SCORE_LOGISTIC) {                                                                   // mipgen.cpp:1171,1224
+        std::vector<const char*> seqs((size_t)n);
+        std::vector<int32_t> lens((size_t)n), starts((size_t)n), stops((size_t)n);
+        std::vector<double> lrc((size_t)n * MIPGEN_N_LRC);
+        for (int i = 0; i < n; i++) {
+            const Region& r = d->regions[(size_t)(r0 + i)];
+            seqs[(size_t)i] = r.long_range_seq.data(); lens[(size_t)i] = (int32_t)r.long_range_seq.size();
+            starts[(size_t)i] = r.seq_start; stops[(size_t)i] = r.seq_stop;
+        }
+        if (mipgen_accel_long_range_content_batch(h, n, seqs.data(), lens.data(), starts.data(), stops.data(), lrc.data())) { bail(19); return; }
+        for (int i = 0; i < n; i++) memcpy(d->regions[(size_t)(r0 + i)].lrc, &lrc[(size_t)i * MIPGEN_N_LRC], sizeof(double) * MIPGEN_N_LRC);
+    }
+    std::vector<mipgen_region> batch((size_t)n);
+    for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)(r0 + i)], batch[(size_t)i]);
+    std::vector<mipgen_grid> grids((size_t)n);
+    // silent designs keep only survivors, so a window may fill the HBM; otherwise its dense results come to the host (17 B per candidate)
+    mipgen_accel_set_window_candidates(h, o.silent ? 0 : (int64_t)64 << 20);
+    if (const char* e = std::getenv("MIPGEN_WINDOW_CANDIDATES")) mipgen_accel_set_window_candidates(h, std::max<int64_t>(1, std::atoll(e)));   // tests force several windows
+    if (mipgen_accel_upload_regions(h, batch.data(), n, grids.data())) { bail(19); return; }
+    const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;               // mixed scans with logistic (:467)
+    const int nw = mipgen_accel_window_count(h);
+    for (int w = 0; w < nw; w++) {
+        int32_t wr0 = 0, wn = 0;
+        int64_t c0 = 0, nc = 0, p0 = 0, np = 0;
+        mipgen_accel_window_info(h, w, &wr0, &wn, &c0, &nc, &p0, &np);
+        std::unique_ptr<WindowResult> res(new WindowResult());
+        res->r0 = r0 + wr0; res->r1 = r0 + wr0 + wn; res->last = w == nw - 1;
+        res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
+        for (auto& g : res->grids) g.offset -= c0;
+        res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np));
+        if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
+        if (!o.silent) {
+            res->scores.resize((size_t)nc); res->records.resize((size_t)nc); res->mask.resize((size_t)nc);
+            if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
+        }
+        if (mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), o.silent ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
+        for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
+        if (o.score_method == MIPGEN_SCORE_MIXED) {
+            // every survivor of the window through the SVR in one call (the pick stage re-scores a subset of them, mipgen.cpp:1523-1527,1873-1877)
+            std::vector<mipgen_candidate> cands;
+            std::vector<size_t> where;
+            int64_t q0 = 0;
+            for (int bi = 0; bi < wn; bi++) {
+                const mipgen_grid& g = res->grids[(size_t)bi];
+                for (int64_t q = 2 * q0; q < 2 * (q0 + g.n_pos); q++) {
+                    const mipgen_survivor& sv = res->surv[(size_t)q];
+                    if (sv.cand_index < 0) continue;
+                    const Cand c = make_cand(o, d->regions[(size_t)(res->r0 + bi)], g, sv.cand_index - g.offset, sv.score, sv.record);
+                    cands.push_back(mipgen_candidate{wr0 + bi, c.scan_start, c.capture, c.ext_len, c.lig_len, c.strand});
+                    where.push_back((size_t)q);
+                }
+                q0 += g.n_pos;
+            }
+            res->svr.assign(res->surv.size(), std::numeric_limits<double>::quiet_NaN());
+            std::vector<double> sc(cands.size());
+            if (!cands.empty() && mipgen_accel_score_candidates(h, cands.data(), (int32_t)cands.size(), MIPGEN_SCORE_SVR, sc.data(), nullptr, nullptr, nullptr)) { bail(20); return; }
+            for (size_t k = 0; k < cands.size(); k++) res->svr[where[k]] = sc[k];
+        }
+        ch->push(std::move(res));
+    }
+    mipgen_accel_destroy(h);
+}
+
+}  // namespace
+
+extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
+{
+    if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
+    const int visible = mipgen_accel_device_count();
+    if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
+    if (n_devices <= 0) {
+        n_devices = visible;
+        if (const char* e = std::getenv("MIPGEN_GPUS")) n_devices = std::max(1, std::atoi(e));
+    }
+    const int n = (int)d->regions.size();
+    n_devices = std::max(1, std::min(n_devices, n));
+    // contiguous region ranges balanced by dense-grid size (the reference's region order is the order of the selection stage)
+    std::vector<int64_t> weight((size_t)n);
+    int64_t total = 0;
+    {
+        const Options& o = d->o;
+        const int64_t A = (int64_t)o.arm_pairs.size(), K = (o.max_capture - o.min_capture) / o.capture_increment + 1;
+        for (int i = 0; i < n; i++) {
+            const Region& r = d->regions[(size_t)i];
+            weight[(size_t)i] = (int64_t)(r.stop_fl - r.start_fl + o.max_capture) * K * A * 2;
+            total += weight[(size_t)i];
+        }
+    }
+    std::vector<std::pair<int, int>> shard;
+    {
+        int lo = 0;
+        int64_t acc = 0;
+        for (int k = 0; k < n_devices; k++) {
+            const int64_t target = total * (k + 1) / n_devices;
+            int hi = lo;
+            while (hi < n && (acc + weight[(size_t)hi] <= target || hi == lo) && (n - hi) > (n_devices - 1 - k)) { acc += weight[(size_t)hi]; hi++; }
+            if (k == n_devices - 1) hi = n;
+            shard.push_back({lo, hi});
+            lo = hi;
+        }
+    }
+    std::vector<std::unique_ptr<Channel>> chans;
+    std::vector<std::thread> threads;
+    for (int k = 0; k < n_devices; k++) {
+        chans.emplace_back(new Channel());
+        threads.emplace_back(worker, d, k % visible, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get());
+    }
+    int rc = 0;
+    for (int k = 0; k < n_devices && rc == 0; k++) {
+        for (;;) {
+            std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
+            if (w->error) { rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
+            int64_t pos0 = 0;
+            for (int bi = 0; bi < w->r1 - w->r0 && rc == 0; bi++) {
+                const mipgen_grid& g = w->grids[(size_t)bi];
+                SurvivorRescorer rs;
+                rs.w = w.get(); rs.pos0 = pos0; rs.g = &g;
+                const bool dense = !w->scores.empty();
+                try {
+                    rc = mipgen_design_select_region(d, w->r0 + bi, &g, w->surv.data() + 2 * pos0, w->emitted[(size_t)bi],
+                                                     dense ? w->scores.data() + g.offset : nullptr, dense ? w->records.data() + g.offset : nullptr,
+                                                     dense ? w->mask.data() + g.offset : nullptr,
+                                                     d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
+                } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
+                pos0 += g.n_pos;
+            }
+            if (w->last || rc) break;
+        }
+    }
+    for (auto& c : chans) c->stop();
+    if (rc) for (auto& c : chans) { std::lock_guard<std::mutex> lk(c->m); c->q.clear(); }
+    for (auto& t : threads) t.join();
+    return rc;
+}

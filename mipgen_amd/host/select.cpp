@@ -17,7 +17,6 @@ namespace mipgen {
 
 Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t li, double score, uint64_t rec)
 {
-    (void)r;
     Cand c;
     const int A = (int)o.arm_pairs.size();
     // strand-major dense order: li = (((pi * n_sizes) + ki) * 2 + strand) * A + a   (include/mipgen_accel.h)
@@ -39,6 +38,15 @@ Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t 
         c.lig_start = c.scan_start - c.lig_len; c.lig_stop = c.scan_start - 1;
     }
     c.ext_copy = (int)MIPGEN_REC_EXT_COPY(rec); c.lig_copy = (int)MIPGEN_REC_LIG_COPY(rec);
+    // the record's 16-bit copy fields saturate; bwa's X0 count does not (mipgen.cpp:586-587): a saturated field is read from the
+    // region's own copy table, so printed and compared copies are the reference's
+    auto true_copy = [&](int start, int len) -> int {
+        if ((size_t)len >= r.copy_ptr.size() || !r.copy_ptr[(size_t)len]) return 65535;
+        const long rel = (long)start - r.seq_start;
+        return rel >= 0 && rel < (long)r.seq.size() ? r.copy_ptr[(size_t)len][rel] : 0;
+    };
+    if (c.ext_copy == 65535) c.ext_copy = true_copy(c.ext_start, c.ext_len);
+    if (c.lig_copy == 65535) c.lig_copy = true_copy(c.lig_start, c.lig_len);
     c.snp_count = (int)MIPGEN_REC_SNP_COUNT(rec);
     c.masked = (double)MIPGEN_REC_MASKED_N(rec) / (double)(c.lig_len + c.ext_len);  // mipgen.cpp:610
     c.score = score;

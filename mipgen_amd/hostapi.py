@@ -1,0 +1,140 @@
+"""ctypes binding of include/mipgen_host.h (libmipgen_host.so: options + input stage + selection stage of the drop-in front end).
+
+Plumbing for tests and bench.py: with it the torch.distributed harness can end where the reference does - rank 0 feeds the gathered
+survivors through the sequential pick stage and writes picked_mips.txt.  The host library is C++ (mipgen_amd/host/); nothing is
+re-implemented here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmipgen_host.so")
+
+RESCORE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32, C.POINTER(capi.Candidate))
+
+EXPORTED_SYMBOLS = [
+    "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
+    "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region",
+    "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region", "mipgen_design_counters",
+    "mipgen_design_run",
+]
+
+_lib = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HostError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    capi.load_library()                                   # libmipgen_accel.so first (rpath $ORIGIN resolves it as well)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mipgen_host_last_error.restype = C.c_char_p
+    lib.mipgen_design_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp)]
+    lib.mipgen_design_close.argtypes = [vp]
+    lib.mipgen_design_params.argtypes = [vp, C.POINTER(capi.Params)]
+    lib.mipgen_design_score_method.argtypes = [vp]
+    lib.mipgen_design_silent.argtypes = [vp]
+    lib.mipgen_design_model_path.argtypes = [vp]
+    lib.mipgen_design_model_path.restype = C.c_char_p
+    lib.mipgen_design_region_count.argtypes = [vp]
+    lib.mipgen_design_region.argtypes = [vp, C.c_int32, C.POINTER(capi.Region)]
+    lib.mipgen_design_long_range_seq.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
+    lib.mipgen_design_set_long_range_content.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
+    lib.mipgen_design_select_region.argtypes = [vp, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.c_int64, C.POINTER(C.c_double),
+                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), RESCORE_FN, vp]
+    lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
+    lib.mipgen_design_run.argtypes = [vp, C.c_int32]
+    _lib = lib
+    return lib
+
+
+class Design:
+    """A mipgen design opened from a command line: options parsed, input stage done, output files open."""
+
+    def __init__(self, argv: Sequence[str]):
+        self.lib = load_library()
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        self.h = C.c_void_p()
+        rc = self.lib.mipgen_design_open(len(argv), arr, C.byref(self.h))
+        if rc:
+            raise HostError(f"mipgen_design_open: {rc}: {self.lib.mipgen_host_last_error().decode()}")
+        self._keep: List[object] = []
+
+    def _check(self, rc: int) -> None:
+        if rc:
+            raise HostError(f"mipgen_host error {rc}: {self.lib.mipgen_host_last_error().decode()}")
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.mipgen_design_close(self.h)
+            self.h = C.c_void_p()
+
+    def params(self) -> capi.Params:
+        p = capi.Params()
+        self._check(self.lib.mipgen_design_params(self.h, C.byref(p)))
+        return p
+
+    @property
+    def score_method(self) -> int:
+        return int(self.lib.mipgen_design_score_method(self.h))
+
+    @property
+    def silent(self) -> bool:
+        return bool(self.lib.mipgen_design_silent(self.h))
+
+    @property
+    def model_path(self) -> str:
+        return self.lib.mipgen_design_model_path(self.h).decode()
+
+    def region_count(self) -> int:
+        return int(self.lib.mipgen_design_region_count(self.h))
+
+    def region(self, i: int) -> capi.Region:
+        """The C view of region i (pointers into the design's host arrays; valid until close)."""
+        r = capi.Region()
+        self._check(self.lib.mipgen_design_region(self.h, i, C.byref(r)))
+        return r
+
+    def long_range_seq(self, i: int) -> bytes:
+        s, n = C.c_char_p(), C.c_int32()
+        self._check(self.lib.mipgen_design_long_range_seq(self.h, i, C.byref(s), C.byref(n)))
+        return C.string_at(s, n.value) if n.value else b""
+
+    def set_long_range_content(self, i: int, lrc: np.ndarray) -> None:
+        lrc = np.ascontiguousarray(lrc, dtype=np.float64)
+        self._check(self.lib.mipgen_design_set_long_range_content(self.h, i, lrc.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def select_region(self, i: int, grid: capi.Grid, survivors: np.ndarray, emitted: int, scores: Optional[np.ndarray] = None,
+                      records: Optional[np.ndarray] = None, mask: Optional[np.ndarray] = None,
+                      rescore: Optional[Callable[[int, capi.Candidate], float]] = None) -> None:
+        survivors = np.ascontiguousarray(survivors)
+        assert survivors.dtype == capi.SURVIVOR_DTYPE and survivors.shape[0] == 2 * grid.n_pos
+        fn = RESCORE_FN(lambda ctx, region, cand: float(rescore(region, cand.contents))) if rescore else RESCORE_FN()
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.mipgen_design_select_region(
+            self.h, i, C.byref(grid), survivors.ctypes.data_as(C.POINTER(capi.Survivor)), emitted,
+            scores.ctypes.data_as(dp) if scores is not None else None,
+            records.ctypes.data_as(C.POINTER(C.c_uint64)) if records is not None else None,
+            mask.ctypes.data_as(C.POINTER(C.c_uint8)) if mask is not None else None, fn, None))
+
+    def counters(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.mipgen_design_counters(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"all_mips": a.value, "collapsed": b.value, "picked": c.value, "gaps": d.value}
+
+    def run(self, n_devices: int = 0) -> None:
+        self._check(self.lib.mipgen_design_run(self.h, n_devices))

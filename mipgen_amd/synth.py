@@ -280,7 +280,8 @@ def revcomp(s: str) -> str:
 
 
 def synthetic_svr_model(path: str, genome: bytes, n_sv: int, seed: int = 7, gamma: float = 0.05 / 192.0 * 40.0,
-                        rho: float = -1.5, drop_zero_frac: float = 0.2, capture: Tuple[int, int] = (140, 180)) -> None:
+                        rho: float = -1.5, drop_zero_frac: float = 0.2, capture: Tuple[int, int] = (140, 180),
+                        coef_scale: float = 1.0) -> None:
     """Write a libsvm 3.17 text model (epsilon_svr / rbf) whose support vectors are feature vectors of
     random real candidates drawn from `genome`, so that RBF distances are O(1) and the kernel values
     spread over (0,1) (SURVEY.md sections 7.3, 8d).  Values use %.8g as svm_save_model does
@@ -317,7 +318,7 @@ def synthetic_svr_model(path: str, genome: bytes, n_sv: int, seed: int = 7, gamm
             ec = 1 if rng.random() < 0.9 else int(rng.integers(2, 150))
             lc = 1 if rng.random() < 0.9 else int(rng.integers(2, 150))
             x = feature_vector_py(ext, lig, ins, ec, lc, lrc)
-            coef = rng.uniform(-1.0, 1.0)
+            coef = rng.uniform(-1.0, 1.0) * coef_scale
             parts = ["%.16g" % coef]
             for j, val in enumerate(x):
                 if val == 0.0 and rng.random() < drop_zero_frac:

@@ -733,10 +733,15 @@ int mo_condense_region(const mipgen_params* P, const mipgen_region* R, const dou
                 if (!emitted[idx]) continue;
                 if (skip_ahead) continue;                                                     /* :1687 */
                 uint64_t r = records[idx];
-                int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+                int a = (int)(j % A);
+                /* the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,612-613), not the record's saturating
+                 * 16-bit copies: take them from the copy table through the candidate's geometry */
+                int e = P->arm_ext[a], l = P->arm_lig[a];
+                int C = P->max_capture_size - (g.first_size_index + (int)(j / A)) * (P->capture_increment ? P->capture_increment : 1);
+                int p = g.first_pos + pi, ss = C - e - l;
+                int ext_copy = copy_lookup(R, s ? p + ss : p - e, e), lig_copy = copy_lookup(R, s ? p - l : p + ss, l);
                 if ((int64_t)ext_copy * lig_copy > P->max_arm_copy_product) continue;         /* :1689 */
                 if (MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING) continue;                      /* :1690 */
-                int a = (int)(j % A);
                 int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;                     /* :1692 */
                 double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / (P->arm_lig[a] + P->arm_ext[a]);   /* :610,1693 */
                 int snp = (int)MIPGEN_REC_SNP_COUNT(r);

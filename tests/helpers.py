@@ -101,3 +101,80 @@ def normalise_flags(line: bytes) -> bytes:
     if len(f) > 18 and len(f[18]) == 3 and f[18][0:1] == b"1":
         f[18] = f[18][0:2] + b"0"
     return b"\t".join(f)
+
+
+# ---- the drop-in command line on a golden design ------------------------------------------------------------------------------
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+CLI_BIN = os.path.join(ROOT, "mipgen_amd", "mipgen")
+
+
+def prepare_cli_workdir(meta: dict, work: str, fai: bool = False) -> List[str]:
+    """Lay out the inputs of a golden design in `work` and return the mipgen argument vector (argv[0] = work/mipgen, beside which the
+    model is placed: mipgen.cpp:137-138,409).  fai=True: no -genome_dir; the region sequences come from <index>.fai instead."""
+    os.makedirs(os.path.join(work, "genome"), exist_ok=True)
+    genome = golden_genome()
+    synth.write_fasta(os.path.join(work, "genome", "chr1.fa"), "chr1", genome)
+    shutil.copy(os.path.join(meta["dir"], "regions.bed"), os.path.join(work, "regions.bed"))
+    exe = os.path.join(work, "mipgen")
+    if not os.path.lexists(exe):
+        os.symlink(CLI_BIN, exe)
+    if meta["model"]:
+        shutil.copy(os.path.join(GOLDEN, "models", meta["model"]), os.path.join(work, "mipgen_svr.model"))
+    index = os.path.join(work, "genome", "index.fa")
+    argv = [exe, "-regions_to_scan", os.path.join(work, "regions.bed"), "-project_name", "out",
+            "-min_capture_size", str(meta["minC"]), "-max_capture_size", str(meta["maxC"]),
+            "-bwa_genome_index", index, "-bwa", os.path.join(ORACLE_DIR, "fakebwa.sh"), "-score_method", meta["method"],
+            "-feature_flank", str(meta["flank"]), "-tag_sizes", meta["tags"]]
+    if meta.get("arm_lengths"):
+        argv += ["-arm_lengths", meta["arm_lengths"]]
+    else:
+        argv += ["-arm_length_sums", ",".join(map(str, meta["sums"]))]
+    if fai:
+        # a multi-line FASTA with its .fai index (name, length, offset, bases per line, bytes per line), as `samtools faidx` writes it
+        synth.write_fasta(index, "chr1", genome, width=60)
+        with open(index + ".fai", "w") as fh:
+            fh.write(f"chr1\t{len(genome)}\t6\t60\t61\n")
+    else:
+        argv += ["-genome_dir", os.path.join(work, "genome")]
+    if meta["snps"]:
+        shutil.copy(os.path.join(meta["dir"], "snps.vcf"), os.path.join(work, "snps.vcf"))
+        argv += ["-snp_file", os.path.join(work, "snps.vcf"), "-tabix", os.path.join(ORACLE_DIR, "faketabix.sh")]
+    if meta["trf"]:
+        argv += ["-trf", os.path.join(ORACLE_DIR, "faketrf.sh")]
+    argv += list(meta.get("extra", []))
+    return argv
+
+
+def compare_outputs(meta: dict, work: str, keys=("collapsed_mips", "picked_mips", "snp_mips"), check_all: bool = True) -> None:
+    """Output files of a run in `work` against the files the real reference wrote (tests/golden/design_*), byte for byte."""
+    import hashlib
+    for key in keys:
+        got = open(os.path.join(work, f"out.{key}.txt"), "rb").read()
+        ref = gzip.open(os.path.join(meta["dir"], f"ref.{key}.txt.gz"), "rb").read()
+        if got != ref:
+            gl, rl = got.split(b"\n"), ref.split(b"\n")
+            first = next((i for i, (a, b) in enumerate(zip(gl, rl)) if a != b), min(len(gl), len(rl)))
+            raise AssertionError(f"{meta['name']} {key}: first difference at line {first + 1}\n ours: {gl[first][:300] if first < len(gl) else None}\n"
+                                 f" ref : {rl[first][:300] if first < len(rl) else None}\n lines {len(gl)} vs {len(rl)}")
+    for bed in meta.get("gap_files", []):
+        got = open(os.path.join(work, "out." + bed), "rb").read()
+        ref = open(os.path.join(meta["dir"], "ref." + bed), "rb").read()
+        assert got == ref, (meta["name"], bed)
+    if not check_all:
+        return
+    got_all = open(os.path.join(work, "out.all_mips.txt"), "rb").read()
+    assert got_all.count(b"\n") == meta["lines"]["all_mips"], (got_all.count(b"\n"), meta["lines"]["all_mips"])
+    if os.path.exists(os.path.join(meta["dir"], "ref.all_mips.txt.gz")):
+        ref_all = gzip.open(os.path.join(meta["dir"], "ref.all_mips.txt.gz"), "rb").read()
+        g = got_all.split(b"\n")
+        r = [normalise_flags(l) for l in ref_all.split(b"\n")]        # uninitialised masking byte of the reference, see normalise_flags
+        bad = [i for i, (a, b) in enumerate(zip(g, r)) if a != b]
+        assert not bad, (meta["name"], "all_mips first diff line", bad[0] + 1, g[bad[0]][:200], r[bad[0]][:200])
+    elif meta["sha256"].get("all_mips_normalised"):
+        norm = b"\n".join(normalise_flags(l) for l in got_all.split(b"\n"))
+        assert hashlib.sha256(norm).hexdigest() == meta["sha256"]["all_mips_normalised"]
+    else:
+        assert hashlib.sha256(got_all).hexdigest() == meta["sha256"]["all_mips"]

@@ -330,23 +330,132 @@ def test_arm_pair_counts(genome, n_pairs):
     acc.close()
 
 
-@pytest.mark.parametrize("deg", ["8", "10"])
-def test_exp2_degree_variants(genome, monkeypatch, deg):
-    """The table stage's exp2 polynomial is degree 8 or 10 depending on sum|coef| (chosen when the model is set); both
-    instantiations are forced here and checked on every dense-grid candidate of a golden design."""
-    monkeypatch.setenv("MIPGEN_ACCEL_EXP_DEG", deg)
+def test_sv_split_variants(genome):
+    """A dense SVR launch may be cut along the support-vector list (work unit = tile x SV part; partial sums added in part order by
+    k_svr_finish).  Every split agrees with the oracle within 1e-5 and with the unsplit launch to rounding; a given split is bitwise
+    reproducible."""
     meta = H.load_design("svr_small")
     P = H.design_params(meta)
     regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
-    mp = _model_path(meta)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_200.model")
     acc = capi.Accel(P)
     acc.load_model_file(mp)
     om = po.Model(mp)
-    grids, scores, records = acc.score_regions(regions, capi.SCORE_SVR)
-    for rd, g in zip(regions, grids):
-        og, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
-        ok, mx = _close(scores[g.offset:g.offset + g.count], os_)
-        assert ok.all(), (deg, mx)
+    ref = None
+    for split in (1, 2, 3, 5):
+        acc.set_sv_split(split)
+        grids, scores, records = acc.score_regions(regions, capi.SCORE_SVR)
+        _, again, _ = acc.score_regions(regions, capi.SCORE_SVR)
+        assert np.array_equal(scores, again, equal_nan=True)
+        if ref is None:
+            ref = scores
+            for rd, g in zip(regions, grids):
+                _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+                ok, mx = _close(scores[g.offset:g.offset + g.count], os_)
+                assert ok.all(), mx
+                assert np.array_equal(records[g.offset:g.offset + g.count], or_)
+        else:
+            assert np.nanmax(np.abs(scores - ref)) < 1e-11, split
+    acc.close()
+
+
+def test_result_windows(genome):
+    """A batch whose dense results exceed the result arrays is scored window by window (consecutive regions); inputs stay resident.
+    Dense results, replay masks and survivors equal the single-window run; mipgen_accel_score_condense_all leaves the survivors of
+    every window behind."""
+    meta = H.load_design("logistic_default_arms")
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P)
+    acc = capi.Accel(P)
+    grids, s1, r1 = acc.score_regions(regions, capi.SCORE_LOGISTIC)
+    assert acc.window_count() == 1
+    acc.replay_condense()
+    e1, v1, m1 = acc.download_replay()
+    g1, s1c, r1c = acc.score_regions_one_call(regions, capi.SCORE_LOGISTIC, capacity=int(s1.size) + 5)
+    assert np.array_equal(s1, s1c, equal_nan=True) and np.array_equal(r1, r1c)
+    acc.set_window_candidates(int(max(g.count for g in grids)) + 1)              # one region per window
+    grids2, s2, r2 = acc.score_regions(regions, capi.SCORE_LOGISTIC)
+    assert acc.window_count() == len(regions) > 1
+    assert [g.offset for g in grids2] == [g.offset for g in grids]
+    assert np.array_equal(s1, s2, equal_nan=True) and np.array_equal(r1, r2)
+    with pytest.raises(capi.AccelError):
+        acc.score_resident(capi.SCORE_LOGISTIC)                                   # several windows: the caller must say which
+    pos0 = 0
+    for w in range(acc.window_count()):
+        wi = acc.window_info(w)
+        acc.score_window(w, capi.SCORE_LOGISTIC)
+        acc.replay_condense()
+        e, v, m = acc.download_replay(window=w)
+        assert np.array_equal(e, e1[wi["first_region"]:wi["first_region"] + wi["n_regions"]])
+        assert np.array_equal(m, m1[wi["first_candidate"]:wi["first_candidate"] + wi["n_candidates"]])
+        ref = v1[2 * pos0:2 * (pos0 + wi["n_positions"])]
+        for f in ("cand_index", "record"):
+            assert np.array_equal(v[f], ref[f]), (w, f)
+        assert np.array_equal(v["score"], ref["score"], equal_nan=True)
+        pos0 += wi["n_positions"]
+    acc.score_condense_all(capi.SCORE_LOGISTIC)
+    e3, v3 = acc.download_survivors()
+    assert np.array_equal(e3, e1)
+    for f in ("cand_index", "record"):
+        assert np.array_equal(v3[f], v1[f]), f
+    assert np.array_equal(v3["score"], v1["score"], equal_nan=True)
+    acc.close()
+
+
+def test_copy_numbers_beyond_16_bits(genome):
+    """bwa's X0 count is unbounded (mipgen.cpp:586-587); the 64-bit record saturates its copy fields at 65535.  The condense fold compares
+    the true counts (a candidate with copy 70,000 beats one with 80,000 at :1709): the device fetches them from the copy table."""
+    Pc = capi.make_params(152, 162, arm_pairs=[(20, 24), (21, 23), (22, 22)], max_arm_copy_product=2_000_000_000)
+    rd = capi.build_region(genome, "1", 7000, 7080, Pc, bwa_mode="hashed", label="big")
+    rng = np.random.default_rng(21)
+    for ln, tab in rd.copy.items():
+        hit = rng.random(tab.shape[0]) < 0.5
+        tab[hit] = rng.integers(65_000, 90_000, size=int(hit.sum()))
+    rd2 = capi.RegionData(rd.c.start_flanked, rd.c.stop_flanked, rd.c.seq_start, rd.seq, copy=rd.copy, unmappable=rd.unmappable,
+                          chrom="1", label="big", start=rd.start, stop=rd.stop)
+    acc = capi.Accel(Pc)
+    grids, scores, records = acc.score_regions([rd2], capi.SCORE_LOGISTIC)
+    assert (capi.rec_ext_copy(records) == 65535).any()
+    acc.replay_condense()
+    emitted, surv, mask = acc.download_replay()
+    n_emit, omask = po.replay_region(Pc, rd2, scores, records)
+    osurv = po.condense_region(Pc, rd2, scores, records, omask)
+    assert np.array_equal(mask, omask)
+    assert np.array_equal(surv["cand_index"], osurv["cand_index"])
+    assert np.array_equal(surv["record"], osurv["record"])
+    acc.close()
+
+
+def test_long_range_batch(genome):
+    """mipgen_accel_long_range_content_batch: one launch, one workgroup per region; bit-exact against the oracle."""
+    P = capi.make_params(120, 130)
+    acc = capi.Accel(P)
+    rng = np.random.default_rng(8)
+    seqs, starts, stops = [], [], []
+    for _ in range(37):
+        a = int(rng.integers(0, len(genome) - 4000)); ln = int(rng.integers(2100, 3900))
+        seqs.append(genome[a:a + ln]); starts.append(a + 1001); stops.append(a + ln - 1000)
+    got = acc.long_range_content_batch(seqs, starts, stops)
+    for i in range(len(seqs)):
+        assert np.array_equal(got[i], po.long_range_content(seqs[i], starts[i], stops[i]))
+    acc.close()
+
+
+def test_logistic_designs_are_not_bound_by_svr_limits(genome):
+    """More than 240 arm pairs and scan sizes below 3 are limits of the dense SVR kernel only: logistic designs run, SVR requests on
+    such a handle fail with a message (the reference accepts both)."""
+    pairs = [(e, l) for e in range(16, 31) for l in range(14, 31)]          # 255 pairs
+    P = capi.make_params(150, 155, arm_pairs=pairs)
+    acc = capi.Accel(P)
+    rd = capi.build_region(genome, "1", 9000, 9030, P, bwa_mode="hashed", label="many")
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_LOGISTIC)
+    _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_LOGISTIC, None)
+    assert np.array_equal(records, or_)
+    ok, mx = _close(scores, os_)
+    assert ok.all(), mx
+    acc.load_model_file(os.path.join(H.GOLDEN, "models", "svr_syn_64.model"))
+    with pytest.raises(capi.AccelError, match="too many arm pairs"):
+        acc.score_window(0, capi.SCORE_SVR)
     acc.close()
 
 
@@ -366,3 +475,39 @@ def test_tiny_models(genome, tmp_path, n_sv):
     ok, mx = _close(scores[:og.count], os_)
     assert ok.all(), (n_sv, mx)
     acc.close()
+
+
+def test_survivor_array_as_torch_tensor(tmp_path):
+    """The multi-GPU gather sends the library's survivor array straight from HBM: mipgen_accel_survivors_device_ptr wrapped as a torch
+    tensor (no copy) holds the same bytes mipgen_accel_download_survivors returns.  Run as bench.py runs: torch first, then the library
+    (a fresh process; this one has had the HIP runtime initialised by the library alone)."""
+    import subprocess
+    import sys
+    script = tmp_path / "view.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import numpy as np, torch
+torch.cuda.set_device(0)
+from mipgen_amd import capi
+from tests import helpers as H
+meta = H.load_design("logistic_default_arms")
+P = H.design_params(meta)
+regions = H.design_regions(meta, H.golden_genome(), P)
+acc = capi.Accel(P, stream=torch.cuda.current_stream().cuda_stream)
+acc.upload(regions)
+acc.score_condense_all(capi.SCORE_LOGISTIC)
+emitted, surv = acc.download_survivors()
+ptr, n = acc.survivors_device_ptr()
+assert n == surv.shape[0] > 0
+class View:
+    __cuda_array_interface__ = {{"shape": (n * 24,), "typestr": "|u1", "data": (ptr, False), "version": 2}}
+t = torch.as_tensor(View(), device="cuda:0")
+torch.cuda.synchronize()
+got = t.cpu().numpy().view(capi.SURVIVOR_DTYPE)
+assert np.array_equal(got["cand_index"], surv["cand_index"]) and np.array_equal(got["record"], surv["record"])
+acc.close()
+print("view ok")
+""")
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"view ok" in p.stdout, p.stdout.decode()[-2000:]
