@@ -65,7 +65,7 @@ def parse_args():
     ap.add_argument("--sv-split", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the nSV sweep and the logistic line")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the multi-core CPU baseline (0 = all host cores, at most 64)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the multi-core CPU baseline (0 = all host cores, at most 32)")
     return ap.parse_args()
 
 
@@ -171,7 +171,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
     """The reference CPU path (oracle/_ref/mipgen_ref, the real reference compiled -O2 from /root/reference by oracle/Makefile) timed on
     this box: one process alone, then C processes at once (the reference is single-threaded and not re-entrant: multi-core = independent
     processes on BED shards).  Bounded sample of the practice62 / capture 140-180 / SVR workload: regions of
-    ~120-135 bp, where 2-4 capture sizes survive the static skip (~10-25 s of single-core work each)."""
+    ~115-130 bp, where 2-3 capture sizes survive the static skip (~10-20 s of single-core work each)."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
@@ -183,7 +183,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
         cores_avail = len(os.sched_getaffinity(0))
     except AttributeError:
         cores_avail = os.cpu_count() or 1
-    cores = args.cpu_cores or min(cores_avail, 64)
+    cores = args.cpu_cores or min(cores_avail, 32)
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -192,7 +192,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                 break
     except OSError:
         pass
-    pool = sorted(ivs, key=lambda v: abs((v.bed_end - v.bed_start) - 128))[:8]
+    pool = sorted(ivs, key=lambda v: abs((v.bed_end - v.bed_start) - 122))[:8]
     work = tempfile.mkdtemp(prefix="mipgen_cpu_")
 
     def run_one(i: int):
@@ -223,7 +223,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                     "scope": "reference binary end to end per region (enumeration + scoring + its FASTQ / stand-in bwa I/O and selection); "
                              "the GPU figure covers the resident hot path only",
                     "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2), one region each from the "
-                              f"{len(pool)} regions closest to 128 bp ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp; 2-4 capture sizes survive the static skip), "
+                              f"{len(pool)} regions closest to 122 bp ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp; 2-4 capture sizes survive the static skip), "
                               f"{n_all} emitted candidates in {wall:.1f} s wall; alone: {len1}-bp region, {n1} candidates in {t1:.1f} s"}
         # port: the oracle's C restatement (same arithmetic as the reference, no text hop, -O2), one core
         from oracle import pyoracle as po

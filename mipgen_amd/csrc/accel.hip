@@ -32,7 +32,7 @@ hipError_t mipgen_launch_candidates(hipStream_t, int n, const DevParams*, const 
                                     double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
-hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, const DevRegion*,
+hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
                                          const int32_t* pos_region, const int32_t* pos_local, const double* scores,
                                          const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
                                          mipgen_survivor* survivors, unsigned long long* emitted_per_region);
@@ -124,7 +124,7 @@ struct mipgen_accel {
     DevBuf<mipgen_survivor> survivors;
     DevBuf<unsigned long long> emitted_per_region;
     DevBuf<int32_t> pos_region, pos_local;
-    bool replayed = false;
+    bool replayed = false, mask_valid = false;
     // sparse scratch
     DevBuf<mipgen_candidate> cand_in;
     DevBuf<double> cand_scores, cand_feats;
@@ -671,15 +671,19 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method)
     return MIPGEN_OK;
 }
 
-static int replay_window_impl(mipgen_accel* h)
+static int replay_window_impl(mipgen_accel* h, bool want_mask)
 {
     const int w = h->cur_window;
     const Window& W = h->windows[(size_t)w];
     // asynchronous on the handle's stream; buffers and the position map were laid out at upload
     if (W.r1 > W.r0) HIP_TRY(hipMemsetAsync(h->emitted_per_region.p + W.r0, 0, (size_t)(W.r1 - W.r0) * sizeof(unsigned long long), h->stream));
-    if (W.n_cand) HIP_TRY(hipMemsetAsync(h->emitted.p, 0, (size_t)W.n_cand, h->stream));
-    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)W.n_pos, h->dp, h->regions.p, h->pos_region.p + W.pos0, h->pos_local.p + W.pos0,
-                                          h->scores.p, h->records.p, h->copy.p, W.cand0, h->emitted.p, h->survivors.p + 2 * W.pos0, h->emitted_per_region.p));
+    // the per-candidate emitted flags are only materialised for callers that fetch them (the all_mips file); the fold itself keeps
+    // them as lane masks in LDS
+    if (want_mask && W.n_cand) HIP_TRY(hipMemsetAsync(h->emitted.p, 0, (size_t)W.n_cand, h->stream));
+    HIP_TRY(mipgen_launch_replay_condense(h->stream, h->n_regions, (int)W.n_pos, h->dp, h->hp.n_pairs, h->hp.n_sizes_all, h->regions.p, h->pos_region.p + W.pos0,
+                                          h->pos_local.p + W.pos0, h->scores.p, h->records.p, h->copy.p, W.cand0, want_mask ? h->emitted.p : nullptr,
+                                          h->survivors.p + 2 * W.pos0, h->emitted_per_region.p));
+    h->mask_valid = want_mask;
     if (h->timing && h->ev.size() >= 4 * ((size_t)w + 1)) { HIP_TRY(hipEventRecord(h->ev[4 * (size_t)w + 3], h->stream)); h->ev_used[(size_t)w] |= 2; }
     h->replayed = true;
     return MIPGEN_OK;
@@ -718,7 +722,7 @@ int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
     std::fill(h->ev_used.begin(), h->ev_used.end(), 0);
     for (int w = 0; w < (int)h->windows.size(); w++) {
         if (int rc = score_window_impl(h, w, method)) return rc;
-        if (int rc = replay_window_impl(h)) return rc;
+        if (int rc = replay_window_impl(h, false)) return rc;
     }
     return MIPGEN_OK;
 }
@@ -844,7 +848,7 @@ int mipgen_accel_replay_condense(mipgen_accel* h)
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
     if (!h->scored || h->cur_window < 0) return fail(MIPGEN_E_STATE, "replay requested before scoring");
     HIP_TRY(hipSetDevice(h->device));
-    return replay_window_impl(h);
+    return replay_window_impl(h, true);
 }
 
 int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity,
@@ -862,6 +866,7 @@ int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, m
         if (W.n_pos) HIP_TRY(hipMemcpy(survivors, h->survivors.p + 2 * W.pos0, (size_t)(2 * W.n_pos) * sizeof(mipgen_survivor), hipMemcpyDeviceToHost));
     }
     if (emitted_mask) {
+        if (!h->mask_valid) return fail(MIPGEN_E_STATE, "the emitted mask is only kept by mipgen_accel_replay_condense, not by mipgen_accel_score_condense_all");
         if (mask_capacity < W.n_cand) return fail(MIPGEN_E_INVALID, "mask capacity too small");
         if (W.n_cand) HIP_TRY(hipMemcpy(emitted_mask, h->emitted.p, (size_t)W.n_cand, hipMemcpyDeviceToHost));
     }

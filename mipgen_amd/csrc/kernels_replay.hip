@@ -5,15 +5,26 @@
 //   mipgen::condense_mips              /root/reference/mipgen.cpp:1670-1746
 //
 // Both are sequential state machines, but only *within* one scan-start position: every position is independent
-// (previous_best_score is reset at :426; the condense state is declared per position at :1677-1680).  One lane
-// therefore replays one position end to end: it walks the position's (capture size, arm pair) rows in
-// generation order, marks the candidates the reference would have constructed, then folds the two strands'
-// newest-first lists into the (position, strand) survivors that collapse/pick consume.  This removes the
-// device-to-host copy of the dense grid (16 B/candidate) for silent designs: 2 survivors per position remain.
+// (previous_best_score is reset at :426; the condense state is declared per position at :1677-1680).  One WAVEFRONT replays one
+// position; its lanes are the arm pairs of one (capture size, strand) row, so every load is a coalesced row segment:
+//
+//   replay    per capture size the row's plus / minus scores and valid flags are loaded once; the arm-sum lists of the row are then
+//             walked with wave-level bit operations (ballot / count-leading-zeros on 64-bit lane masks): the only sequential state
+//             is previous_best_score between lists, `previous_*_score` / skip_ahead inside a list - a list costs a handful of scalar
+//             instructions, not one step per pair.  The emitted flags of the position stay in LDS as lane masks.
+//   condense  the fold over the newest-first candidate list changes its state only when a candidate is TAKEN, which is rare (a
+//             record-breaking event).  All lanes evaluate the take rules against the current state at once; the first taker in fold
+//             order is applied (v_readlane), the lanes after it are re-evaluated against the new state.  A row costs 1 + (number of
+//             takes) wave iterations instead of one step per candidate, and the fold ends early exactly where the reference's does
+//             (skip_ahead, :1736).
+//
+// This removes the device-to-host copy of the dense grid (16 B/candidate) for silent designs: 2 survivors per position remain.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include "common.h"
 #include "device_utils.h"
+
+#define REPLAY_WAVES 4
 
 namespace {
 
@@ -24,16 +35,30 @@ __device__ __forceinline__ int to_int_x86(double v)
     return (int)v;
 }
 
+__device__ __forceinline__ double readlane_d(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t x, int l)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+}
+__device__ __forceinline__ int top_bit(uint64_t m) { return 63 - __builtin_clzll(m); }      // m != 0
+
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_replay_condense(
-    int total_pos, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions,
+__global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense(
+    int total_pos, int n_chunks, int lds_pitch, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions,
     const int32_t* __restrict__ pos_region, const int32_t* __restrict__ pos_local, const double* __restrict__ scores,
     const uint64_t* __restrict__ records, const int32_t* __restrict__ copy, int64_t cand_base, uint8_t* __restrict__ emitted,
     mipgen_survivor* __restrict__ survivors, unsigned long long* __restrict__ emitted_per_region)
 {
-    const int gp = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ uint64_t s_masks[];                                  // [wave][size index][chunk of 64 pairs]: emitted lanes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gp = blockIdx.x * REPLAY_WAVES + wave;
     if (gp >= total_pos) return;
+    uint64_t* emask = s_masks + (size_t)wave * lds_pitch;
     const int ri = pos_region[gp], pi = pos_local[gp];
     const DevRegion& R = regions[ri];
     const int A = P->n_pairs, nK = R.n_sizes;
@@ -41,102 +66,158 @@ __global__ __launch_bounds__(64) void k_replay_condense(
     const int64_t base = R.out_off + (int64_t)pi * per_pos;
     const double upper = P->upper, lower = P->lower;
     const bool heuristic = P->score_method == MIPGEN_SCORE_LOGISTIC && P->logistic_heuristic;
+    const int min_sum = P->min_sum;
+    const uint64_t lane_bit = 1ull << lane, below_me = lane_bit - 1;
 
     // ---- replay, mipgen.cpp:426-497 ---------------------------------------------------------------------
     unsigned long long n_emitted = 0;
-    double previous_best_score = 0.0;
+    double pbs = 0.0;                                                        // previous_best_score (:426)
     for (int ki = 0; ki < nK; ki++) {
-        if (previous_best_score > upper) continue;                                   // :430
-        int a = 0;
-        while (a < A) {
-            const int a_end = P->group_end[a];
-            const int sum = P->arm_ext[a] + P->arm_lig[a];
-            if (previous_best_score > upper && sum != P->min_sum) { a = a_end; continue; }      // :434
-            int previous_minus_score = 0, previous_plus_score = 0;
-            bool skip_ahead = false;
-            for (; a < a_end; a++) {
-                if (skip_ahead) continue;                                            // :440
-                const int64_t idx = base + ((int64_t)ki * 2) * A + a, idm = idx + A;     // strand-major rows
-                if (!(MIPGEN_REC_FLAGS(records[idx]) & MIPGEN_FLAG_VALID)) continue; // :443-444
-                emitted[idx] = 1; emitted[idm] = 1;
-                n_emitted += 2;
-                const double plus = scores[idx], minus = scores[idm];
-                if (heuristic && plus < (double)previous_plus_score && minus < (double)previous_minus_score) skip_ahead = true;   // :494
-                previous_best_score = (minus > plus) ? minus : plus;                 // :495
-                previous_minus_score = to_int_x86(minus);                            // :496
-                previous_plus_score = to_int_x86(plus);                              // :497
+        if (lane < n_chunks) emask[ki * n_chunks + lane] = 0;
+        if (pbs > upper) continue;                                           // :430
+        int prev_plus = 0, prev_minus = 0;                                   // previous_plus_score / previous_minus_score (:435-436)
+        bool skip_ahead = false, list_skipped = false;
+        int list_end = 0;                                                    // end of the arm-sum list in progress
+        for (int c = 0; c < n_chunks; c++) {
+            const int a = c * 64 + lane;
+            const bool in = a < A;
+            const int64_t idx = base + ((int64_t)ki * 2) * A + a;
+            const double plus = in ? scores[idx] : 0.0, minus = in ? scores[idx + A] : 0.0;
+            const bool valid = in && (MIPGEN_REC_FLAGS(records[idx]) & MIPGEN_FLAG_VALID);       // :443-444
+            const uint64_t vmask_all = __ballot(valid);
+            uint64_t emit_chunk = 0;
+            const int c_end = min(A, c * 64 + 64);
+            int a0 = c * 64;
+            while (a0 < c_end) {
+                if (a0 == list_end) {                                        // a new arm-sum list starts here (:431-436)
+                    list_end = P->group_end[a0];
+                    list_skipped = pbs > upper && (P->arm_ext[a0] + P->arm_lig[a0]) != min_sum;   // :434
+                    prev_plus = 0; prev_minus = 0; skip_ahead = false;
+                }
+                const int a1 = min(list_end, c_end);
+                if (!list_skipped && !skip_ahead) {
+                    const int lo = a0 - c * 64, hi = a1 - c * 64;            // lanes [lo, hi)
+                    const uint64_t seg = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & ~((1ull << lo) - 1);
+                    const uint64_t vmask = vmask_all & seg;
+                    if (vmask) {
+                        uint64_t emit = vmask;
+                        if (heuristic) {
+                            // the pair before me in this list that was constructed: its truncated scores are what :494 compares against
+                            const uint64_t below = vmask & below_me;
+                            const int src = below ? top_bit(below) : lane;
+                            const double pp = __shfl(plus, src, 64), pm = __shfl(minus, src, 64);
+                            const int ip = below ? to_int_x86(pp) : prev_plus, im = below ? to_int_x86(pm) : prev_minus;
+                            const bool cond = (vmask & lane_bit) && plus < (double)ip && minus < (double)im;      // :494
+                            const uint64_t cmask = __ballot(cond);
+                            if (cmask) { emit = vmask & ((2ull << __builtin_ctzll(cmask)) - 1); skip_ahead = true; }   // that pair is still constructed
+                        }
+                        const int last = top_bit(emit);
+                        const double lp = readlane_d(plus, last), lm = readlane_d(minus, last);
+                        pbs = (lm > lp) ? lm : lp;                           // :495
+                        prev_minus = to_int_x86(lm); prev_plus = to_int_x86(lp);                                  // :496-497
+                        emit_chunk |= emit;
+                        n_emitted += 2ull * (unsigned)__builtin_popcountll(emit);
+                    }
+                }
+                a0 = a1;
+            }
+            if (emit_chunk) {
+                if (lane == 0) emask[ki * n_chunks + c] = emit_chunk;
+                if (emitted && (emit_chunk & lane_bit)) { emitted[idx] = 1; emitted[idx + A] = 1; }
             }
         }
     }
-    if (n_emitted) atomicAdd(&emitted_per_region[ri], n_emitted);
+    if (n_emitted && lane == 0) atomicAdd(&emitted_per_region[ri], n_emitted);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the lane masks written above are read by every lane below
+    __builtin_amdgcn_wave_barrier();
 
     // ---- condense, mipgen.cpp:1670-1746 -------------------------------------------------------------------
+    const int target_copy = P->target_arm_copy;
+    const int64_t max_product = P->max_arm_copy_product;
+    const double thr = P->masked_arm_threshold;
     int chosen_copy = 0;
     double chosen_masked = 0.0;                                                      // per position, not per strand (:1677-1680)
     for (int s = 0; s < 2; s++) {
         int64_t best_idx = -1;
         double best_score = 0.0;
         uint64_t best_rec = 0;
-        bool skip_ahead = false;
-        for (int64_t j = per_pos / 2 - 1; j >= 0 && !skip_ahead; j--) {              // newest first (push_front, :475,489)
-            const int64_t idx = base + ((j / A) * 2 + s) * A + (j % A);              // j = (size, pair) in generation order
-            if (!emitted[idx]) continue;
-            const uint64_t r = records[idx];
-            int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
-            const int a = (int)(j % A);
-            if (ext_copy == 65535 || lig_copy == 65535) {
-                // the record's 16-bit fields saturate; the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,1692,1709):
-                // fetch the true values from the copy table
-                const int e = P->arm_ext[a], l = P->arm_lig[a];
-                const int C = P->max_capture - (R.k0 + (int)(j / A)) * P->inc, p = R.first_pos + pi, ss = C - e - l;
-                const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
-                const int se = P->len_slot[e], sl = P->len_slot[l];
-                const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
-                if (R.copy_off >= 0) {
+        int best_snp = 0;
+        bool stop = false;
+        for (int ki = nK - 1; ki >= 0 && !stop; ki--) {                              // newest first (push_front, :475,489)
+            for (int c = n_chunks - 1; c >= 0 && !stop; c--) {
+                const uint64_t em = emask[ki * n_chunks + c];
+                if (!em) continue;
+                const int a = c * 64 + lane;
+                const bool mine = (em & lane_bit) != 0;
+                const int64_t idx = base + ((int64_t)ki * 2 + s) * A + a;
+                const uint64_t r = mine ? records[idx] : 0;
+                const double sc = mine ? scores[idx] : 0.0;
+                int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+                const int e = mine ? P->arm_ext[a] : 1, l = mine ? P->arm_lig[a] : 1;
+                if (mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0) {
+                    // the record's 16-bit fields saturate; the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,1692,1709):
+                    // fetch the true values from the copy table
+                    const int C = P->max_capture - (R.k0 + ki) * P->inc, p = R.first_pos + pi, ss = C - e - l;
+                    const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
+                    const int se = P->len_slot[e], sl = P->len_slot[l];
+                    const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
                     ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
                     lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
                 }
-            }
-            if ((int64_t)ext_copy * lig_copy > P->max_arm_copy_product) continue;     // :1689
-            if (MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING) continue;                  // :1690
-            const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
-            const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / (double)(P->arm_lig[a] + P->arm_ext[a]);
-            const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
-            const double sc = scores[idx];
-            bool take = false, update_chosen = true;
-            if (best_idx < 0) take = true;                                                                    // :1695
-            else if (cur_masked > P->masked_arm_threshold && cur_masked < chosen_masked) take = true;         // :1701
-            else if (cur_copy > P->target_arm_copy && cur_copy < chosen_copy) take = true;                    // :1709
-            else if (cur_copy <= P->target_arm_copy) {
-                if (sc < lower && sc > best_score) take = true;                                               // :1717
-                else if (sc > lower) {
-                    const int bsnp = (int)MIPGEN_REC_SNP_COUNT(best_rec);
-                    if (snp < bsnp) take = true;                                                              // :1725
-                    else if (snp == bsnp && sc > best_score) {                                                // :1731-1737
-                        take = true; update_chosen = false;
-                        if (sc > upper) skip_ahead = true;
+                const bool ok = mine && !((int64_t)ext_copy * lig_copy > max_product) && !(MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING);   // :1689-1690
+                const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
+                const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / (double)(l + e);
+                const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
+                uint64_t pending = __ballot(ok);
+                while (pending) {
+                    // every pending lane evaluates the take rules against the current state; the first taker in fold order (highest pair
+                    // index first) is applied, the lanes after it are re-evaluated
+                    bool take = false, update_chosen = true, stops = false;
+                    if (best_idx < 0) take = true;                                                                    // :1695
+                    else if (cur_masked > thr && cur_masked < chosen_masked) take = true;                             // :1701
+                    else if (cur_copy > target_copy && cur_copy < chosen_copy) take = true;                           // :1709
+                    else if (cur_copy <= target_copy) {
+                        if (sc < lower && sc > best_score) take = true;                                               // :1717
+                        else if (sc > lower) {
+                            if (snp < best_snp) take = true;                                                          // :1725
+                            else if (snp == best_snp && sc > best_score) { take = true; update_chosen = false; stops = sc > upper; }   // :1731-1737
+                        }
                     }
+                    const uint64_t tmask = __ballot(take) & pending;
+                    if (!tmask) break;
+                    const int f = top_bit(tmask);
+                    best_idx = base + ((int64_t)ki * 2 + s) * A + (c * 64 + f);
+                    best_score = readlane_d(sc, f);
+                    best_rec = readlane_u64(r, f);
+                    best_snp = (int)MIPGEN_REC_SNP_COUNT(best_rec);
+                    if (__builtin_amdgcn_readlane((int)update_chosen, f)) {
+                        chosen_masked = readlane_d(cur_masked, f);
+                        chosen_copy = __builtin_amdgcn_readlane(cur_copy, f);
+                    }
+                    if (__builtin_amdgcn_readlane((int)stops, f)) { stop = true; break; }
+                    pending &= (1ull << f) - 1;
                 }
             }
-            if (take) {
-                best_idx = idx; best_score = sc; best_rec = r;
-                if (update_chosen) { chosen_masked = cur_masked; chosen_copy = cur_copy; }
-            }
         }
-        mipgen_survivor out;
-        out.cand_index = best_idx < 0 ? -1 : best_idx + cand_base; out.score = best_score; out.record = best_rec;
-        survivors[2 * (int64_t)gp + s] = out;
+        if (lane == 0) {
+            mipgen_survivor out;
+            out.cand_index = best_idx < 0 ? -1 : best_idx + cand_base; out.score = best_score; out.record = best_rec;
+            survivors[2 * (int64_t)gp + s] = out;
+        }
     }
 }
 
 extern "C" hipError_t mipgen_launch_replay_condense(
-    hipStream_t stream, int n_regions, int total_pos, const DevParams* P, const DevRegion* regions, const int32_t* pos_region,
-    const int32_t* pos_local, const double* scores, const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
-    mipgen_survivor* survivors, unsigned long long* emitted_per_region)
+    hipStream_t stream, int n_regions, int total_pos, const DevParams* P, int n_pairs, int n_sizes_max, const DevRegion* regions,
+    const int32_t* pos_region, const int32_t* pos_local, const double* scores, const uint64_t* records, const int32_t* copy, int64_t cand_base,
+    uint8_t* emitted, mipgen_survivor* survivors, unsigned long long* emitted_per_region)
 {
     (void)n_regions;
     if (total_pos <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_replay_condense, dim3((total_pos + 63) / 64), dim3(64), 0, stream, total_pos, P, regions, pos_region,
-                       pos_local, scores, records, copy, cand_base, emitted, survivors, emitted_per_region);
+    const int n_chunks = (n_pairs + 63) / 64;
+    const int pitch = n_sizes_max * n_chunks;
+    const size_t lds = (size_t)REPLAY_WAVES * pitch * sizeof(uint64_t);
+    hipLaunchKernelGGL(k_replay_condense, dim3((total_pos + REPLAY_WAVES - 1) / REPLAY_WAVES), dim3(REPLAY_WAVES * 64), lds, stream, total_pos,
+                       n_chunks, pitch, P, regions, pos_region, pos_local, scores, records, copy, cand_base, emitted, survivors, emitted_per_region);
     return hipGetLastError();
 }
