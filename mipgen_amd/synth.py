@@ -93,6 +93,8 @@ def shim_copy(start: np.ndarray, length: int, mode: str = "unique") -> np.ndarra
     start = np.asarray(start, dtype=np.int64)
     if mode == "unique":
         return np.ones_like(start, dtype=np.int32)
+    if mode == "blocks":
+        return np.where(((start % 3000) >= 1200) & ((start % 3000) < 1500), 500, 1).astype(np.int32)
     h = (start * 7919 + length * 104729) % 1000
     copy = np.ones_like(start, dtype=np.int64)
     copy = np.where((h >= 940) & (h < 970), 2 + (h % 19), copy)
@@ -106,7 +108,7 @@ def shim_copy(start: np.ndarray, length: int, mode: str = "unique") -> np.ndarra
 def shim_unmappable(pos: np.ndarray, size: int, mode: str = "unique") -> np.ndarray:
     """True where the fakebwa stand-in reports the capture window (size, pos) as non-unique."""
     pos = np.asarray(pos, dtype=np.int64)
-    if mode == "unique":
+    if mode in ("unique", "blocks"):
         return np.zeros(pos.shape, dtype=bool)
     return ((pos * 31 + size * 17) % 211) == 0
 

@@ -12,7 +12,8 @@
 # (mipgen_amd/synth.py: shim_copy / shim_unmappable) can rebuild the same tables:
 #   arm oligo  "chr<c>:<start>-<stop>"  -> copy = f(start, stop-start+1)
 #   capture    "<size>_<c>_<pos>"       -> unique unless g(pos,size) == 0
-# FAKEBWA_MODE=unique (default) gives copy 1 / always mappable; FAKEBWA_MODE=hashed varies them.
+# FAKEBWA_MODE=unique (default) gives copy 1 / always mappable; FAKEBWA_MODE=hashed varies them;
+# FAKEBWA_MODE=blocks puts a 300-base zone of copy-500 oligos into every 3000 bases.
 if [ $# -eq 0 ]; then exit 1; fi
 case "$1" in
   aln) exit 0 ;;
@@ -37,6 +38,11 @@ case "$1" in
             else if (h < 995) copy = 101 + (h % 400)
             else if (h < 998) tag = 0
             else copy = 0
+          }
+          if (mode == "blocks") {
+            # dead zones: every oligo starting in [1200, 1500) of each 3000-base block is highly repetitive (no MIP can be placed
+            # there: the copy product exceeds -max_arm_copy_product, so the pick stage has to open gaps)
+            if ((start % 3000) >= 1200 && (start % 3000) < 1500) copy = 500
           }
           if (tag) printf "%s\t0\tsynthetic\t1\t37\t%dM\t*\t0\t0\t*\t*\tXT:A:U\tX0:i:%d\tX1:i:0\n", name, len, copy
           else     printf "%s\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n", name

@@ -121,7 +121,38 @@ DESIGNS = [
 ]
 
 
-def gen_design(genome: bytes, d: dict) -> None:
+# Designs on the second golden genome (80 kb): longer regions, every selection-stage option, gaps, >= 10 regions on one chromosome.
+# `extra` goes to the reference's command line verbatim; all_mips is kept as a sha256 of the normalised lines (tests/helpers.py).
+DESIGNS2 = [
+    dict(name="gaps_blocks", method="logistic", ivs=[("1", 6000, 8600, "long"), ("1", 12000, 12300, "b"), ("1", 13150, 13420, "c")], minC=152, maxC=162,
+         sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="blocks", model=None, extra=[]),
+    dict(name="double_tile_unaware", method="logistic", ivs=[("1", 20000, 20900, "a"), ("1", 22000, 22400, "b")], minC=152, maxC=162,
+         sums=[40, 42, 44], flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model=None, extra=["-double_tile_strand_unaware", "on"]),
+    dict(name="double_tile_separately", method="logistic", ivs=[("1", 24000, 24700, "a"), ("1", 25500, 25800, "b")], minC=152, maxC=162,
+         sums=[41, 43, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model=None, extra=["-double_tile_strands_separately", "on"]),
+    dict(name="seal_both", method="logistic", ivs=[("1", 28000, 28800, "a")], minC=140, maxC=150, sums=[40, 41, 42], flank=0, tags="5,0", snps=True,
+         trf=False, bwa="hashed", model=None, extra=["-seal_both_strands", "on", "-starting_mip_overlap", "5"]),
+    dict(name="half_seal_overlap", method="logistic", ivs=[("1", 30000, 30750, "a"), ("1", 31500, 31650, "b")], minC=140, maxC=150, sums=[40, 41, 42], flank=0,
+         tags="5,0", snps=False, trf=True, bwa="hashed", model=None,
+         extra=["-half_seal_both_strands", "on", "-max_mip_overlap", "40", "-starting_mip_overlap", "10", "-masked_arm_threshold", "0.2"]),
+    dict(name="arm_lengths_unsorted", method="logistic", ivs=[("1", 34000, 34500, "a"), ("1", 35000, 35120, "b")], minC=150, maxC=160, sums=None,
+         arm_lengths="20:22,16:24,25:20,18:27,22:20,30:18,17:25", flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model=None, extra=[]),
+    dict(name="heuristic_off_copy_off", method="logistic", ivs=[("1", 38000, 38600, "a"), ("1", 39400, 39520, "b")], minC=152, maxC=162, sums=[40, 41, 42, 43, 44, 45],
+         flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model=None, extra=["-logistic_heuristic", "off", "-check_copy_number", "off"]),
+    dict(name="mixed_12_regions", method="mixed", ivs=[("1", 42000 + 700 * i, 42000 + 700 * i + 60 + 13 * i, f"m{i}") for i in range(12)], minC=125, maxC=135,
+         sums=[42, 43], flank=0, tags="5,0", snps=True, trf=False, bwa="hashed", model="svr_syn_64.model", extra=[]),
+    dict(name="svr_2kb", method="svr", ivs=[("1", 54000, 56000, "s")], minC=130, maxC=140, sums=[44, 45], flank=10, tags="4,4", snps=False, trf=False,
+         bwa="hashed", model="svr_syn_64.model", extra=[]),
+    dict(name="merge_flank_tags", method="logistic", ivs=[("1", 60000, 60100, "x"), ("1", 60160, 60300, "y"), ("1", 61000, 61090, "z")], minC=152, maxC=162,
+         sums=[40, 41, 42, 43, 44, 45], flank=20, tags="0,8", snps=True, trf=True, bwa="hashed", model=None, extra=["-capture_increment", "2"]),
+    dict(name="long_default", method="logistic", ivs=[("1", 64000, 67600, "big"), ("1", 69000, 69200, "small")], minC=120, maxC=160,
+         sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-capture_increment", "10"]),
+    dict(name="double_tile_both", method="logistic", ivs=[("1", 72000, 72600, "a")], minC=152, maxC=162, sums=[42, 44], flank=0, tags="5,0", snps=False,
+         trf=False, bwa="hashed", model=None, extra=["-double_tile_strand_unaware", "on", "-double_tile_strands_separately", "on"]),
+]
+
+
+def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -> None:
     out = os.path.join(HERE, "design_" + d["name"])
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
@@ -132,10 +163,15 @@ def gen_design(genome: bytes, d: dict) -> None:
     ivs = [synth.Interval(*iv) for iv in d["ivs"]]
     synth.write_bed(w + "/regions.bed", ivs)
     shutil.copy(w + "/regions.bed", out + "/regions.bed")
-    extra = ["-arm_length_sums", ",".join(map(str, d["sums"])), "-feature_flank", str(d["flank"]), "-tag_sizes", d["tags"]]
+    extra = ["-feature_flank", str(d["flank"]), "-tag_sizes", d["tags"]]
+    extra += ["-arm_lengths", d["arm_lengths"]] if d.get("arm_lengths") else ["-arm_length_sums", ",".join(map(str, d["sums"]))]
+    extra += list(d.get("extra", []))
     snp_path = None
     if d["snps"]:
-        snps = synth.random_snps("1", genome, 4000, 10000, seed=13, per_bp=1 / 40.0)
+        lo = min(iv.bed_start for iv in ivs) - 1000
+        hi = max(iv.bed_end for iv in ivs) + 1000
+        snps = synth.random_snps("1", genome, 4000, 10000, seed=13, per_bp=1 / 40.0) if genome_name == "genome_chr1.fa.gz" else \
+            synth.random_snps("1", genome, lo, hi, seed=13, per_bp=1 / 60.0)
         snp_path = w + "/snps.vcf"
         synth.write_vcf(snp_path, snps)
         shutil.copy(snp_path, out + "/snps.vcf")
@@ -145,7 +181,10 @@ def gen_design(genome: bytes, d: dict) -> None:
     assert r["returncode"] == 0, r["stderr"]
     meta = {k: d[k] for k in ("name", "method", "minC", "maxC", "sums", "flank", "tags", "snps", "trf", "bwa", "model")}
     meta["intervals"] = d["ivs"]
-    meta["genome"] = "genome_chr1.fa.gz"
+    meta["genome"] = genome_name
+    if genome_name != "genome_chr1.fa.gz":
+        meta["extra"] = list(d.get("extra", []))
+        meta["arm_lengths"] = d.get("arm_lengths")
     meta["sha256"] = {}
     meta["lines"] = {}
     for key in ("all_mips", "collapsed_mips", "picked_mips", "snp_mips"):
@@ -154,14 +193,22 @@ def gen_design(genome: bytes, d: dict) -> None:
         with open(path, "rb") as fh:
             data = fh.read()
         meta["lines"][key] = data.count(b"\n")
-        if key == "all_mips" and not d["keep_all"]:
+        if key == "all_mips" and not d.get("keep_all", False):
+            if genome_name != "genome_chr1.fa.gz":
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from helpers import normalise_flags
+                meta["sha256"]["all_mips_normalised"] = hashlib.sha256(b"\n".join(normalise_flags(l) for l in data.split(b"\n"))).hexdigest()
             continue
         with gzip.GzipFile(out + f"/ref.{key}.txt.gz", "wb", mtime=0) as gz:
             gz.write(data)
-    for gap in ("coverage_failed.bed",):
+    meta_gaps = []
+    for gap in ("coverage_failed.bed", "double_tile_failed.bed", "minus_strand_failed.bed", "minus_strand_double_tile_failed.bed"):
         p = os.path.join(w, "out." + gap)
         if os.path.exists(p):
             shutil.copy(p, out + "/ref." + gap)
+            meta_gaps.append(gap)
+    if genome_name != "genome_chr1.fa.gz":
+        meta["gap_files"] = meta_gaps
     with open(out + "/meta.json", "w") as fh:
         json.dump(meta, fh, indent=1)
     print("design", d["name"], meta["lines"])
@@ -179,6 +226,15 @@ def main() -> None:
     gen_candidates(genome)
     for d in DESIGNS:
         gen_design(genome, d)
+    genome2 = synth.random_genome(80000, 202, n_run_frac=0.002, n_run_len=8)
+    with gzip.GzipFile(os.path.join(HERE, "genome2_chr1.fa.gz"), "wb", mtime=0) as gz:
+        gz.write(b">chr1\n")
+        for i in range(0, len(genome2), 60):
+            gz.write(genome2[i:i + 60] + b"\n")
+    only = set(sys.argv[1:])
+    for d in DESIGNS2:
+        if not only or d["name"] in only:
+            gen_design(genome2, d, "genome2_chr1.fa.gz")
 
 
 if __name__ == "__main__":

@@ -15,8 +15,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 UNIVERSAL = b"CTTCAGCTTCCCGATATCCGACGGTAGTGT"
 
 
-def golden_genome() -> bytes:
-    with gzip.open(os.path.join(GOLDEN, "genome_chr1.fa.gz"), "rb") as fh:
+def golden_genome(name: str = "genome_chr1.fa.gz") -> bytes:
+    with gzip.open(os.path.join(GOLDEN, name), "rb") as fh:
         return b"".join(l.strip() for l in fh.read().split(b"\n")[1:])
 
 
@@ -115,7 +115,7 @@ def prepare_cli_workdir(meta: dict, work: str, fai: bool = False) -> List[str]:
     """Lay out the inputs of a golden design in `work` and return the mipgen argument vector (argv[0] = work/mipgen, beside which the
     model is placed: mipgen.cpp:137-138,409).  fai=True: no -genome_dir; the region sequences come from <index>.fai instead."""
     os.makedirs(os.path.join(work, "genome"), exist_ok=True)
-    genome = golden_genome()
+    genome = golden_genome(meta.get("genome", "genome_chr1.fa.gz"))
     synth.write_fasta(os.path.join(work, "genome", "chr1.fa"), "chr1", genome)
     shutil.copy(os.path.join(meta["dir"], "regions.bed"), os.path.join(work, "regions.bed"))
     exe = os.path.join(work, "mipgen")

@@ -19,13 +19,23 @@ class RegionView:
         self.alleles = None
 
 
-def open_design(argv: List[str], work: str) -> hostapi.Design:
+import contextlib
+
+
+@contextlib.contextmanager
+def in_dir(work: str):
+    """The front end resolves -project_name, the TRF mask (mipgen.cpp:1051-1054) and the gap files relative to the CWD, as the reference does."""
     cwd = os.getcwd()
-    os.chdir(work)                 # the TRF mask is looked up relative to the CWD (mipgen.cpp:1051-1054); outputs go to <cwd>/out.*
+    os.chdir(work)
     try:
-        return hostapi.Design(argv)
+        yield
     finally:
         os.chdir(cwd)
+
+
+def open_design(argv: List[str], work: str) -> hostapi.Design:
+    with in_dir(work):
+        return hostapi.Design(argv)
 
 
 def design_views(d: hostapi.Design) -> List[RegionView]:

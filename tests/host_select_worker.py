@@ -42,9 +42,10 @@ def main() -> None:
     if rank == 0:
         pos = 0
         rescore = HS.make_rescorer(P, views, model) if d.score_method == capi.SCORE_MIXED else None
-        for i, g in enumerate(grids):
-            d.select_region(i, g, all_surv[2 * pos:2 * (pos + g.n_pos)], int(all_emitted[i]), rescore=rescore)
-            pos += g.n_pos
+        with HS.in_dir(work):
+            for i, g in enumerate(grids):
+                d.select_region(i, g, all_surv[2 * pos:2 * (pos + g.n_pos)], int(all_emitted[i]), rescore=rescore)
+                pos += g.n_pos
         c = d.counters()
         json.dump({"shards": shards, "n_regions": len(grids), "picked": c["picked"], "all_mips": c["all_mips"]}, open(out_path, "w"))
     d.close()

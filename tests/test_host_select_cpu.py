@@ -33,8 +33,6 @@ def test_host_library_exports_every_declared_symbol():
 @pytest.mark.parametrize("name", DESIGNS)
 def test_selection_stage_on_oracle_survivors_matches_reference_files(name, tmp_path):
     meta = H.load_design(name)
-    if meta.get("cpu_seconds", 0) > 60:
-        pytest.skip("oracle dense scoring of this design takes minutes; covered on the GPU (tests/test_gpu_cli.py)")
     work = str(tmp_path)
     argv = H.prepare_cli_workdir(meta, work)
     env_mode = os.environ.get("FAKEBWA_MODE")
@@ -51,9 +49,10 @@ def test_selection_stage_on_oracle_survivors_matches_reference_files(name, tmp_p
     views = HS.design_views(d)
     scan = capi.SCORE_SVR if d.score_method == capi.SCORE_SVR else capi.SCORE_LOGISTIC
     rescore = HS.make_rescorer(P, views, model) if d.score_method == capi.SCORE_MIXED else None
-    for i, v in enumerate(views):
-        r = HS.oracle_region_results(P, v, scan, model)
-        d.select_region(i, r["grid"], r["survivors"], r["emitted"], r["scores"], r["records"], r["mask"], rescore)
+    with HS.in_dir(work):
+        for i, v in enumerate(views):
+            r = HS.oracle_region_results(P, v, scan, model)
+            d.select_region(i, r["grid"], r["survivors"], r["emitted"], r["scores"], r["records"], r["mask"], rescore)
     with pytest.raises(hostapi.HostError):
         d.select_region(0, r["grid"], r["survivors"], r["emitted"])          # out of order
     assert d.counters()["all_mips"] == meta["lines"]["all_mips"] - 1
