@@ -88,6 +88,10 @@ int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* c
  */
 int mipgen_design_run(mipgen_design* d, int32_t n_devices);
 
+/* The selection stage's private copy of glibc's never-seeded rand() stream (mipgen.cpp:1863 picks the first strand with rand() % 2):
+ * its first n values, for checking it against the C library's. */
+int mipgen_host_rand_stream(int32_t* out, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

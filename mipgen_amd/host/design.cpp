@@ -435,3 +435,11 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     for (auto& t : threads) t.join();
     return rc;
 }
+
+// test hook: the first n values of the private rand() stream (compared with libc's in tests/test_host_select_cpu.py)
+extern "C" int mipgen_host_rand_stream(int32_t* out, int32_t n)
+{
+    GlibcRand g;
+    for (int i = 0; i < n; i++) out[i] = g.next();
+    return 0;
+}

@@ -104,6 +104,18 @@ std::string format_record(const Options& o, const Region& r, const Tables& t, co
 // re-scoring hook for -score_method mixed (mipgen.cpp:1523-1527,1873-1877)
 struct Rescorer { virtual double svr(const Cand& c) = 0; virtual ~Rescorer() {} };
 
+// glibc's rand() as a never-seeded process sees it (TYPE_3 additive feedback generator, seed 1): the reference picks the strand it
+// tries first with `rand() % 2` (mipgen.cpp:1863) and never calls srand, so its picks depend on this exact stream.  A private copy
+// keeps the stream out of reach of anything else in the process (device runtime, worker threads) that might call rand().
+class GlibcRand {
+public:
+    GlibcRand();
+    int next();
+private:
+    uint32_t r_[34];
+    int f_ = 3, b_ = 0;
+};
+
 class Selector {
 public:
     Selector(const Options& o, const Tables& t, Outputs& out) : o_(o), t_(t), out_(out) {}
@@ -117,6 +129,7 @@ private:
     std::map<std::string, std::map<int, std::set<int>>> used_;             // chr_strand_pos_used_arm_bases (persists across regions)
     std::map<int, std::map<int, CandPtr>> scan_best_, pos_best_;           // [position][strand 0/1]
     const Region* r_ = nullptr; Rescorer* rs_ = nullptr; double lower_ = 0, upper_ = 0;
+    GlibcRand rand_;
     void collapse();
     void output_collapsed();
     void pick();

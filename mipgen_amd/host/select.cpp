@@ -147,6 +147,33 @@ void open_outputs(const Options& o, Outputs& out)
     out.snp << ">mip_key\t" << (o.score_method == MIPGEN_SCORE_LOGISTIC ? "logistic" : "svr") << k_cols;
 }
 
+// ---- the reference's random stream -------------------------------------------------------------------------
+// glibc random_r.c, TYPE_3 (degree 31, separation 3), as initialised by srandom(1): the state a process that never calls
+// srand() starts from.  r[i] = r[i-31] + r[i-3] (mod 2^32); rand() returns r >> 1.
+GlibcRand::GlibcRand()
+{
+    int32_t st[34];
+    st[0] = 1;
+    for (int i = 1; i < 31; i++) {                       // 16807 * x mod (2^31 - 1), Schrage's method as glibc writes it
+        const long hi = st[i - 1] / 127773, lo = st[i - 1] % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        st[i] = (int32_t)w;
+    }
+    for (int i = 0; i < 31; i++) r_[i] = (uint32_t)st[i];
+    f_ = 3; b_ = 0;
+    for (int i = 0; i < 310; i++) (void)next();          // glibc discards the first 10 * degree outputs
+}
+
+int GlibcRand::next()
+{
+    r_[f_] += r_[b_];
+    const int out = (int)(r_[f_] >> 1);
+    if (++f_ >= 31) f_ = 0;
+    if (++b_ >= 31) b_ = 0;
+    return out;
+}
+
 // ---- selection ---------------------------------------------------------------------------------------------
 
 bool Selector::arm_used(const Cand& c, int strand) const
@@ -259,7 +286,7 @@ Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_
          chosen += dir) {
         int strand_index, iterations;
         if (strand_to_use != -1) { strand_index = 1 - strand_to_use; iterations = 1; }
-        else { strand_index = rand() % 2; iterations = 2; }                       // libc rand(), never seeded (:1863)
+        else { strand_index = rand_.next() % 2; iterations = 2; }                 // the reference's libc rand(), never seeded (:1863)
         for (int i = 0; i < iterations; i++) {
             strand_index = 1 - strand_index;
             auto& slot = scan_best_[chosen];                                       // operator[]: creates the position, as the reference does (:1869)

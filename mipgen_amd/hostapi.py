@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
     "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region",
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region", "mipgen_design_counters",
-    "mipgen_design_run",
+    "mipgen_design_run", "mipgen_host_rand_stream",
 ]
 
 _lib = None
@@ -58,6 +58,7 @@ def load_library():
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), RESCORE_FN, vp]
     lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
+    lib.mipgen_host_rand_stream.argtypes = [C.POINTER(C.c_int32), C.c_int32]
     _lib = lib
     return lib
 

@@ -30,6 +30,18 @@ def test_host_library_exports_every_declared_symbol():
     assert declared == set(hostapi.EXPORTED_SYMBOLS), declared ^ set(hostapi.EXPORTED_SYMBOLS)
 
 
+def test_private_rand_stream_is_glibc_rand():
+    """The reference orders the two strands with a never-seeded libc rand() (mipgen.cpp:1863); the selection stage carries its own copy
+    of that generator (nothing else in the process can advance it): 20,000 values equal a fresh process's rand()."""
+    import ctypes as C
+    n = 20000
+    buf = (C.c_int32 * n)()
+    hostapi.load_library().mipgen_host_rand_stream(buf, n)
+    ref = subprocess.run([sys.executable, "-c", f"import ctypes; l = ctypes.CDLL('libc.so.6'); print(' '.join(str(l.rand()) for _ in range({n})))"],
+                         stdout=subprocess.PIPE, check=True).stdout.split()
+    assert [int(x) for x in ref] == list(buf)
+
+
 @pytest.mark.parametrize("name", DESIGNS)
 def test_selection_stage_on_oracle_survivors_matches_reference_files(name, tmp_path):
     meta = H.load_design(name)
