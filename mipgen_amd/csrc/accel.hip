@@ -539,30 +539,54 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                 span_max = std::max(span_max, t.np + Cmax + Lmax);
             }
             if (!svr_possible) continue;
-            // SVR tiles: capture sizes in nearly equal runs of <= 9 (fewer when the scan-size range would not fit LDS), positions in runs
-            // that fill the block's lanes
-            const int NP_CAP = 32;
-            for (int kc_cap = 9; kc_cap >= 1; kc_cap--) {
-                const size_t st_mark = st.size();
-                size_t lds_r = 0;
+            // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs as long as the tile's LDS allows (more positions
+            // per tile = fewer factor-table entries per candidate and fewer idle candidate lanes).  Every split of the sizes is priced
+            // with the kernel's instruction budget - ~47 VALU per (table entry, SV) against ~2.7 per (candidate, SV) at full lanes -
+            // and the cheapest one is laid out.
+            const int lanes = 64 * h->geom.wpc;
+            struct Run { int ki0, kc, np; };
+            std::vector<Run> best_runs;
+            double best_cost = 0;
+            size_t best_lds = 0;
+            for (int kc_cap = std::min(9, d.n_sizes); kc_cap >= 1; kc_cap--) {
                 const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
-                for (int c = 0; c < nkc; c++) {
+                if (kc_cap < std::min(9, d.n_sizes) && nkc == (d.n_sizes + kc_cap) / (kc_cap + 1)) continue;   // same split as the previous cap
+                std::vector<Run> runs;
+                double ent = 0, slots = 0;
+                size_t lds_r = 0;
+                bool ok = true;
+                for (int c = 0; c < nkc && ok; c++) {
                     const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
                     const int kc = ki1 - ki0;
-                    int np = std::max(1, std::min(NP_CAP, (64 * h->geom.wpc) / kc));
-                    // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping)
-                    { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 8 >= np * 7) np = np_cf; }
                     const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
-                    const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum;
-                    for (int p0 = 0; p0 < d.n_pos; p0 += np) {
-                        const int npt = std::min(np, d.n_pos - p0);
-                        for (int s = 0; s < 2; s++) { SvrTile t = {i, s, p0, npt, ki0, kc}; st.push_back(t); }
+                    const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum, ssr = ssmax - ssmin + 1;
+                    int np = std::max(1, std::min({lanes / kc, 64, d.n_pos}));
+                    size_t lds_t = 0;
+                    for (; np >= 1; np--) {
+                        lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
+                        if (lds_t <= 160 * 1024) break;
                     }
-                    lds_r = std::max(lds_r, mipgen_svr_lds_bytes_tile(np, ssmax - ssmin + 1, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l));
+                    if (np < 1) { ok = false; break; }
+                    // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping):
+                    // taken when it costs few positions
+                    { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 10 >= np * 9) { np = np_cf; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
+                    runs.push_back({ki0, kc, np});
+                    lds_r = std::max(lds_r, lds_t);
+                    const double tiles = std::ceil((double)d.n_pos / np);
+                    ent += tiles * (np * (h->geom.n_e + h->geom.n_l) / 2.0 + (np + ssr - 1) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)np * ssr);
+                    slots += tiles * lanes;
                 }
-                if (lds_r <= 160 * 1024 || kc_cap == 1) { svr_lds = std::max(svr_lds, lds_r); break; }
-                st.resize(st_mark);
+                if (!ok) continue;
+                const double cost = 47.0 * ent + 2.7 * slots * D.n_pairs / 1.0;
+                if (best_runs.empty() || cost < best_cost) { best_runs = runs; best_cost = cost; best_lds = lds_r; }
             }
+            if (best_runs.empty()) { svr_lds = (size_t)1 << 30; continue; }
+            svr_lds = std::max(svr_lds, best_lds);
+            for (const Run& r : best_runs)
+                for (int p0 = 0; p0 < d.n_pos; p0 += r.np) {
+                    const int npt = std::min(r.np, d.n_pos - p0);
+                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); }
+                }
         }
         w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0;
     }

@@ -511,3 +511,50 @@ print("view ok")
 """)
     p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b"view ok" in p.stdout, p.stdout.decode()[-2000:]
+
+
+def test_model_loader_paths(genome, tmp_path):
+    """svm_load_model's grammar (svm.cpp:2779-2962) through mipgen_accel_load_model_file: non-RBF / non-SVR models, unknown header
+    keys and truncated SV lists are errors with a message; nu_svr loads; libsvm indices beyond 192 (x has none: they contribute
+    sv^2 to every distance, svm.cpp:359-363) load and score as the oracle's merge walk does."""
+    base = open(os.path.join(H.GOLDEN, "models", "svr_syn_64.model")).read()
+    P = capi.make_params(130, 140, score_method=capi.SCORE_SVR, arm_pairs=synth.arm_pairs_from_sums([44, 45]))
+    acc = capi.Accel(P)
+
+    def write(name, text):
+        p = tmp_path / name
+        p.write_text(text)
+        return str(p)
+    with pytest.raises(capi.AccelError, match="rbf only"):
+        acc.load_model_file(write("lin.model", base.replace("kernel_type rbf", "kernel_type linear")))
+    with pytest.raises(capi.AccelError, match="SVR only"):
+        acc.load_model_file(write("csvc.model", base.replace("svm_type epsilon_svr", "svm_type c_svc")))
+    with pytest.raises(capi.AccelError, match="unknown text"):
+        acc.load_model_file(write("junk.model", base.replace("nr_class 2", "nr_klass 2")))
+    lines = base.split("\n")
+    with pytest.raises(capi.AccelError, match="SV lines"):
+        acc.load_model_file(write("short.model", "\n".join(lines[:-6]) + "\n"))
+    with pytest.raises(capi.AccelError, match="unknown text"):                # the SV line is missing: the first coefficient is read as a header key (svm.cpp:2893)
+        acc.load_model_file(write("nosv.model", "\n".join(l for l in lines if l.strip() != "SV")[:400]))
+    with pytest.raises(capi.AccelError, match="malformed"):
+        acc.load_model_file(write("badgamma.model", base.replace("gamma 0.0104167", "gamma abc").replace("gamma 0.010416", "gamma abc")))
+    acc.load_model_file(write("nu.model", base.replace("svm_type epsilon_svr", "svm_type nu_svr")))
+    assert acc.model_info()[0] == 64
+    # indices > 192 on a third of the SV lines
+    i_sv = lines.index("SV") + 1
+    ext = lines[:i_sv] + [l.rstrip() + (f" 193:{0.25 + 0.01 * k:.4g} 260:{0.5 - 0.003 * k:.4g} " if k % 3 == 0 and l.strip() else "") for k, l in enumerate(lines[i_sv:])]
+    mp = write("extra.model", "\n".join(ext))
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    rd = capi.build_region(genome, "1", 5000, 5060, P, bwa_mode="hashed", label="x", lrc=np.linspace(0.02, 0.3, 44))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+    ok, mx = _close(scores, os_)
+    assert ok.all(), mx
+    base_acc = capi.Accel(P)
+    base_acc.load_model_file(os.path.join(H.GOLDEN, "models", "svr_syn_64.model"))
+    _, s0, _ = base_acc.score_regions([rd], capi.SCORE_SVR)
+    valid = (capi.rec_flags(records) & capi.FLAG_VALID) != 0
+    assert np.nanmax(np.abs(s0[valid] - scores[valid])) > 1e-6            # the extra indices do change the scores
+    base_acc.close()
+    acc.close()

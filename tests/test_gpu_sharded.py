@@ -1,0 +1,85 @@
+"""GPU: the multi-GPU design flow on one device - the regions of a design sharded over two accelerator handles exactly as
+mipgen_amd/dist.py shards them over ranks, each shard scored + replayed + condensed on its own handle (silent path), the survivors
+concatenated in rank order (what the RCCL gather delivers) and fed through the sequential selection stage of libmipgen_host.so:
+the picked / snp files equal the single-handle run AND the files the real reference wrote."""
+import os
+
+import numpy as np
+import pytest
+
+from mipgen_amd import capi, dist as mdist, hostapi
+from tests import helpers as H
+from tests import host_select_common as HS
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(meta, work, n_shards):
+    os.makedirs(work)
+    os.environ["FAKEBWA_MODE"] = meta["bwa"]
+    d = HS.open_design(H.prepare_cli_workdir(meta, work) + ["-silent_mode", "on"], work)
+    P = d.params()
+    n = d.region_count()
+    scan = capi.SCORE_SVR if d.score_method == capi.SCORE_SVR else capi.SCORE_LOGISTIC
+    # long-range content on the device, through the host library's own region views
+    if d.score_method != capi.SCORE_LOGISTIC:
+        acc0 = capi.Accel(P)
+        views = [d.region(i) for i in range(n)]
+        lrc = acc0.long_range_content_batch([d.long_range_seq(i) for i in range(n)], [v.seq_start for v in views], [v.seq_stop for v in views])
+        for i in range(n):
+            d.set_long_range_content(i, lrc[i])
+        acc0.close()
+    views = [HS.RegionView(d.region(i)) for i in range(n)]
+    probe = capi.Accel(P)
+    weights = [g.count for g in probe.upload(views)]
+    probe.close()
+    shards = mdist.shard_regions(weights, n_shards)
+    surv_parts, emitted_parts, grids = [], [], []
+    handles = []
+    for lo, hi in shards:                                       # one handle per "rank"
+        acc = capi.Accel(P)
+        if d.score_method != capi.SCORE_LOGISTIC:
+            acc.load_model_file(d.model_path)
+        acc.set_sv_split(1)                                     # same summation order whatever the shard size: bitwise comparable
+        g = acc.upload(views[lo:hi])
+        acc.score_condense_all(scan)
+        e, s = acc.download_survivors()
+        for gi in g:
+            gi2 = capi.Grid(); gi2.offset, gi2.count, gi2.first_pos, gi2.n_pos, gi2.first_size_index, gi2.n_sizes = gi.offset, gi.count, gi.first_pos, gi.n_pos, gi.first_size_index, gi.n_sizes
+            grids.append(gi2)
+        surv_parts.append(s); emitted_parts.append(e)
+        handles.append((acc, lo))
+    surv = np.concatenate(surv_parts)
+    emitted = np.concatenate(emitted_parts)
+    model_acc = {lo: acc for acc, lo in handles}
+
+    def rescore(region, cand):                                  # mixed designs: rank 0's local accelerator re-scores
+        k = max(i for i, (lo, hi) in enumerate(shards) if lo <= region)
+        acc, lo = handles[k]
+        s, _, _, _ = acc.score_candidates([(region - lo, cand.scan_start, cand.capture_size, cand.ext_len, cand.lig_len, cand.strand)], capi.SCORE_SVR)
+        return float(s[0])
+    pos = 0
+    with HS.in_dir(work):
+        for i, g in enumerate(grids):
+            d.select_region(i, g, surv[2 * pos:2 * (pos + g.n_pos)], int(emitted[i]), rescore=rescore if d.score_method == capi.SCORE_MIXED else None)
+            pos += g.n_pos
+    c = d.counters()
+    d.close()
+    for acc, _ in handles:
+        acc.close()
+    return surv, emitted, c, shards
+
+
+@pytest.mark.parametrize("name", ["long_default", "mixed_12_regions", "svr_2kb", "double_tile_both"])
+def test_sharded_survivors_through_rank0_pick(name, tmp_path):
+    meta = H.load_design(name)
+    s1, e1, c1, _ = _run(meta, str(tmp_path / "one"), 1)
+    n_sh = 2 if len(meta["intervals"]) > 1 else 1
+    s2, e2, c2, shards = _run(meta, str(tmp_path / "two"), n_sh)
+    assert np.array_equal(e1, e2) and c1 == c2
+    assert np.array_equal(s1["record"], s2["record"])
+    assert np.array_equal(s1["score"], s2["score"], equal_nan=True)          # same kernels, same summation order: bit-identical
+    # candidate indices are batch-wide: compare them per region (the second shard restarts at 0)
+    for w in ("one", "two"):
+        H.compare_outputs(meta, str(tmp_path / w), keys=("picked_mips", "snp_mips"), check_all=False)
+    assert c1["picked"] == meta["lines"]["picked_mips"] - 1 and c1["all_mips"] == meta["lines"]["all_mips"] - 1
