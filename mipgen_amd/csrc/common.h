@@ -129,6 +129,7 @@ struct SvrLayout {
     // the seven prefix arrays of a PF block (len+1 slots each) are described by svr_arr_len / svr_arr_off / svr_arr_chunk
     // below: plain scalars only, so that the device copy of this struct stays in SGPRs (an indexed member would put it in scratch)
     int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; slots per SV
+    int tj, ti;                                // PF block: junction terms [18], insert scan-size terms [ssr] (per SV, like the rest of the block)
     int tu, td, tb_stride;                     // TB block: first upstream / downstream slot; slots per SV
     int ssr_p;                                 // IT row pitch in slots (scan-size range rounded up to odd: bank spread)
     int bytes_desc, bytes_ent, bytes_idx, bytes_sb, bytes_psum;   // byte offsets: scan descriptors (int), table-entry
@@ -179,13 +180,15 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.span_b = np + ssmax + 2 * Lmax + 1;
     L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
     int o = 0;
-    L.rinv = o; o += L.rinv_len;
+    L.rinv = o; o += 4 * L.rinv_len;                    // records of {1/i, 1/(i-1), 1/(i-2), 0}: one ds_read_b128 (+ b64) per table entry
     L.lg10 = o; o += 102 + 44;                          // + the region's 44 long-range frequencies (read per SV by the constants unit)
     L.n_ent = np * n_up + L.nq * n_dn;
     L.rows = o; o += 2 * group * SV_ROW;
     int g = 3 * L.ins_sl + 2 * L.up_sl + 2 * L.dn_sl;                         // the seven prefix arrays
     L.ku = g; g += n_arm; L.kd = g; g += n_arm;
     L.ci = g; g += 1;
+    L.tj = g; g += 18;                                  // junction term of a ligation-arm window: code 0 / 17 -> 0, 1..16 -> the 16 junctions
+    L.ti = g; g += ssr;                                 // (scan size - sv_len)^2 term + the insert-side constants, per scan size
     L.pf_stride = g;
     // the phase-0 scratch (np * 80 u16 counters) aliases the PF area
     int pf_doubles = 2 * group * L.pf_stride;                 // double buffered: scan(k+1) runs beside tables(k)
