@@ -20,6 +20,7 @@
  *   mipgen.cpp:1525-1526,1535-1536,1548-1549,1875-1876  mixed-mode re-score        mipgen_accel_score_candidates()
  *   mipgen.cpp:426-437,494-497  score-dependent early exits (replay)               mipgen_accel_replay_condense()
  *   mipgen.cpp:1670-1746 condense_mips                                             mipgen_accel_replay_condense()
+ *   mipgen.cpp:1616-1649 collapse_mips                                             mipgen_accel_collapse()
  *   mipgen.cpp:412-524   tile_regions in -silent_mode (enumerate + score + condense of    mipgen_accel_score_condense_all()
  *                        every region, nothing kept per candidate)
  *
@@ -240,8 +241,9 @@ int mipgen_accel_result_device_ptrs(const mipgen_accel* h, void** scores_dev, vo
  * candidate indices and must lie inside the window scored last */
 int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* records, int64_t first, int64_t count);
 /* The whole batch the way a -silent_mode design needs it (mipgen.cpp:412-524 without the all_mips / collapsed files): every window is
- * scored, replayed and condensed back to back on the stream; only the survivors (2 per scan position) and the per-region emitted
- * counts are kept.  Asynchronous; fetch with mipgen_accel_download_survivors. */
+ * scored, replayed, condensed and collapsed back to back on the stream; only the survivors (2 per scan position), the per-base
+ * collapse result and the per-region emitted counts are kept.  Asynchronous; fetch with mipgen_accel_download_survivors /
+ * mipgen_accel_download_collapsed. */
 int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method);
 /* upload + score + download in one call: the literal replacement for the loop body of mipgen.cpp:446-497 */
 int mipgen_accel_score_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, int32_t method,
@@ -273,6 +275,16 @@ int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, m
 int mipgen_accel_download_survivors(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity);
 /* device pointer of that survivor array (mipgen_survivor[n_survivors], batch order): the send buffer of the multi-GPU gather */
 int mipgen_accel_survivors_device_ptr(const mipgen_accel* h, void** survivors_dev, int64_t* n_survivors);
+
+/* collapse_mips (mipgen.cpp:1616-1649) on the device, over the survivors of the window replayed last: for every base a survivor's
+ * scan target can cover (bases first_pos .. first_pos + n_bases - 1 of each region, n_bases = n_pos + largest scan size - 1) and each
+ * strand, the scan-start index (0-based from the region's first_pos) of the survivor the reference's fold keeps, or -1.
+ * mipgen_accel_score_condense_all runs it for every window. */
+int mipgen_accel_collapse(mipgen_accel* h);
+/* entries [first_entry, first_entry + 2 * n_bases) of the batch-wide collapsed array belong to `region`: [base][strand] */
+int mipgen_accel_region_bases(const mipgen_accel* h, int32_t region, int64_t* first_entry, int32_t* n_bases);
+/* window >= 0: the entries of that window's regions; window < 0: the whole batch (after mipgen_accel_score_condense_all) */
+int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* best_scan_index, int64_t capacity);
 
 /* ---- tuning ---------------------------------------------------------------------------------------- */
 /* A dense SVR launch with few tiles is split along the support-vector list so that it still fills the chip (partial sums are added

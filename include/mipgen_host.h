@@ -10,7 +10,8 @@
  *       get_masked_features_to_scan :1045-1084, load_snps :875-978,                    output files + headers)
  *       check_copy_numbers :796-873, find_copy :558-596
  *   mipgen::tile_regions per-region tail           mipgen.cpp:503-555             mipgen_design_select_region (all_mips records,
- *       print_details :765-794, collapse_mips :1616-1668, pick_mips :1506-1614,        collapse, pick, SNP re-design, gap files)
+ *       print_details :765-794, collapse_mips :1616-1668, pick_mips :1506-1614,        collapse unless the accelerator did it, pick, SNP
+ *                                                                                       re-design, gap files)
  *       optimize_worst_in_region :1748-1820, translocate_down_region :1822-1908,
  *       manage_picked_mip :1910-1939, print_gaps / create_gap :1231-1278
  *   mipgen::tile_regions as a whole                mipgen.cpp:403-556             mipgen_design_run (drives libmipgen_accel on one
@@ -77,6 +78,11 @@ typedef double (*mipgen_rescore_fn)(void* ctx, int32_t region, const mipgen_cand
 int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors,
                                 int64_t emitted, const double* scores, const uint64_t* records, const uint8_t* emitted_mask,
                                 mipgen_rescore_fn rescore, void* ctx);
+/* The same with collapse_mips already done by the accelerator (mipgen_accel_collapse): collapsed = 2 entries per base, n_bases bases
+ * from grid->first_pos on (mipgen_accel_region_bases), each the scan-start index of the winning survivor of that strand or -1. */
+int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors,
+                                          int64_t emitted, const double* scores, const uint64_t* records, const uint8_t* emitted_mask,
+                                          const int32_t* collapsed, int32_t n_bases, mipgen_rescore_fn rescore, void* ctx);
 /* counters after the regions selected so far: all / collapsed / picked records written, gaps reported */
 int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps);
 

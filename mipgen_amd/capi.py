@@ -284,12 +284,15 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_download_survivors.argtypes = [vp, i64p, C.POINTER(Survivor), C.c_int64]
     lib.mipgen_accel_survivors_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
     lib.mipgen_accel_set_sv_split.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_collapse.argtypes = [vp]
+    lib.mipgen_accel_region_bases.argtypes = [vp, C.c_int32, i64p, i32p]
+    lib.mipgen_accel_download_collapsed.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
     for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "long_range_content_batch"):
+                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -305,7 +308,8 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_download_replay", "mipgen_accel_last_kernel_ms", "mipgen_accel_set_timing",
     "mipgen_accel_set_window_candidates", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
-    "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch",
+    "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
+    "mipgen_accel_download_collapsed",
 ]
 
 
@@ -396,6 +400,28 @@ class Accel:
         self._check(self.lib.mipgen_accel_download_survivors(self.h, emitted.ctypes.data_as(C.POINTER(C.c_int64)),
                                                              surv.ctypes.data_as(C.POINTER(Survivor)), 2 * npos))
         return emitted, surv
+
+    def collapse(self) -> None:
+        self._check(self.lib.mipgen_accel_collapse(self.h))
+
+    def region_bases(self, region: int) -> Tuple[int, int]:
+        fe, nb = C.c_int64(), C.c_int32()
+        self._check(self.lib.mipgen_accel_region_bases(self.h, region, C.byref(fe), C.byref(nb)))
+        return fe.value, nb.value
+
+    def download_collapsed(self, window: int = -1) -> np.ndarray:
+        """collapse_mips result of a window (or of the whole batch, window = -1): 2 entries per base, region after region."""
+        if window < 0:
+            fe, nb = self.region_bases(len(self.grids) - 1) if self.grids else (0, 0)
+            n = fe + 2 * nb
+        else:
+            wi = self.window_info(window)
+            f0, _ = self.region_bases(wi["first_region"])
+            f1, nb = self.region_bases(wi["first_region"] + wi["n_regions"] - 1)
+            n = f1 + 2 * nb - f0
+        out = np.empty(max(n, 1), dtype=np.int32)
+        self._check(self.lib.mipgen_accel_download_collapsed(self.h, window, out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0]))
+        return out[:n]
 
     def survivors_device_ptr(self) -> Tuple[int, int]:
         p, n = C.c_void_p(), C.c_int64()

@@ -36,6 +36,8 @@ hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_p
                                          const int32_t* pos_region, const int32_t* pos_local, const double* scores,
                                          const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
                                          mipgen_survivor* survivors, unsigned long long* emitted_per_region);
+hipError_t mipgen_launch_collapse(hipStream_t, int n_tiles, const CollapseTile* tiles, const DevParams*, const DevRegion*, const int64_t* region_pos0,
+                                  const int64_t* region_base0, const mipgen_survivor* survivors, const int32_t* copy, int64_t cand_base, int32_t* collapsed);
 }
 
 // ---- errors ----------------------------------------------------------------------------------------------
@@ -59,7 +61,8 @@ struct Window {
     int r0 = 0, r1 = 0;              // regions [r0, r1)
     int64_t cand0 = 0, n_cand = 0;   // batch-wide candidate index of the first candidate; candidates
     int64_t pos0 = 0, n_pos = 0;     // batch-wide scan-position index; positions
-    int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0;
+    int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0, col_tile0 = 0, n_col_tiles = 0;
+    int64_t base0 = 0, n_base_entries = 0;   // collapsed entries (2 per base) of the window inside the batch-wide array
 };
 
 template <typename T>
@@ -124,6 +127,12 @@ struct mipgen_accel {
     DevBuf<mipgen_survivor> survivors;
     DevBuf<unsigned long long> emitted_per_region;
     DevBuf<int32_t> pos_region, pos_local;
+    // collapse: per base and strand the scan-start index of the best survivor covering it
+    std::vector<int64_t> h_region_base0;     // first collapsed entry of every region (batch-wide), + total at the end
+    DevBuf<int64_t> region_pos0, region_base0;
+    DevBuf<CollapseTile> col_tiles;
+    DevBuf<int32_t> collapsed;
+    bool collapsed_valid = false;
     bool replayed = false, mask_valid = false;
     // sparse scratch
     DevBuf<mipgen_candidate> cand_in;
@@ -291,6 +300,7 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->model.release(); h->regions.release(); h->bases.release(); h->unmap.release(); h->copy.release();
     h->log_tiles.release(); h->svr_tiles.release(); h->scores.release(); h->records.release();
     h->emitted.release(); h->survivors.release(); h->emitted_per_region.release(); h->pos_region.release(); h->pos_local.release();
+    h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
     h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();
     if (h->dp) (void)hipFree(h->dp);
@@ -518,6 +528,17 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     int64_t win_cand_max = 0;
     for (const Window& w : h->windows) win_cand_max = std::max(win_cand_max, w.n_cand);
 
+    // ---- collapse layout: bases a survivor's scan target can cover, per region ----
+    std::vector<int64_t> rpos0((size_t)n + 1, 0);
+    h->h_region_base0.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) {
+        const DevRegion& d = h->hregions[i];
+        const int max_scan = D.max_capture - d.k0 * D.inc - D.min_sum;
+        const int64_t nb = (d.n_pos > 0 && d.n_sizes > 0) ? (int64_t)d.n_pos + max_scan - 1 : 0;
+        rpos0[(size_t)i + 1] = rpos0[(size_t)i] + d.n_pos;
+        h->h_region_base0[(size_t)i + 1] = h->h_region_base0[(size_t)i] + 2 * nb;
+    }
+    std::vector<CollapseTile> ct;
     // ---- tiles, window by window ----
     std::vector<LogTile> lt;
     std::vector<SvrTile> st;
@@ -527,10 +548,12 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
     const bool svr_possible = h->svr_geometry_error.empty();
     for (Window& w : h->windows) {
-        w.log_tile0 = (int)lt.size(); w.svr_tile0 = (int)st.size();
+        w.log_tile0 = (int)lt.size(); w.svr_tile0 = (int)st.size(); w.col_tile0 = (int)ct.size();
+        w.base0 = h->h_region_base0[(size_t)w.r0]; w.n_base_entries = h->h_region_base0[(size_t)w.r1] - w.base0;
         for (int i = w.r0; i < w.r1; i++) {
             const DevRegion& d = h->hregions[i];
             if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
+            for (int64_t j0 = 0; 2 * j0 < h->h_region_base0[(size_t)i + 1] - h->h_region_base0[(size_t)i]; j0 += 128) { CollapseTile t = {i, (int32_t)j0}; ct.push_back(t); }
             const int Cmax = D.max_capture - d.k0 * D.inc;
             const int NPL = 8;  // 8 positions per records tile: ~10 resident blocks per CU hide the per-candidate gathers (32: 2.6 waves/SIMD, 45 % slower)
             for (int p0 = 0; p0 < d.n_pos; p0 += NPL) {
@@ -588,7 +611,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                     for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); }
                 }
         }
-        w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0;
+        w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0; w.n_col_tiles = (int)ct.size() - w.col_tile0;
     }
     h->svr_batch_error.clear();
     if (svr_lds > 160 * 1024) { h->svr_batch_error = "an SVR tile needs more than 160 KiB of LDS: capture range / arm lists too wide"; st.clear(); for (Window& w : h->windows) { w.svr_tile0 = 0; w.n_svr_tiles = 0; } svr_lds = 0; }
@@ -596,6 +619,12 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         h->scores.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) || h->records.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) ||
         h->emitted.reserve((size_t)std::max<int64_t>(win_cand_max, 1)))
         return MIPGEN_E_NOMEM;
+    if (h->region_pos0.reserve((size_t)n + 1) || h->region_base0.reserve((size_t)n + 1) || h->col_tiles.reserve(std::max<size_t>(ct.size(), 1)) ||
+        h->collapsed.reserve((size_t)std::max<int64_t>(h->h_region_base0[(size_t)n], 1)))
+        return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(h->region_pos0.p, rpos0.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->region_base0.p, h->h_region_base0.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    if (!ct.empty()) HIP_TRY(hipMemcpyAsync(h->col_tiles.p, ct.data(), ct.size() * sizeof(CollapseTile), hipMemcpyHostToDevice, h->stream));
     std::vector<int32_t> pr((size_t)pos_total), pl((size_t)pos_total);
     {
         int64_t k = 0;
@@ -614,7 +643,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
     h->log_span_max = span_max; h->svr_lds = svr_lds;
-    h->scored = false; h->replayed = false;
+    h->scored = false; h->replayed = false; h->collapsed_valid = false;
     h->ev_used.assign(h->windows.size(), 0);
 #ifdef MIPGEN_DIAG
     fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates in %zu window(s), %zu record tiles (LDS %zu B), %zu SVR tiles x %d threads (LDS %zu B)\n", n,
@@ -713,6 +742,14 @@ static int replay_window_impl(mipgen_accel* h, bool want_mask)
     return MIPGEN_OK;
 }
 
+static int collapse_window_impl(mipgen_accel* h)
+{
+    const Window& W = h->windows[(size_t)h->cur_window];
+    HIP_TRY(mipgen_launch_collapse(h->stream, W.n_col_tiles, h->col_tiles.p + W.col_tile0, h->dp, h->regions.p, h->region_pos0.p, h->region_base0.p,
+                                   h->survivors.p, h->copy.p, W.cand0, h->collapsed.p));
+    return MIPGEN_OK;
+}
+
 static int check_scoring_args(mipgen_accel* h, int32_t method)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
@@ -747,7 +784,9 @@ int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
     for (int w = 0; w < (int)h->windows.size(); w++) {
         if (int rc = score_window_impl(h, w, method)) return rc;
         if (int rc = replay_window_impl(h, false)) return rc;
+        if (int rc = collapse_window_impl(h)) return rc;
     }
+    h->collapsed_valid = true;
     return MIPGEN_OK;
 }
 
@@ -894,6 +933,40 @@ int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, m
         if (mask_capacity < W.n_cand) return fail(MIPGEN_E_INVALID, "mask capacity too small");
         if (W.n_cand) HIP_TRY(hipMemcpy(emitted_mask, h->emitted.p, (size_t)W.n_cand, hipMemcpyDeviceToHost));
     }
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_collapse(mipgen_accel* h)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (!h->replayed || h->cur_window < 0) return fail(MIPGEN_E_STATE, "collapse requested before replay + condense");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = collapse_window_impl(h)) return rc;
+    h->collapsed_valid = true;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_region_bases(const mipgen_accel* h, int32_t region, int64_t* first_entry, int32_t* n_bases)
+{
+    if (!h || region < 0 || region >= h->n_regions) return fail(MIPGEN_E_INVALID, "region %d out of range", region);
+    if (first_entry) *first_entry = h->h_region_base0[(size_t)region];
+    if (n_bases) *n_bases = (int32_t)((h->h_region_base0[(size_t)region + 1] - h->h_region_base0[(size_t)region]) / 2);
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* best_scan_index, int64_t capacity)
+{
+    if (!h || !best_scan_index) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (!h->collapsed_valid) return fail(MIPGEN_E_STATE, "mipgen_accel_collapse / mipgen_accel_score_condense_all has not run on these survivors");
+    int64_t first = 0, count = h->h_region_base0.empty() ? 0 : h->h_region_base0.back();
+    if (window >= 0) {
+        if (window >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "window %d out of range", window);
+        first = h->windows[(size_t)window].base0; count = h->windows[(size_t)window].n_base_entries;
+    }
+    if (capacity < count) return fail(MIPGEN_E_INVALID, "collapsed capacity %lld < %lld entries", (long long)capacity, (long long)count);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (count) HIP_TRY(hipMemcpy(best_scan_index, h->collapsed.p + first, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
     return MIPGEN_OK;
 }
 

@@ -90,6 +90,12 @@ struct LogTile {
     int32_t pad;
 };
 
+// one workgroup of the collapse kernel: 128 consecutive bases (both strands) of one region
+struct CollapseTile {
+    int32_t region;
+    int32_t j0;            // first base (0-based from the region's first scan position)
+};
+
 // one workgroup of the dense SVR kernel
 struct SvrTile {
     int32_t region;

@@ -167,6 +167,13 @@ int mipgen_design_set_long_range_content(mipgen_design* d, int32_t i, const doub
 int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors, int64_t emitted,
                                 const double* scores, const uint64_t* records, const uint8_t* emitted_mask, mipgen_rescore_fn rescore, void* ctx)
 {
+    return mipgen_design_select_region_collapsed(d, i, grid, survivors, emitted, scores, records, emitted_mask, nullptr, 0, rescore, ctx);
+}
+
+int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors, int64_t emitted,
+                                          const double* scores, const uint64_t* records, const uint8_t* emitted_mask, const int32_t* collapsed,
+                                          int32_t n_bases, mipgen_rescore_fn rescore, void* ctx)
+{
     if (!d || !grid || (!survivors && grid->n_pos > 0)) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
     if (i != d->next_region) {
         char msg[128];
@@ -205,7 +212,7 @@ int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* 
         FnRescorer rs_fn;
         rs_fn.fn = rescore; rs_fn.ctx = ctx; rs_fn.region = i;
         if (o.score_method == MIPGEN_SCORE_MIXED && !rescore) return fail(MIPGEN_HOST_E_USAGE, 0, "a mixed design needs the SVR re-score hook");
-        d->selector->run_region(r, *grid, rs, o.score_method == MIPGEN_SCORE_MIXED ? &rs_fn : nullptr, lower, upper);
+        d->selector->run_region(r, *grid, rs, o.score_method == MIPGEN_SCORE_MIXED ? &rs_fn : nullptr, lower, upper, collapsed, n_bases);
     } catch (int e) {
         char msg[96];
         snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);
@@ -238,6 +245,8 @@ struct WindowResult {
     std::vector<int64_t> emitted;
     std::vector<mipgen_survivor> surv;           // cand_index relative to the window's first candidate
     std::vector<double> svr;                     // mixed designs: SVR score of every survivor (parallel to surv; NaN where none)
+    std::vector<int32_t> collapsed;              // collapse_mips from the device: 2 entries per base, region after region
+    std::vector<int64_t> col_off;                // first entry of every region of the window in `collapsed` (+ total)
     std::vector<double> scores;
     std::vector<uint64_t> records;
     std::vector<uint8_t> mask;
@@ -331,7 +340,15 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch)
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
         for (auto& g : res->grids) g.offset -= c0;
         res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np));
-        if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
+        if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h) || mipgen_accel_collapse(h)) { bail(19); return; }
+        res->col_off.assign((size_t)wn + 1, 0);
+        for (int bi = 0; bi < wn; bi++) {
+            int64_t fe = 0; int32_t nb = 0;
+            mipgen_accel_region_bases(h, wr0 + bi, &fe, &nb);
+            res->col_off[(size_t)bi + 1] = res->col_off[(size_t)bi] + 2 * (int64_t)nb;
+        }
+        res->collapsed.resize((size_t)std::max<int64_t>(res->col_off[(size_t)wn], 1));
+        if (mipgen_accel_download_collapsed(h, w, res->collapsed.data(), (int64_t)res->collapsed.size())) { bail(19); return; }
         if (!o.silent) {
             res->scores.resize((size_t)nc); res->records.resize((size_t)nc); res->mask.resize((size_t)nc);
             if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
@@ -420,9 +437,10 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                 rs.w = w.get(); rs.pos0 = pos0; rs.g = &g;
                 const bool dense = !w->scores.empty();
                 try {
-                    rc = mipgen_design_select_region(d, w->r0 + bi, &g, w->surv.data() + 2 * pos0, w->emitted[(size_t)bi],
+                    rc = mipgen_design_select_region_collapsed(d, w->r0 + bi, &g, w->surv.data() + 2 * pos0, w->emitted[(size_t)bi],
                                                      dense ? w->scores.data() + g.offset : nullptr, dense ? w->records.data() + g.offset : nullptr,
-                                                     dense ? w->mask.data() + g.offset : nullptr,
+                                                     dense ? w->mask.data() + g.offset : nullptr, w->collapsed.data() + w->col_off[(size_t)bi],
+                                                     (int32_t)((w->col_off[(size_t)bi + 1] - w->col_off[(size_t)bi]) / 2),
                                                      d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
                 } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
                 pos0 += g.n_pos;

@@ -121,8 +121,10 @@ public:
     Selector(const Options& o, const Tables& t, Outputs& out) : o_(o), t_(t), out_(out) {}
     // survivors: 2 per scan position ('+','-'); cand_index is region-local or -1.  scores/records: region-local dense arrays
     // (only needed for the survivors; pass the values stored in the survivor records)
+    // collapsed: optional result of the accelerator's collapse (2 entries per base from g.first_pos on: scan-start index of the
+    // winning survivor per strand, or -1; n_bases of them); nullptr = collapse on the host
     void run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& survivors, Rescorer* rescorer,
-                    double lower, double upper);
+                    double lower, double upper, const int32_t* collapsed = nullptr, int32_t n_bases = 0);
 private:
     using CandPtr = std::shared_ptr<Cand>;
     const Options& o_; const Tables& t_; Outputs& out_;

@@ -188,7 +188,7 @@ bool Selector::arm_used(const Cand& c, int strand) const
 }
 
 void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& surv, Rescorer* rs,
-                          double lower, double upper)
+                          double lower, double upper, const int32_t* collapsed, int32_t n_bases)
 {
     r_ = &r; rs_ = rs; lower_ = lower; upper_ = upper;
     scan_best_.clear(); pos_best_.clear();
@@ -198,7 +198,19 @@ void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vect
             if (sv.cand_index < 0) continue;
             scan_best_[g.first_pos + pi][s] = std::make_shared<Cand>(make_cand(o_, r, g, sv.cand_index, sv.score, sv.record));
         }
-    collapse();
+    if (collapsed) {
+        // collapse_mips ran on the accelerator: per base and strand the scan-start index of the survivor the fold keeps
+        for (int32_t j = 0; j < n_bases; j++)
+            for (int s = 0; s < 2; s++) {
+                const int32_t pi = collapsed[2 * (size_t)j + s];
+                if (pi < 0) continue;
+                auto it = scan_best_.find(g.first_pos + pi);
+                if (it == scan_best_.end()) throw 21;
+                auto is = it->second.find(s);
+                if (is == it->second.end()) throw 21;
+                pos_best_[g.first_pos + j][s] = is->second;
+            }
+    } else collapse();
     if (!o_.silent) output_collapsed();
     out_.progress << "mips collapsed! picking mips...\n";
     if (o_.score_method == MIPGEN_SCORE_MIXED) { lower_ = o_.svr_priority; upper_ = o_.svr_optimal; }     // mipgen.cpp:510-514

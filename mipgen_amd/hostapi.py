@@ -22,7 +22,8 @@ RESCORE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32, C.POINTER(capi.Candi
 EXPORTED_SYMBOLS = [
     "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
     "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region",
-    "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region", "mipgen_design_counters",
+    "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
+    "mipgen_design_select_region_collapsed", "mipgen_design_counters",
     "mipgen_design_run", "mipgen_host_rand_stream",
 ]
 
@@ -56,6 +57,8 @@ def load_library():
     lib.mipgen_design_set_long_range_content.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     lib.mipgen_design_select_region.argtypes = [vp, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.c_int64, C.POINTER(C.c_double),
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), RESCORE_FN, vp]
+    lib.mipgen_design_select_region_collapsed.argtypes = [vp, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.c_int64, C.POINTER(C.c_double),
+                                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int32, RESCORE_FN, vp]
     lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
     lib.mipgen_host_rand_stream.argtypes = [C.POINTER(C.c_int32), C.c_int32]
@@ -121,16 +124,20 @@ class Design:
 
     def select_region(self, i: int, grid: capi.Grid, survivors: np.ndarray, emitted: int, scores: Optional[np.ndarray] = None,
                       records: Optional[np.ndarray] = None, mask: Optional[np.ndarray] = None,
-                      rescore: Optional[Callable[[int, capi.Candidate], float]] = None) -> None:
+                      rescore: Optional[Callable[[int, capi.Candidate], float]] = None, collapsed: Optional[np.ndarray] = None) -> None:
         survivors = np.ascontiguousarray(survivors)
         assert survivors.dtype == capi.SURVIVOR_DTYPE and survivors.shape[0] == 2 * grid.n_pos
         fn = RESCORE_FN(lambda ctx, region, cand: float(rescore(region, cand.contents))) if rescore else RESCORE_FN()
         dp = C.POINTER(C.c_double)
-        self._check(self.lib.mipgen_design_select_region(
-            self.h, i, C.byref(grid), survivors.ctypes.data_as(C.POINTER(capi.Survivor)), emitted,
-            scores.ctypes.data_as(dp) if scores is not None else None,
-            records.ctypes.data_as(C.POINTER(C.c_uint64)) if records is not None else None,
-            mask.ctypes.data_as(C.POINTER(C.c_uint8)) if mask is not None else None, fn, None))
+        args = (self.h, i, C.byref(grid), survivors.ctypes.data_as(C.POINTER(capi.Survivor)), emitted,
+                scores.ctypes.data_as(dp) if scores is not None else None,
+                records.ctypes.data_as(C.POINTER(C.c_uint64)) if records is not None else None,
+                mask.ctypes.data_as(C.POINTER(C.c_uint8)) if mask is not None else None)
+        if collapsed is not None:
+            collapsed = np.ascontiguousarray(collapsed, dtype=np.int32)
+            self._check(self.lib.mipgen_design_select_region_collapsed(*args, collapsed.ctypes.data_as(C.POINTER(C.c_int32)), collapsed.shape[0] // 2, fn, None))
+        else:
+            self._check(self.lib.mipgen_design_select_region(*args, fn, None))
 
     def counters(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()

@@ -558,3 +558,72 @@ def test_model_loader_paths(genome, tmp_path):
     assert np.nanmax(np.abs(s0[valid] - scores[valid])) > 1e-6            # the extra indices do change the scores
     base_acc.close()
     acc.close()
+
+
+def _collapse_py(P, g, surv, target, max_product, thr):
+    """collapse_mips (mipgen.cpp:1616-1649) restated as a plain loop over the survivors in scan-start order (test-side checker)."""
+    A = P.n_arm_pairs
+    max_scan = P.max_capture_size - g.first_size_index * P.capture_increment - min(P.arm_ext[i] + P.arm_lig[i] for i in range(A))
+    n_base = g.n_pos + max_scan - 1 if g.n_pos > 0 and g.n_sizes > 0 else 0
+    best = -np.ones((n_base, 2), dtype=np.int32)
+    state = {}
+    for pi in range(g.n_pos):
+        for s in range(2):
+            m = surv[2 * pi + s]
+            if m["cand_index"] < 0:
+                continue
+            rel = int(m["cand_index"]) - g.offset - pi * g.n_sizes * A * 2
+            a, ki = rel % A, rel // (2 * A)
+            e, l = P.arm_ext[a], P.arm_lig[a]
+            ss = P.max_capture_size - (g.first_size_index + ki) * P.capture_increment - e - l
+            r = int(m["record"])
+            ec, lc = r & 0xFFFF, (r >> 16) & 0xFFFF
+            if ec * lc > max_product or ec > target or lc > target:
+                continue
+            if ((r >> 32) & 0xFF) / (l + e) > thr:
+                continue
+            snp, sc = (r >> 40) & 0xFF, float(m["score"])
+            for j in range(pi, pi + ss):
+                cur = state.get((j, s))
+                if cur is None or snp < cur[0] or (sc > cur[1] and snp == cur[0]):
+                    state[(j, s)] = (snp, sc)
+                    best[j, s] = pi
+    return best
+
+
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "mixed_small", "svr_small"])
+def test_collapse_on_device(name, genome):
+    """mipgen_accel_collapse: per base and strand the survivor the reference's collapse fold keeps (SNP count first, then strictly higher
+    score, first come first kept), incl. the copy / masked-arm filters - against a plain restatement of the fold; window by window and
+    through the fused silent path."""
+    meta = H.load_design(name)
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
+    acc = capi.Accel(P)
+    if meta["model"]:
+        acc.load_model_file(_model_path(meta))
+    acc.set_window_candidates(int(max(po.grid(P, r).count for r in regions)) + 1)
+    grids = acc.upload(regions)
+    per_window = []
+    for w in range(acc.window_count()):
+        acc.score_window(w, method)
+        acc.replay_condense()
+        acc.collapse()
+        e, surv, _ = acc.download_replay(want_mask=False, window=w)
+        col = acc.download_collapsed(w)
+        wi = acc.window_info(w)
+        off = 0
+        pos = 0
+        for ri in range(wi["first_region"], wi["first_region"] + wi["n_regions"]):
+            g = grids[ri]
+            fe, nb = acc.region_bases(ri)
+            exp = _collapse_py(P, g, surv[2 * pos:2 * (pos + g.n_pos)], P.target_arm_copy, P.max_arm_copy_product, P.masked_arm_threshold)
+            assert exp.shape[0] == nb
+            assert np.array_equal(col[off:off + 2 * nb].reshape(nb, 2), exp), (name, ri)
+            assert (exp >= 0).any()
+            off += 2 * nb; pos += g.n_pos
+        per_window.append(col)
+    acc.score_condense_all(method)
+    assert np.array_equal(acc.download_collapsed(-1), np.concatenate(per_window))
+    acc.close()

@@ -1,9 +1,9 @@
 #!/bin/bash
 # tools/profile_round.sh TAG — the measurements behind DESIGN.md / bench.py's roofline object, on the MI355X box:
 #   1. bench.py (default workload) -> gpurun_out/TAG_bench.json
-#   2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/TAG_kernel_stats.csv
-#   3. separate rocprofv3 --pmc passes (never combined with other trace domains) -> gpurun_out/TAG_pmc.json
-# Run as:  gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01d'   then copy the three files into profiles/.
+#   2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/TAG_kernel_stats.csv (+ the logistic / 5 kb / exome configs)
+#   3. separate rocprofv3 --pmc passes (never combined with other trace domains) -> gpurun_out/TAG_pmc.json, TAG_hbm_traffic.json
+# Run as:  gpurun --timeout 1800 -- 'bash tools/profile_round.sh r02d'   then copy the files into profiles/.
 set -u
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -11,30 +11,37 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 5 --warmup 2 > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
-tail -c 600 "$OUT/${TAG}_bench.json"; echo
+tail -c 400 "$OUT/${TAG}_bench.json"; echo
 rm -rf "$OUT/prof_$TAG"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/stats" -o s -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+B="--steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/stats" -o s -- python3 "$R/bench.py" $B > /dev/null 2>&1
 cp "$(find "$OUT/prof_$TAG/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+for cfg in "regions5k --method logistic" "regions5k --method svr" "exome"; do
+  name=$(echo $cfg | tr -d ' -' )
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/stats_$name" -o s -- python3 "$R/bench.py" --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  cp "$(find "$OUT/prof_$TAG/stats_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_$name.csv"
+done
 i=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
             "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/prof_$TAG/pmc$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-replay > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/prof_$TAG/pmc$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
-for kern in ("k_svr_dense", "k_records_logistic"):
+for kern in ("k_svr_dense", "k_records_logistic", "k_replay_condense"):
     agg = collections.defaultdict(float); n = collections.Counter()
     for fn in glob.glob(f"{out}/prof_{tag}/pmc*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
             if kern in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     res[kern] = {k: agg[k] / n[k] for k in sorted(agg)}
-res["_note"] = "mean per launch, summed over the device; separate --pmc passes of `bench.py --steps 2 --warmup 1 --no-replay --no-cpu-baseline`"
+res["_note"] = ("mean per launch, summed over the device; separate --pmc passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` "
+                "(default workload: practice62, capture 140-180, SVR n_sv=1024)")
 json.dump(res, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(res["k_svr_dense"], indent=1))
 PY
-grep -E "k_svr_dense|k_records|k_replay|Name" "$OUT/${TAG}_kernel_stats.csv" | cut -c1-200
+grep -E "k_svr_dense|k_records|k_replay|k_svr_finish|Name" "$OUT/${TAG}_kernel_stats.csv" | cut -c1-220
