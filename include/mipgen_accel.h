@@ -21,6 +21,7 @@
  *   mipgen.cpp:426-437,494-497  score-dependent early exits (replay)               mipgen_accel_replay_condense()
  *   mipgen.cpp:1670-1746 condense_mips                                             mipgen_accel_replay_condense()
  *   mipgen.cpp:1616-1649 collapse_mips                                             mipgen_accel_collapse()
+ *   mipgen.cpp:558-596,825-835 arm-oligo copy numbers through bwa                  mipgen_accel_count_oligo_copies()  (opt-in, exact matches)
  *   mipgen.cpp:412-524   tile_regions in -silent_mode (enumerate + score + condense of    mipgen_accel_score_condense_all()
  *                        every region, nothing kept per candidate)
  *
@@ -286,6 +287,21 @@ int mipgen_accel_region_bases(const mipgen_accel* h, int32_t region, int64_t* fi
 /* window >= 0: the entries of that window's regions; window < 0: the whole batch (after mipgen_accel_score_condense_all) */
 int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* best_scan_index, int64_t capacity);
 
+/* ---- section 8f-3 (opt-in): arm-oligo copy numbers without the bwa round trip ----------------------------------------------------
+ * Replaces check_copy_numbers / find_copy's oligo half (mipgen.cpp:825-835 writes every arm oligo to a FASTQ file, :558-596 reads bwa's
+ * X0:i best-hit count back): an oligo always matches itself, so its best hits are its exact occurrences on either strand, counted here in
+ * ONE streaming pass over the genome (1 byte per base; canonical 2-bit k-mer keys, exact for lengths <= 31).
+ *   chrom_seqs / chrom_lens   the genome the oligos are counted against (ASCII, any case; non-ACGT bytes break k-mers)
+ *   region_seqs / region_lens the region strings (Featurev5::chromosomal_sequence)
+ *   lengths                   the design's distinct oligo lengths, ascending
+ *   copy_out[r]               int32 [n_lengths][region_lens[r]]: exactly the mipgen_region.copy slices (copy[len][start - seq_start]);
+ *                             oligos with a non-ACGT byte get 100 (a read without an X0 tag, :589-592), oligos that would run past the
+ *                             region string 0 (never written, :829)
+ * BWA's mismatch-tolerant uniqueness test of whole capture windows (:841-868) is not reproduced: pass unmappable = NULL. */
+int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens,
+                                    int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens,
+                                    int32_t n_lengths, const int32_t* lengths, int32_t* const* copy_out);
+
 /* ---- tuning ---------------------------------------------------------------------------------------- */
 /* A dense SVR launch with few tiles is split along the support-vector list so that it still fills the chip (partial sums are added
  * in a fixed order: results are deterministic for a given split).  0 = chosen per launch from the tile count (default), n >= 1 forces
@@ -295,7 +311,7 @@ int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
 /* ---- instrumentation ------------------------------------------------------------------------------ */
 /* HIP-event time (ms) of the kernels of the last scoring call (summed over its windows), measured on the handle's stream;
  * negative if unavailable.  which: 0 = dense SVR kernel, 1 = records + scoring kernels, 2 = records / logistic kernel,
- * 3 = replay + condense. */
+ * 3 = replay + condense; 4 = genome pass of the last mipgen_accel_count_oligo_copies (always recorded). */
 double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which);
 /* enable/disable per-call event timing (it inserts two hipEventRecord per call) */
 int mipgen_accel_set_timing(mipgen_accel* h, int32_t enabled);

@@ -287,12 +287,14 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_collapse.argtypes = [vp]
     lib.mipgen_accel_region_bases.argtypes = [vp, C.c_int32, i64p, i32p]
     lib.mipgen_accel_download_collapsed.argtypes = [vp, C.c_int32, i32p, C.c_int64]
+    lib.mipgen_accel_count_oligo_copies.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, C.c_int32, i32p,
+                                                    C.POINTER(C.POINTER(C.c_int32))]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
     for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed"):
+                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -309,7 +311,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_set_window_candidates", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
-    "mipgen_accel_download_collapsed",
+    "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies",
 ]
 
 
@@ -400,6 +402,21 @@ class Accel:
         self._check(self.lib.mipgen_accel_download_survivors(self.h, emitted.ctypes.data_as(C.POINTER(C.c_int64)),
                                                              surv.ctypes.data_as(C.POINTER(Survivor)), 2 * npos))
         return emitted, surv
+
+    def count_oligo_copies(self, chroms: Sequence[bytes], region_seqs: Sequence[bytes], lengths: Sequence[int]) -> List[Dict[int, np.ndarray]]:
+        """Exact occurrence counts (both strands) of every oligo of the region strings in the genome: per region {length: int32[len(seq)]},
+        the layout of mipgen_region.copy."""
+        nc, nr, nl = len(chroms), len(region_seqs), len(lengths)
+        ca = (C.c_char_p * max(nc, 1))(*chroms)
+        cl = np.array([len(c) for c in chroms], dtype=np.int64)
+        ra = (C.c_char_p * max(nr, 1))(*region_seqs)
+        rl = np.array([len(r) for r in region_seqs], dtype=np.int32)
+        la = np.ascontiguousarray(lengths, dtype=np.int32)
+        outs = [np.zeros((nl, len(r)), dtype=np.int32) for r in region_seqs]
+        op = (C.POINTER(C.c_int32) * max(nr, 1))(*[o.ctypes.data_as(C.POINTER(C.c_int32)) for o in outs])
+        self._check(self.lib.mipgen_accel_count_oligo_copies(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
+                                                             rl.ctypes.data_as(C.POINTER(C.c_int32)), nl, la.ctypes.data_as(C.POINTER(C.c_int32)), op))
+        return [{int(k): o[i] for i, k in enumerate(lengths)} for o in outs]
 
     def collapse(self) -> None:
         self._check(self.lib.mipgen_accel_collapse(self.h))

@@ -36,6 +36,10 @@ hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_p
                                          const int32_t* pos_region, const int32_t* pos_local, const double* scores,
                                          const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
                                          mipgen_survivor* survivors, unsigned long long* emitted_per_region);
+struct KmerParams { int32_t n_k; int32_t k[MIPGEN_MAX_OLIGO]; int32_t kmax; int32_t pad; uint64_t cap_mask; };
+hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, const KmerParams*, uint64_t* keys);
+hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, unsigned int* counts);
+hipError_t mipgen_launch_kmer_lookup(hipStream_t, const char* seq, int64_t len, const KmerParams*, const uint64_t* keys, const unsigned int* counts, int32_t* out);
 hipError_t mipgen_launch_collapse(hipStream_t, int n_tiles, const CollapseTile* tiles, const DevParams*, const DevRegion*, const int64_t* region_pos0,
                                   const int64_t* region_base0, const mipgen_survivor* survivors, const int32_t* copy, int64_t cand_base, int32_t* collapsed);
 }
@@ -133,6 +137,8 @@ struct mipgen_accel {
     DevBuf<CollapseTile> col_tiles;
     DevBuf<int32_t> collapsed;
     bool collapsed_valid = false;
+    double kmer_count_ms = -1.0;             // genome pass of the last mipgen_accel_count_oligo_copies
+    int64_t kmer_genome_bytes = 0;
     bool replayed = false, mask_valid = false;
     // sparse scratch
     DevBuf<mipgen_candidate> cand_in;
@@ -993,8 +999,87 @@ int mipgen_accel_survivors_device_ptr(const mipgen_accel* h, void** survivors_de
     return MIPGEN_OK;
 }
 
+// ---- section 8f-3: arm-oligo copy numbers by exact k-mer counting (opt-in replacement of the bwa round trip) ----------------
+int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                    const char* const* region_seqs, const int32_t* region_lens, int32_t n_lengths, const int32_t* lengths,
+                                    int32_t* const* copy_out)
+{
+    if (!h || n_chrom < 0 || n_regions < 0 || n_lengths < 1 || n_lengths > MIPGEN_MAX_OLIGO || !lengths || (n_chrom && (!chrom_seqs || !chrom_lens)) ||
+        (n_regions && (!region_seqs || !region_lens || !copy_out)))
+        return fail(MIPGEN_E_INVALID, "bad arguments");
+    KmerParams KP;
+    memset(&KP, 0, sizeof KP);
+    KP.n_k = n_lengths;
+    for (int i = 0; i < n_lengths; i++) {
+        if (lengths[i] < 1 || lengths[i] > 31 || (i && lengths[i] <= lengths[i - 1])) return fail(MIPGEN_E_INVALID, "oligo lengths must be ascending and <= 31 (exact 2-bit keys)");
+        KP.k[i] = lengths[i];
+    }
+    KP.kmax = lengths[n_lengths - 1];
+    if (n_regions == 0) return MIPGEN_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    // region sequences, separated by one 'N' (no k-mer crosses it)
+    int64_t total = 0;
+    std::vector<int64_t> roff((size_t)n_regions);
+    for (int r = 0; r < n_regions; r++) { roff[(size_t)r] = total; total += (int64_t)region_lens[r] + 1; }
+    std::vector<char> q((size_t)total, 'N');
+    for (int r = 0; r < n_regions; r++) memcpy(&q[(size_t)roff[(size_t)r]], region_seqs[r], (size_t)region_lens[r]);
+    uint64_t cap = 1024;
+    while (cap < 2 * (uint64_t)total) cap <<= 1;
+    KP.cap_mask = cap - 1;
+    int64_t gmax = 0;
+    for (int c = 0; c < n_chrom; c++) gmax = std::max(gmax, chrom_lens[c]);
+    DevBuf<char> dq, dg;
+    DevBuf<uint64_t> dkeys;
+    DevBuf<unsigned int> dcounts;
+    DevBuf<int32_t> dout;
+    const size_t tab = (size_t)cap * (size_t)n_lengths;
+    int rc = 0;
+    if (dq.reserve((size_t)total) || dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || dkeys.reserve(tab) || dcounts.reserve(tab) || dout.reserve((size_t)total * (size_t)n_lengths)) rc = MIPGEN_E_NOMEM;
+    auto cleanup = [&]() { dq.release(); dg.release(); dkeys.release(); dcounts.release(); dout.release(); };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+#define KTRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return fail(MIPGEN_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
+    if (rc) { cleanup(); return rc; }
+    KTRY(hipEventCreate(&e0)); KTRY(hipEventCreate(&e1));
+    KTRY(hipMemcpyAsync(dq.p, q.data(), (size_t)total, hipMemcpyHostToDevice, h->stream));
+    KTRY(hipMemsetAsync(dkeys.p, 0xFF, tab * sizeof(uint64_t), h->stream));
+    KTRY(hipMemsetAsync(dcounts.p, 0, tab * sizeof(unsigned int), h->stream));
+    KTRY(mipgen_launch_kmer_insert(h->stream, dq.p, total, &KP, dkeys.p));
+    double ms_total = 0.0;
+    int64_t gbytes = 0;
+    for (int c = 0; c < n_chrom; c++) {                                // one streaming pass per chromosome: 1 byte per genome base
+        if (chrom_lens[c] <= 0) continue;
+        KTRY(hipMemcpyAsync(dg.p, chrom_seqs[c], (size_t)chrom_lens[c], hipMemcpyHostToDevice, h->stream));
+        KTRY(hipEventRecord(e0, h->stream));
+        KTRY(mipgen_launch_kmer_count(h->stream, dg.p, chrom_lens[c], &KP, dkeys.p, dcounts.p));
+        KTRY(hipEventRecord(e1, h->stream));
+        KTRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        KTRY(hipEventElapsedTime(&ms, e0, e1));
+        ms_total += ms; gbytes += chrom_lens[c];
+    }
+    KTRY(mipgen_launch_kmer_lookup(h->stream, dq.p, total, &KP, dkeys.p, dcounts.p, dout.p));
+    std::vector<int32_t> out((size_t)total * (size_t)n_lengths);
+    KTRY(hipMemcpyAsync(out.data(), dout.p, out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    KTRY(hipStreamSynchronize(h->stream));
+#undef KTRY
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    cleanup();
+    for (int r = 0; r < n_regions; r++) {
+        const int len = region_lens[r];
+        if (!copy_out[r]) continue;
+        for (int s = 0; s < n_lengths; s++) {
+            int32_t* dst = copy_out[r] + (size_t)s * (size_t)len;
+            memcpy(dst, &out[(size_t)s * (size_t)total + (size_t)roff[(size_t)r]], (size_t)len * sizeof(int32_t));
+            for (int i = std::max(0, len - lengths[s]); i < len; i++) dst[i] = 0;      // oligos the reference never writes (mipgen.cpp:829): absent key -> 0
+        }
+    }
+    h->kmer_count_ms = ms_total; h->kmer_genome_bytes = gbytes;
+    return MIPGEN_OK;
+}
+
 double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which)
 {
+    if (h && which == 4) return h->kmer_count_ms;
     if (!h || !h->timing) return -1.0;
     if (hipSetDevice(h->device) != hipSuccess) return -1.0;
     double total = 0.0;

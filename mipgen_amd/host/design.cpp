@@ -70,7 +70,8 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         Options& o = d->o;
         const std::string status = parse_command_line(argc, const_cast<char**>(argv), o);
         if (!status.empty()) return fail(MIPGEN_HOST_E_USAGE, 1, status);
-        if (std::system(o.arg("-bwa").c_str()) != 256) { std::cerr << "load bwa" << std::endl; throw 2; }            // mipgen.cpp:146-151
+        const bool gpu_copies = o.arg("-gpu_copy_counter") == "on";
+        if (!gpu_copies && std::system(o.arg("-bwa").c_str()) != 256) { std::cerr << "load bwa" << std::endl; throw 2; }            // mipgen.cpp:146-151
         if (o.arg("-trf") != "off" && std::system(o.arg("-trf").c_str()) != 65280) { std::cerr << "TRF directory invalid" << std::endl; throw 3; }
         finalize_options(o);
         d->model_path = o.file_dir + "mipgen_svr.model";                                                              // mipgen.cpp:409
@@ -92,12 +93,18 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         load_snps(o, d->regions, d->tables);
         out.progress << "all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         std::cerr << "[mipgen] all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
-        const std::string copy_status = check_copy_numbers(o, d->regions, d->tables);
-        if (copy_status.empty()) { std::cerr << "error with copy number analysis" << std::endl; throw 11; }
-        out.progress << copy_status;
-        find_copy(o, d->tables);
-        out.progress << "bwa copy number analysis finished\n";
-        std::cerr << "[mipgen] bwa copy number analysis finished\n";
+        if (gpu_copies) {
+            gpu_copy_numbers(o, d->regions);
+            out.progress << "0 ambiguously mapping start positions must be avoided\nexact oligo copy numbers counted on the accelerator\n";
+            std::cerr << "[mipgen] oligo copy numbers counted on the accelerator (no bwa)\n";
+        } else {
+            const std::string copy_status = check_copy_numbers(o, d->regions, d->tables);
+            if (copy_status.empty()) { std::cerr << "error with copy number analysis" << std::endl; throw 11; }
+            out.progress << copy_status;
+            find_copy(o, d->tables);
+            out.progress << "bwa copy number analysis finished\n";
+            std::cerr << "[mipgen] bwa copy number analysis finished\n";
+        }
         open_outputs(o, out);
         for (Region& r : d->regions) attach_tables(o, d->tables, r);
         d->selector.reset(new Selector(d->o, d->tables, d->out));

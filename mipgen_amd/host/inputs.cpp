@@ -329,10 +329,11 @@ static char comp(char c)
 void attach_tables(const Options& o, const Tables& t, Region& r)
 {
     const int n = (int)r.seq.size();
-    r.copy_store.clear();
+    if (!r.copy_ready) r.copy_store.clear();
     r.copy_ptr.assign(MIPGEN_MAX_OLIGO + 1, nullptr);
     auto cit = t.copies.find(r.chr);
     for (int len : o.oligo_sizes) {
+        if (r.copy_ready) break;
         if (len < 0 || len > MIPGEN_MAX_OLIGO) continue;
         r.copy_store.emplace_back((size_t)n, 0);                                 // absent key -> 0 (std::map::operator[], mipgen.cpp:612-613)
         std::vector<int32_t>& v = r.copy_store.back();
@@ -373,6 +374,58 @@ void attach_tables(const Options& o, const Tables& t, Region& r)
                 ok = g == al[0] || (comp(al[0]) != 0 && g == comp(al[0]));
             r.snp_class[(size_t)(it->first - r.seq_start)] = ok ? 1 : 2;
         }
+    }
+}
+
+// the arm-oligo copy numbers (mipgen.cpp:558-596, 825-835) as exact occurrence counts against the whole genome,
+// counted by the accelerator in one streaming pass per chromosome - no FASTQ files, no bwa.
+void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
+{
+    // the genome the reference's bwa index was built from: every chr*.fa of -genome_dir, or every record of the indexed fasta
+    std::vector<std::string> chroms;
+    auto read_fasta = [&](const std::string& path) {
+        std::ifstream fh(path);
+        if (!fh.is_open()) return false;
+        std::string line;
+        while (std::getline(fh, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+            if (!line.empty() && line[0] == '>') { chroms.emplace_back(); continue; }
+            if (chroms.empty()) chroms.emplace_back();
+            chroms.back() += line;
+        }
+        return true;
+    };
+    if (o.has("-genome_dir")) {
+        const std::string dir = o.arg("-genome_dir");
+        std::set<std::string> seen;
+        for (const Region& r : regs) if (seen.insert(r.chr).second && !read_fasta(dir + "/chr" + r.chr + ".fa")) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; throw 7; }
+        // chromosomes without a region still count towards copy numbers when they sit next to the others: chr*.fa listed in <dir>/chromosomes.txt
+        std::ifstream lst(dir + "/chromosomes.txt");
+        std::string name;
+        while (lst >> name) if (seen.insert(name).second) read_fasta(dir + "/chr" + name + ".fa");
+    } else if (!read_fasta(o.bwa_genome_index)) { std::cerr << "genome fasta could not be opened; check file path and permissions?" << std::endl; throw 9; }
+    std::vector<const char*> cs; std::vector<int64_t> cl;
+    for (const std::string& c : chroms) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
+    std::vector<int32_t> lengths(o.oligo_sizes.begin(), o.oligo_sizes.end());
+    std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<std::vector<int32_t>> flat(regs.size()); std::vector<int32_t*> outp;
+    for (size_t i = 0; i < regs.size(); i++) {
+        rs.push_back(regs[i].seq.data()); rl.push_back((int32_t)regs[i].seq.size());
+        flat[i].assign(lengths.size() * regs[i].seq.size(), 0);
+        outp.push_back(flat[i].data());
+    }
+    mipgen_params ap = o.accel_params();
+    mipgen_accel* h = nullptr;
+    if (mipgen_accel_create(&ap, 0, nullptr, &h)) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; throw 17; }
+    const int rc = mipgen_accel_count_oligo_copies(h, (int32_t)cs.size(), cs.data(), cl.data(), (int32_t)regs.size(), rs.data(), rl.data(),
+                                                   (int32_t)lengths.size(), lengths.data(), outp.data());
+    if (rc) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; mipgen_accel_destroy(h); throw 11; }
+    mipgen_accel_destroy(h);
+    for (size_t i = 0; i < regs.size(); i++) {
+        Region& r = regs[i];
+        const size_t n = r.seq.size();
+        r.copy_store.clear();
+        for (size_t s = 0; s < lengths.size(); s++) r.copy_store.emplace_back(flat[i].begin() + (long)(s * n), flat[i].begin() + (long)((s + 1) * n));
+        r.copy_ready = true;
     }
 }
 

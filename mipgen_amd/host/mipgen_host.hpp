@@ -63,6 +63,7 @@ struct Region {                                   // Featurev5
     std::vector<const int32_t*> copy_ptr;
     std::vector<uint8_t> unmappable, snp_class;
     std::string long_range_seq;                   // region +/- 1000 bases (svr / mixed only)
+    bool copy_ready = false;                      // copy_store already holds the oligo copy numbers (-gpu_copy_counter on)
 };
 
 struct Tables {                                   // global lookup tables the input stage fills (mipgen.cpp:81-83)
@@ -81,6 +82,8 @@ void load_snps(const Options& o, const std::vector<Region>& regs, Tables& t);
 std::string check_copy_numbers(const Options& o, const std::vector<Region>& regs, Tables& t);   // "" on failure
 void find_copy(const Options& o, Tables& t);
 void attach_tables(const Options& o, const Tables& t, Region& r);                          // fill copy/unmappable/snp slices
+// -gpu_copy_counter on: exact oligo copy numbers from the accelerator's k-mer counter instead of the bwa round trip; throws int on failure
+void gpu_copy_numbers(const Options& o, std::vector<Region>& regs);
 void fill_accel_region(const Region& r, mipgen_region& out);
 
 // one candidate as the selection stage sees it (the fields of SVMipv4 it reads)

@@ -20,7 +20,8 @@ static const char* k_options[] = {
     "-silent_mode", "-masked_arm_threshold", "-seal_both_strands", "-half_seal_both_strands", "-tag_sizes", "-ext_min_length",
     "-lig_min_length", "-bwa_threads", "-snp_file", "-double_tile_strand_unaware", "-double_tile_strands_separately",
     "-score_method", "-logistic_heuristic", "-file_of_parameters", "-logistic_priority_score", "-svr_priority_score",
-    "-logistic_optimal_score", "-svr_optimal_score", "-max_arm_copy_product", "-target_arm_copy"};
+    "-logistic_optimal_score", "-svr_optimal_score", "-max_arm_copy_product", "-target_arm_copy",
+    "-gpu_copy_counter"};          // extension (not in the reference): "on" = exact oligo copy numbers by k-mer counting on the GPU, no bwa
 
 static bool known(const std::string& p)
 {
@@ -60,7 +61,9 @@ static const char* k_doc =
     "  -logistic_optimal_score f (0.98)  -svr_optimal_score f (2.2)\n"
     "  -logistic_priority_score f (0.9)  -svr_priority_score f (1.5)\n"
     "misc\n"
-    "  -silent_mode on   skip the all_mips / collapsed_mips files\n";
+    "  -silent_mode on   skip the all_mips / collapsed_mips files\n"
+    "  -gpu_copy_counter on   (extension) arm copy numbers = exact occurrences in -genome_dir / the indexed fasta, counted on the GPU;\n"
+    "                         bwa is not run and the whole-window uniqueness flag is not set\n";
 
 static void set_defaults(Options& o)
 {
@@ -71,7 +74,7 @@ static void set_defaults(Options& o)
     a["-half_seal_both_strands"] = "off"; a["-masked_arm_threshold"] = "0.5"; a["-snp_file"] = "<none>";
     a["-capture_increment"] = "5"; a["-max_mip_overlap"] = "30"; a["-score_method"] = "logistic";
     a["-lig_min_length"] = "18"; a["-ext_min_length"] = "16"; a["-max_arm_copy_product"] = "75";
-    a["-target_arm_copy"] = "20"; a["-bwa_threads"] = "1";
+    a["-target_arm_copy"] = "20"; a["-bwa_threads"] = "1"; a["-gpu_copy_counter"] = "off";
 }
 
 std::string parse_command_line(int argc, char** argv, Options& o)

@@ -244,3 +244,46 @@ def print_details(region: capi.RegionData, strand: int, d: Designed, score: floa
     n = oracle().mo_print_details(region.chrom.encode(), region.label.encode(), region.start, region.stop, strand,
                                   C.byref(d), score, middle, mip_index, int(minor), buf, 4096)
     return buf.raw[:n]
+
+
+# ---- CPU counter for the opt-in k-mer copy numbers (checker of mipgen_accel_count_oligo_copies) ------------------
+_RC = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def count_oligo_copies(chroms: Sequence[bytes], seq: bytes, lengths: Sequence[int]):
+    """For every oligo seq[i:i+k]: the number of genome positions (any chromosome) where it or its reverse complement occurs exactly.
+    Oligos with a non-ACGT byte -> 100 (a read without an X0 tag, /root/reference/mipgen.cpp:589-592); oligos that would run past the
+    region string -> 0 (never written, :829; absent key :612-613).  Plain dictionary counting: parity for this row is unpinned against
+    BWA itself, this is the definition the device path is held to."""
+    out = {}
+    seq = seq.upper()
+    for k in lengths:
+        want = {}
+        for i in range(len(seq) - k + 1):
+            s = seq[i:i + k]
+            if s.strip(b"ACGT"):
+                continue
+            r = s.translate(_RC)[::-1]
+            want[min(s, r)] = 0
+        for g in chroms:
+            g = g.upper()
+            for i in range(len(g) - k + 1):
+                s = g[i:i + k]
+                if s in want:
+                    want[s] += 1
+                else:
+                    r = s.translate(_RC)[::-1]
+                    if r < s and r in want:
+                        want[r] += 1
+        col = np.zeros(len(seq), dtype=np.int32)
+        for i in range(len(seq)):
+            if i >= len(seq) - k:
+                col[i] = 0
+                continue
+            s = seq[i:i + k]
+            if s.strip(b"ACGT"):
+                col[i] = 100
+            else:
+                col[i] = want[min(s, s.translate(_RC)[::-1])]
+        out[int(k)] = col
+    return out

@@ -1,0 +1,85 @@
+"""GPU: SURVEY.md section 8f-3 - arm-oligo copy numbers by exact k-mer counting on the device (opt-in replacement of the reference's
+FASTQ -> bwa aln / samse -> X0:i round trip, /root/reference/mipgen.cpp:558-596, 825-835).  Parity against BWA itself is unpinned (no bwa in
+this image, and X0 counts mismatch-tolerant best hits); the device path is held bit-exact to the dictionary counter in oracle/pyoracle.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mipgen_amd import capi, synth
+from oracle import pyoracle as po
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+_RC = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _genome_with_repeats(seed=3):
+    rng = np.random.default_rng(seed)
+    a = bytearray(synth.random_genome(60_000, 31, n_run_frac=0.002, n_run_len=7))
+    b = bytearray(synth.random_genome(40_000, 32))
+    unit = bytes(a[5000:5300])
+    for pos in (12_000, 30_500, 51_000):                      # direct repeats of a 300-base unit
+        a[pos:pos + 300] = unit
+    b[7000:7300] = unit
+    b[20_000:20_300] = unit.translate(_RC)[::-1]              # and an inverted copy on the other chromosome
+    a[41_000:41_060] = b"ACGT" * 15                           # low-complexity stretch: palindromic k-mers
+    for i in rng.integers(0, 60_000, 40):
+        a[int(i)] = ord("acgtn"[int(i) % 5])                  # soft-masked (lower case) and n bytes
+    return bytes(a), bytes(b)
+
+
+def test_copy_counter_vs_dictionary_counter():
+    g1, g2 = _genome_with_repeats()
+    P = capi.make_params(152, 162)
+    acc = capi.Accel(P)
+    lengths = sorted({e for e, _ in capi.arm_pairs_of(P)} | {l for _, l in capi.arm_pairs_of(P)})
+    assert lengths[0] == 16 and lengths[-1] == 29
+    regions = [g1[4800:5500].upper(), g1[11_900:12_400].upper(), g1[40_950:41_120].upper(), g2[19_900:20_400].upper(), g2[100:160].upper(), b"ACGTN" * 8]
+    got = acc.count_oligo_copies([g1, g2], regions, lengths)
+    for seq, tab in zip(regions, got):
+        exp = po.count_oligo_copies([g1, g2], seq, lengths)
+        for k in lengths:
+            assert np.array_equal(tab[k], exp[k]), (k, np.nonzero(tab[k] != exp[k])[0][:5], tab[k][:8], exp[k][:8])
+    assert max(int(t[16].max()) for t in got) >= 6            # the planted unit: 6 copies (incl. the inverted one)
+    assert acc.last_kernel_ms(4) > 0
+    with pytest.raises(capi.AccelError):
+        acc.count_oligo_copies([g1], regions, [16, 40])       # > 31: no exact 2-bit key
+    acc.close()
+
+
+def test_cli_with_gpu_copy_counter(tmp_path):
+    """`mipgen ... -gpu_copy_counter on`: no bwa is run (the -bwa path does not even exist), the copy columns of all_mips are the exact
+    occurrence counts of the printed arm sequences in the genome, and the design still tiles."""
+    meta = H.load_design("logistic_default_arms")
+    work = str(tmp_path)
+    argv = H.prepare_cli_workdir(meta, work)
+    argv[argv.index("-bwa") + 1] = "/nonexistent/bwa"
+    p = subprocess.run(argv + ["-gpu_copy_counter", "on"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert not os.path.exists(os.path.join(work, "out.oligo_copy_count.fq"))
+    genome = H.golden_genome()
+    lines = open(os.path.join(work, "out.all_mips.txt"), "rb").read().split(b"\n")[1:-1]
+    assert len(lines) > 100_000
+    rng = np.random.default_rng(1)
+    cache = {}
+
+    def count(s):
+        if s not in cache:
+            r = s.translate(_RC)[::-1]
+            n, k = 0, len(s)
+            for i in range(len(genome) - k + 1):
+                w = genome[i:i + k]
+                n += (w == s) or (w == r and r != s)
+            cache[s] = n
+        return cache[s]
+    for i in rng.choice(len(lines), 60, replace=False):
+        f = lines[int(i)].split(b"\t")
+        ext_seq, lig_seq, ext_copy, lig_copy = f[6], f[10], int(f[5]), int(f[9])
+        for seq, c in ((ext_seq, ext_copy), (lig_seq, lig_copy)):
+            if b"N" in seq:
+                assert c == 100
+            else:
+                assert c == count(seq), (seq, c, count(seq))
+    assert open(os.path.join(work, "out.picked_mips.txt"), "rb").read().count(b"\n") >= 5
