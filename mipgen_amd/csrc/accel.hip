@@ -36,6 +36,9 @@ hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_p
                                          const int32_t* pos_region, const int32_t* pos_local, const double* scores,
                                          const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
                                          mipgen_survivor* survivors, unsigned long long* emitted_per_region);
+size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn);
+hipError_t mipgen_launch_logistic_dense(hipStream_t, int n_tiles, size_t lds_bytes, const DevParams*, const DevRegion*, const SvrTile*, const uint8_t*,
+                                        const int32_t*, const uint8_t*, const HostConsts*, double*, uint64_t*);
 struct KmerParams { int32_t n_k; int32_t k[MIPGEN_MAX_OLIGO]; int32_t kmax; int32_t pad; uint64_t cap_mask; };
 hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, const KmerParams*, uint64_t* keys);
 hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, unsigned int* counts);
@@ -65,7 +68,7 @@ struct Window {
     int r0 = 0, r1 = 0;              // regions [r0, r1)
     int64_t cand0 = 0, n_cand = 0;   // batch-wide candidate index of the first candidate; candidates
     int64_t pos0 = 0, n_pos = 0;     // batch-wide scan-position index; positions
-    int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0, col_tile0 = 0, n_col_tiles = 0;
+    int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0, col_tile0 = 0, n_col_tiles = 0, ld_tile0 = 0, n_ld_tiles = 0;
     int64_t base0 = 0, n_base_entries = 0;   // collapsed entries (2 per base) of the window inside the batch-wide array
 };
 
@@ -115,7 +118,8 @@ struct mipgen_accel {
     DevBuf<uint8_t> bases, unmap;
     DevBuf<int32_t> copy;
     DevBuf<LogTile> log_tiles;
-    DevBuf<SvrTile> svr_tiles;
+    DevBuf<SvrTile> svr_tiles, ld_tiles;      // dense SVR tiles; tiles of the table-based dense logistic kernel (same shape, own sizes)
+    size_t ld_lds = 0;                        // 0: some region does not fit that kernel's LDS -> the per-candidate kernel scores the batch
     int log_span_max = 0;
     size_t svr_lds = 0;
     // result windows: the inputs of every region stay resident; the dense result arrays (16 B per candidate) hold one window of
@@ -304,7 +308,7 @@ void mipgen_accel_destroy(mipgen_accel* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->model.release(); h->regions.release(); h->bases.release(); h->unmap.release(); h->copy.release();
-    h->log_tiles.release(); h->svr_tiles.release(); h->scores.release(); h->records.release();
+    h->log_tiles.release(); h->svr_tiles.release(); h->ld_tiles.release(); h->scores.release(); h->records.release();
     h->emitted.release(); h->survivors.release(); h->emitted_per_region.release(); h->pos_region.release(); h->pos_local.release();
     h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
@@ -545,6 +549,10 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         h->h_region_base0[(size_t)i + 1] = h->h_region_base0[(size_t)i] + 2 * nb;
     }
     std::vector<CollapseTile> ct;
+    std::vector<SvrTile> ldt;
+    size_t ld_lds = 0;
+    bool ld_ok = true;
+    const int64_t ld_np_cap = pos_total * 2 < 8192 ? 8 : (pos_total * 2 < 65536 ? 16 : 64);      // small batches: more, smaller tiles (fill 256 CUs)
     // ---- tiles, window by window ----
     std::vector<LogTile> lt;
     std::vector<SvrTile> st;
@@ -554,7 +562,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
     const bool svr_possible = h->svr_geometry_error.empty();
     for (Window& w : h->windows) {
-        w.log_tile0 = (int)lt.size(); w.svr_tile0 = (int)st.size(); w.col_tile0 = (int)ct.size();
+        w.log_tile0 = (int)lt.size(); w.svr_tile0 = (int)st.size(); w.col_tile0 = (int)ct.size(); w.ld_tile0 = (int)ldt.size();
         w.base0 = h->h_region_base0[(size_t)w.r0]; w.n_base_entries = h->h_region_base0[(size_t)w.r1] - w.base0;
         for (int i = w.r0; i < w.r1; i++) {
             const DevRegion& d = h->hregions[i];
@@ -566,6 +574,25 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                 LogTile t = {i, p0, std::min(NPL, d.n_pos - p0), 0};
                 lt.push_back(t);
                 span_max = std::max(span_max, t.np + Cmax + Lmax);
+            }
+            // tiles of the table-based dense logistic kernel: capture sizes in runs of <= 9, as many positions as its LDS tables allow
+            if (ld_ok) {
+                const int nkc = (d.n_sizes + 8) / 9;
+                for (int c = 0; c < nkc && ld_ok; c++) {
+                    const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc), kc = ki1 - ki0;
+                    const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
+                    const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum, ssr = ssmax - ssmin + 1;
+                    int np = (int)std::min<int64_t>({ld_np_cap, (int64_t)d.n_pos, 64});
+                    size_t b = 0;
+                    for (; np >= 1; np--) {
+                        b = std::max(mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
+                                     mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
+                        if (b <= 80 * 1024) break;                         // two 512-thread workgroups per compute unit: one builds tables while the other scores
+                    }
+                    if (np < 1 || ssmin < 1) { ld_ok = false; break; }
+                    ld_lds = std::max(ld_lds, b);
+                    for (int p0 = 0; p0 < d.n_pos; p0 += np) { SvrTile t = {i, 0, p0, std::min(np, d.n_pos - p0), ki0, kc}; ldt.push_back(t); }   // both strands
+                }
             }
             if (!svr_possible) continue;
             // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs as long as the tile's LDS allows (more positions
@@ -618,9 +645,14 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                 }
         }
         w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0; w.n_col_tiles = (int)ct.size() - w.col_tile0;
+        w.n_ld_tiles = (int)ldt.size() - w.ld_tile0;
     }
     h->svr_batch_error.clear();
     if (svr_lds > 160 * 1024) { h->svr_batch_error = "an SVR tile needs more than 160 KiB of LDS: capture range / arm lists too wide"; st.clear(); for (Window& w : h->windows) { w.svr_tile0 = 0; w.n_svr_tiles = 0; } svr_lds = 0; }
+    if (!ld_ok) { ldt.clear(); ld_lds = 0; }
+    h->ld_lds = ld_lds;
+    if (h->ld_tiles.reserve(std::max<size_t>(ldt.size(), 1))) return MIPGEN_E_NOMEM;
+    if (!ldt.empty()) HIP_TRY(hipMemcpyAsync(h->ld_tiles.p, ldt.data(), ldt.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
     if (h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
         h->scores.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) || h->records.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) ||
         h->emitted.reserve((size_t)std::max<int64_t>(win_cand_max, 1)))
@@ -713,8 +745,13 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method)
     hipEvent_t* ev = nullptr;
     if (h->timing) { if (ensure_events(h)) return MIPGEN_E_HIP; ev = &h->ev[4 * (size_t)w]; }
     if (ev) HIP_TRY(hipEventRecord(ev[0], h->stream));
-    HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
-                                           h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
+    if (method == MIPGEN_SCORE_LOGISTIC && h->ld_lds > 0)
+        // records + logistic scores from per-window tables (kernels_logistic_dense.hip)
+        HIP_TRY(mipgen_launch_logistic_dense(h->stream, W.n_ld_tiles, h->ld_lds, h->dp, h->regions.p, h->ld_tiles.p + W.ld_tile0, h->bases.p, h->copy.p,
+                                             h->unmap.p, h->dconsts, h->scores.p, h->records.p));
+    else
+        HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
+                                               h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
     if (ev) HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (method == MIPGEN_SCORE_SVR) {
         const double gamma_l2e = h->gamma * 1.4426950408889634074;

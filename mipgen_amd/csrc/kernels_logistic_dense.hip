@@ -1,0 +1,283 @@
+// kernels_logistic_dense.hip — dense-grid integer records + logistic scores with per-window tables (gfx950).
+//
+// Same outputs as k_records_logistic<true> (kernels_logistic.hip): for every dense-grid candidate the 8-byte record of design_mip
+// (/root/reference/mipgen.cpp:599-762) and SVMipv4::get_score (/root/reference/SVMipv4.cpp:114-248).  That kernel evaluates all 69
+// terms of the exponent and walks the copy / mappability tables per candidate (430 VALU instructions per candidate-wave: 12 % of the
+// HBM roofline of its 16 B per candidate).  Here the exponent is regrouped by sequence window (logistic_groups.h, generated from the
+// model header):
+//     exponent = (C0 - C1) + fE + fL + fT + LG*gLG + LLC*gLLC + LLEN*gLLEN + JS*gJS + LA*gLA + BPS*(hE + hL) + TGC*(hE' + hL') + TA*hL''
+// where fE / g* / hE* depend only on the extension-arm window, fL / hL* on the ligation-arm window and fT on the insert.  A workgroup
+// (region, run of positions, run of <= 9 capture sizes; both strands, one after the other; 512 threads, <= 80 KB of LDS so that two
+// workgroups share a compute unit and one builds tables while the other scores) builds one table entry per distinct
+// arm window (8 doubles + a packed integer word: copy number, masked-N / SNP counts, guard, junction; the global copy / mappability
+// gathers happen HERE, once per window, not once per candidate) and per insert window (4 doubles), then a wavefront takes one
+// (position, capture size) row at a time with its lanes on the arm pairs: a candidate is ~20 LDS reads, a dozen FMAs, one exp2, one
+// division, and the two 8-byte stores of a row are contiguous.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "device_utils.h"
+#include "logistic_device.h"
+#include "logistic_groups.h"
+
+#define LD_THREADS 512
+#define LD_ARM_STRIDE 9              // doubles per arm-window entry: 8 values + one packed 64-bit word
+#define LD_INS_STRIDE 4              // fT, BPS, TGC, TA
+
+// shared with the host (tile sizing)
+extern "C" size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn)
+{
+    const int nq = np + ssr - 1;
+    const int span = np + ssmax + 2 * Lmax + 2;
+    size_t b = 0;
+    b += (size_t)3 * (span + 1) * 8 + 64;                       // W0..W2 prefix words + scan scratch
+    const int n_max = n_up > n_dn ? n_up : n_dn;                 // both strands reuse the tables: sized for either role assignment
+    b += (size_t)np * n_max * LD_ARM_STRIDE * 8;                 // upstream arm windows
+    b += (size_t)nq * n_max * LD_ARM_STRIDE * 8;                 // downstream arm windows
+    b += (size_t)np * ssr * LD_INS_STRIDE * 8;                   // insert windows
+    b += (size_t)np * n_max * 2 + 16;                            // mappability masks of the upstream windows (bit per capture size of the tile)
+    b += (size_t)span + 16;                                      // bases
+    return (b + 15) & ~(size_t)15;
+}
+
+namespace {
+
+// packed integer word of an arm window
+//   bits  0..31  copy number (as the table holds it; 1 when there is no table)
+//   bits 32..39  masked-sequence N count      40..47 SNP count      48..55 SNPs without an alternate-allele arm
+//   bit  56      an SNP with an alternate-allele arm      bit 57  N or '-' in the window (guard)
+//   bits 58..62  junction code 4*b0+b1 of the oriented ligation arm, 16 = not ACGT (ligation-role windows only)
+__device__ __forceinline__ uint64_t pack_word(int copy, uint32_t masked, uint32_t snp_any, uint32_t snp_bad, bool snp_ok, bool guard, uint32_t jc)
+{
+    return (uint64_t)(uint32_t)copy | ((uint64_t)min(masked, 255u) << 32) | ((uint64_t)min(snp_any, 255u) << 40) | ((uint64_t)min(snp_bad, 255u) << 48) |
+           ((uint64_t)snp_ok << 56) | ((uint64_t)guard << 57) | ((uint64_t)jc << 58);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
+    const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, const SvrTile* __restrict__ tiles, int n_tiles,
+    const uint8_t* __restrict__ bases, const int32_t* __restrict__ copy, const uint8_t* __restrict__ unmap,
+    const HostConsts* __restrict__ HC, double* __restrict__ scores, uint64_t* __restrict__ records)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const SvrTile tile = tiles[xcd_remap(blockIdx.x, n_tiles)];
+    const DevRegion& R = regions[tile.region];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, NW = LD_THREADS / WAVE;
+    const int A = P->n_pairs, nK = R.n_sizes, inc = P->inc;
+    const int Lmax = max(P->e_max, P->l_max);
+    const int Cmax_t = P->max_capture - (R.k0 + tile.ki0) * inc, Cmin_t = Cmax_t - (tile.kc - 1) * inc;
+    const int ssmax = Cmax_t - P->min_sum, ssmin = Cmin_t - P->max_sum, ssr = ssmax - ssmin + 1;
+    const int np = tile.np, nq = np + ssr - 1;
+    const int n_e = P->e_max - P->e_min + 1, n_l = P->l_max - P->l_min + 1, n_max = max(n_e, n_l);
+    const int p_first = R.first_pos + tile.p0;
+    const int lo = p_first - Lmax;                                     // chromosome coordinate of local base 0
+    const int span = np + ssmax + 2 * Lmax + 2;
+
+    uint64_t* W0 = (uint64_t*)smem;
+    uint64_t* W1 = W0 + (span + 1);
+    uint64_t* W2 = W1 + (span + 1);
+    uint64_t* scratch = W2 + (span + 1);                               // 8
+    double* TU = (double*)(scratch + 8);
+    double* TD = TU + (size_t)np * n_max * LD_ARM_STRIDE;
+    double* TT = TD + (size_t)nq * n_max * LD_ARM_STRIDE;
+    uint16_t* UM = (uint16_t*)(TT + (size_t)np * ssr * LD_INS_STRIDE);
+    uint8_t* sb = (uint8_t*)(UM + (size_t)np * n_max + 8);
+
+    // ---- stage bases and the packed prefix words (as k_records_logistic) ---------------------------------------------------------
+    for (int i = tid; i < span; i += LD_THREADS) {
+        const int ri = lo + i - R.seq_start;
+        sb[i] = (ri >= 0 && ri < R.seq_len) ? bases[R.seq_off + ri] : (uint8_t)BASE_OTHER;
+    }
+    __syncthreads();
+    for (int i = tid; i < span; i += LD_THREADS) {
+        const uint8_t b = sb[i];
+        const int c = b & BASE_CODE_MASK, snp = (b >> BASE_SNP_SHIFT) & 3;
+        int sw = 0;
+        if (i > 0) {
+            const int cp = sb[i - 1] & BASE_CODE_MASK;
+            sw = ((c == BASE_G || c == BASE_C) != (cp == BASE_G || cp == BASE_C));
+        }
+        W0[i] = (uint64_t)(c == BASE_A) | ((uint64_t)(c == BASE_C) << 16) | ((uint64_t)(c == BASE_G) << 32) | ((uint64_t)(c == BASE_N || c == BASE_DASH) << 48);
+        W1[i] = (uint64_t)((b & BASE_MASKED_BIT) != 0) | ((uint64_t)(snp != 0) << 16) | ((uint64_t)(snp == 2) << 32) | ((uint64_t)(snp == 1) << 48);
+        W2[i] = (uint64_t)sw | ((uint64_t)(c >= 4) << 16);
+    }
+    __syncthreads();
+    block_exclusive_scan_u64(W0, span, scratch);
+    block_exclusive_scan_u64(W1, span, scratch);
+    block_exclusive_scan_u64(W2, span, scratch);
+
+    // Both strands of the tile, one after the other: the '+' and '-' rows of a (position, capture size) are neighbours in the result
+    // arrays (912 bytes together), so writing them from the same compute unit a few microseconds apart lets L2 merge them into full lines
+    // (a per-strand tile can only ever write half of every line).  The prefix words are shared; the tables are rebuilt per strand.
+    for (int strand = 0; strand < 2; strand++) {
+    const bool minus = strand != 0;
+    // roles: the upstream arm of p is the extension arm on '+', the ligation arm on '-'; the downstream arm the other one
+    const int up_min = minus ? +P->l_min : +P->e_min, dn_min = minus ? +P->e_min : +P->l_min;
+    const int n_up = minus ? n_l : n_e, n_dn = minus ? n_e : n_l;
+    if (strand) __syncthreads();                                      // every wavefront is done with the '+' tables
+    // ---- arm-window entries ----------------------------------------------------------------------------------------------------------
+    // entry w < nU: upstream window ending at position pl (start = Lmax + pl - len); else downstream window starting at q (= Lmax + ssmin + q)
+    const int nU = np * n_up, nD = nq * n_dn;
+    for (int w = tid; w < nU + nD; w += LD_THREADS) {
+        const bool up = w < nU;
+        int wl, li, len, s;
+        if (up) { wl = w / n_up; li = w - wl * n_up; len = up_min + li; s = Lmax + wl - len; }
+        else { const int w2 = w - nU; wl = w2 / n_dn; li = w2 - wl * n_dn; len = dn_min + li; s = Lmax + ssmin + wl; }
+        const bool lig_role = up ? minus : !minus;
+        const uint64_t d0 = W0[s + len] - W0[s], d1 = W1[s + len] - W1[s], d2 = W2[s + len] - W2[s];
+        const uint32_t nA = f16(d0, 0), nC = f16(d0, 1), nG = f16(d0, 2), nBad = f16(d0, 3), nOther = f16(d2, 1);
+        const uint32_t nT = (uint32_t)len - nA - nC - nG - nOther;
+        // copy number of the oligo, mipgen.cpp:612-613 (absent key -> 0)
+        int cp = 1;
+        const int start_chr = lo + s;                                  // chromosome coordinate of the window start
+        if (R.copy_off >= 0) {
+            const int slot = P->len_slot[len], ri = start_chr - R.seq_start;
+            cp = (slot >= 0 && ri >= 0 && ri < R.seq_len) ? copy[R.copy_off + (int64_t)slot * R.seq_len + ri] : 0;
+        }
+        uint32_t jc = 16;
+        if (lig_role) {
+            int j0, j1;
+            if (!minus) { j0 = sb[s] & BASE_CODE_MASK; j1 = sb[s + 1] & BASE_CODE_MASK; }
+            else { j0 = comp_code(sb[s + len - 1] & BASE_CODE_MASK); j1 = comp_code(sb[s + len - 2] & BASE_CODE_MASK); }
+            if (j0 < 4 && j1 < 4) jc = (uint32_t)(4 * j0 + j1);
+        }
+        double* e = (up ? TU : TD) + (size_t)(up ? wl * n_up + li : wl * n_dn + li) * LD_ARM_STRIDE;
+        // oriented base contents: the reverse complement swaps A<->T and C<->G
+        const double rl = 1.0 / (double)len, dl = (double)len;
+        const double a_c = (double)(minus ? nT : nA) * rl, g_c = (double)(minus ? nC : nG) * rl, gc_c = (double)(nC + nG) * rl;
+        const double lcopy = log_copy_dev(HC, cp);
+        if (!lig_role) {
+            e[0] = MLG_FE(a_c, g_c, gc_c, dl, lcopy);
+            e[1] = MLG_G_LG(a_c, g_c, gc_c, dl, lcopy); e[2] = MLG_G_LLC(a_c, g_c, gc_c, dl, lcopy); e[3] = MLG_G_LLEN(a_c, g_c, gc_c, dl, lcopy);
+            e[4] = MLG_G_JS(a_c, g_c, gc_c, dl, lcopy); e[5] = MLG_G_LA(a_c, g_c, gc_c, dl, lcopy);
+            e[6] = MLG_HE_BPS(a_c, g_c, gc_c, dl, lcopy); e[7] = MLG_HE_TGC(a_c, g_c, gc_c, dl, lcopy);
+        } else {
+            const double js = jc < 16 ? c_junction_scores[jc] : 0.0;
+            e[0] = MLG_FL(gc_c, g_c, js, a_c, dl, lcopy);
+            e[1] = g_c; e[2] = lcopy; e[3] = js; e[4] = a_c;
+            e[5] = MLG_HL_BPS(gc_c, g_c, js, a_c, dl, lcopy); e[6] = MLG_HL_TA(gc_c, g_c, js, a_c, dl, lcopy); e[7] = MLG_HL_TGC(gc_c, g_c, js, a_c, dl, lcopy);
+        }
+        ((uint64_t*)e)[8] = pack_word(cp, f16(d1, 0), f16(d1, 1), f16(d1, 2), f16(d1, 3) != 0, nBad != 0, jc);
+        if (up) {
+            // mapping flag, mipgen.cpp:615-625: the MIP starts at its upstream arm on either strand; one bit per capture size of the tile
+            uint32_t mask = 0;
+            if (R.unmap_off >= 0 && P->check_copy_number) {
+                const int ms = start_chr - R.seq_start;
+                if (ms >= 0 && ms < R.seq_len)
+                    for (int k = 0; k < tile.kc; k++) mask |= (uint32_t)(unmap[R.unmap_off + (int64_t)(R.k0 + tile.ki0 + k) * R.seq_len + ms] != 0) << k;
+            }
+            UM[wl * n_up + li] = (uint16_t)mask;
+        }
+    }
+    // ---- insert-window entries (position pl, scan size ssmin + ssi) ------------------------------------------------------------------------
+    for (int w = tid; w < np * ssr; w += LD_THREADS) {
+        const int pl = w / ssr, ssi = w - pl * ssr, ss = ssmin + ssi, bi = Lmax + pl;
+        double* t = TT + (size_t)w * LD_INS_STRIDE;
+        if (ss <= 0) { t[0] = 0.0; t[1] = 0.0; t[2] = 0.0; t[3] = 0.0; continue; }
+        const uint64_t t0 = W0[bi + ss] - W0[bi], t2 = W2[bi + ss] - W2[bi];
+        const uint32_t tA = f16(t0, 0), tC = f16(t0, 1), tG = f16(t0, 2), t_other = f16(t2, 1);
+        const uint32_t tT = (uint32_t)ss - tA - tC - tG - t_other;
+        int run;
+        if (t_other == 0) run = 1 + (int)(f16(W2[bi + ss], 0) - f16(W2[bi + 1], 0));        // GC/AT class switches inside the window, SVMipv4.cpp:118-142
+        else run = run_count_slow(sb, bi, ss, minus);
+        const double dn = (double)ss, rn = 1.0 / dn;
+        const double bps = dn / (double)run, tlen = ss > 250 ? 250.0 : dn;
+        const double ta = (double)(minus ? tT : tA) * rn, tg = (double)(minus ? tC : tG) * rn, tgc = (double)(tC + tG) * rn;
+        t[0] = MLG_FT(bps, tlen, ta, tgc, tg); t[1] = bps; t[2] = tgc; t[3] = ta;
+    }
+    __syncthreads();
+
+    // ---- candidates: one (position, capture size) row per wavefront pass, lanes on the arm pairs ----------------------------------------
+    const double thr = P->masked_arm_threshold;
+    const double x0 = MIPGEN_LOGISTIC_C0 - MIPGEN_LOGISTIC_C1;
+    const int n_rows = np * tile.kc;
+    for (int a0 = 0; a0 < A; a0 += WAVE) {
+        const int a = a0 + lane;
+        const bool have = a < A;
+        const int e = have ? P->arm_ext[a] : 2, l = have ? P->arm_lig[a] : 2, S = e + l;
+        const int ulen = minus ? l : e, dlen = minus ? e : l;
+        const int u_col = ulen - up_min, d_col = dlen - dn_min;
+        const double dl_lig = (double)l;
+        // masking_failed is "masked N count / (l + e) > threshold" (mipgen.cpp:610,626): the smallest count that satisfies it, found with the
+        // reference's own double division once per pair - the candidates then compare integers
+        int mthr;
+        {
+            const double den = (double)(l + e);
+            const double est = thr * den;
+            mthr = est >= 1.0 ? (est < den + 2.0 ? (int)est - 1 : l + e + 1) : 0;      // a safe start just below the boundary, then <= 3 exact tests
+            while (mthr <= l + e && !((double)mthr / den > thr)) mthr++;
+        }
+        // LDS byte offsets of the pair's table columns (32-bit arithmetic in the row loop)
+        const uint32_t u_off = (uint32_t)u_col * (LD_ARM_STRIDE * 8), d_off = (uint32_t)d_col * (LD_ARM_STRIDE * 8);
+        const uint32_t u_pitch = (uint32_t)n_up * (LD_ARM_STRIDE * 8), d_pitch = (uint32_t)n_dn * (LD_ARM_STRIDE * 8), t_pitch = (uint32_t)ssr * (LD_INS_STRIDE * 8);
+        typedef __attribute__((address_space(3))) const double lds_cd;
+        typedef __attribute__((address_space(3))) const uint64_t lds_cq;
+        const uint32_t tu_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TU, td_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TD, tt_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TT;
+        for (int row = wid; row < n_rows; row += NW) {
+            const int pl = row / tile.kc, kci = row - pl * tile.kc;
+            const int C = Cmax_t - kci * inc, p = p_first + pl, ss = C - S;
+            const int64_t out = R.out_off + ((((int64_t)(tile.p0 + pl) * nK + (tile.ki0 + kci)) * 2 + (minus ? 1 : 0)) * A) + a;
+            if (!have) continue;
+            // bounds skips, mipgen.cpp:443-444
+            const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) && ss > 0;
+            uint64_t rec = 0;
+            double score = 0.0;
+            if (valid) {
+                const uint32_t ua = tu_a + __umul24((uint32_t)pl, u_pitch) + u_off;
+                const uint32_t da = td_a + __umul24((uint32_t)(pl + ss - ssmin), d_pitch) + d_off;
+                lds_cd* T = (lds_cd*)(unsigned long)(tt_a + __umul24((uint32_t)pl, t_pitch) + (uint32_t)(ss - ssmin) * (LD_INS_STRIDE * 8));
+                lds_cd* Ee = (lds_cd*)(unsigned long)(minus ? da : ua);    // extension-role entry
+                lds_cd* Le = (lds_cd*)(unsigned long)(minus ? ua : da);    // ligation-role entry
+                const uint64_t we = ((lds_cq*)Ee)[8], wl_ = ((lds_cq*)Le)[8];
+                const int ext_copy = (int)(uint32_t)we, lig_copy = (int)(uint32_t)wl_;
+                const bool guard = ((we | wl_) >> 57) & 1;
+                const bool mapping = (UM[pl * n_up + u_col] >> kci) & 1;
+                const uint32_t masked_n = (uint32_t)((we >> 32) & 0xFF) + (uint32_t)((wl_ >> 32) & 0xFF);
+                uint32_t flags = MIPGEN_FLAG_VALID | (guard ? MIPGEN_FLAG_GUARD : 0u), snp_count = 0;
+                if (mapping) flags |= MIPGEN_FLAG_MAPPING;                  // early return of design_mip: masking / SNP fields stay at their defaults
+                else {
+                    if ((int)masked_n >= mthr) flags |= MIPGEN_FLAG_MASKING;                                        // :610,626
+                    snp_count = (uint32_t)((we >> 40) & 0xFF) + (uint32_t)((wl_ >> 40) & 0xFF);
+                    const uint32_t snp_bad = (uint32_t)((we >> 48) & 0xFF) + (uint32_t)((wl_ >> 48) & 0xFF);
+                    if (snp_bad != 0 || snp_count > 1) flags |= MIPGEN_FLAG_SNP;                                   // :690-693,759-760
+                    if (((we | wl_) >> 56) & 1) flags |= MIPGEN_FLAG_HAS_SNP_MIP;
+                }
+                const uint32_t jraw = (uint32_t)((wl_ >> 58) & 31);
+                const uint32_t jc = jraw < 16 ? jraw : 255u;
+                const uint32_t ec = (uint32_t)min(max(ext_copy, 0), 65535), lc = (uint32_t)min(max(lig_copy, 0), 65535);
+                rec = (uint64_t)ec | ((uint64_t)lc << 16) | ((uint64_t)min(masked_n, 255u) << 32) | ((uint64_t)min(snp_count, 255u) << 40) |
+                      ((uint64_t)flags << 48) | ((uint64_t)jc << 56);
+                if (guard) score = -1000.0;                                // SVMipv4.cpp:116
+                else if (ext_copy <= 0 || lig_copy <= 0) score = __longlong_as_double(0xFFF8000000000000LL);   // log10(0) = -inf (or NaN) meets terms of both signs: NaN
+                else {
+                    double x = x0 + Ee[0];
+                    x += Le[0];
+                    x += T[0];
+                    x = fma(Le[1], Ee[1], x);                              // LG  * gLG
+                    x = fma(Le[2], Ee[2], x);                              // LLC * gLLC
+                    x = fma(dl_lig, Ee[3], x);                             // LLEN * gLLEN
+                    x = fma(Le[3], Ee[4], x);                              // JS  * gJS
+                    x = fma(Le[4], Ee[5], x);                              // LA  * gLA
+                    x = fma(T[1], Ee[6] + Le[5], x);                       // BPS * (hE + hL)
+                    x = fma(T[2], Ee[7] + Le[7], x);                       // TGC * (hE + hL)
+                    x = fma(T[3], Le[6], x);                               // TA  * hL
+                    score = logistic_from_exponent_rcp(HC, x);
+                }
+            }
+            records[out] = rec;
+            scores[out] = score;
+        }
+    }
+    }   // strand
+}
+
+extern "C" hipError_t mipgen_launch_logistic_dense(hipStream_t stream, int n_tiles, size_t lds_bytes, const DevParams* P, const DevRegion* regions,
+                                                   const SvrTile* tiles, const uint8_t* bases, const int32_t* copy, const uint8_t* unmap,
+                                                   const HostConsts* HC, double* scores, uint64_t* records)
+{
+    if (n_tiles <= 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)k_logistic_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records);
+    return hipGetLastError();
+}
