@@ -30,6 +30,7 @@ hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t
 hipError_t mipgen_launch_candidates(hipStream_t, int n, const DevParams*, const DevRegion*, const mipgen_candidate*, const uint8_t*,
                                     const int32_t*, const uint8_t*, const HostConsts*, const double* model, int n_sv, double gamma,
                                     double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*);
+hipError_t mipgen_launch_svr_batch(hipStream_t, int n, const double* feats, const uint64_t* records, const double* model, int n_sv, double gamma, double rho, double* scores);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
@@ -887,9 +888,14 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
         (features && h->cand_feats.reserve((size_t)n * MIPGEN_N_FEATURES)) || (ints && h->cand_ints.reserve((size_t)n)))
         return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpyAsync(h->cand_in.p, cands, (size_t)n * sizeof(mipgen_candidate), hipMemcpyHostToDevice, h->stream));
+    // long SVR lists (a mixed design re-scores every condensed survivor): features per candidate first, then the model streamed through LDS
+    // once per 32 candidates (k_svr_batch) instead of once per candidate
+    const bool batched = method == MIPGEN_SCORE_SVR && n >= 256 && scores;
+    if (batched && h->cand_feats.reserve((size_t)n * MIPGEN_N_FEATURES)) return MIPGEN_E_NOMEM;
     HIP_TRY(mipgen_launch_candidates(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
-                                     h->model.p, h->n_sv, h->gamma, h->rho, method, h->cand_scores.p, h->cand_records.p,
-                                     features ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
+                                     h->model.p, h->n_sv, h->gamma, h->rho, method, batched ? nullptr : h->cand_scores.p, h->cand_records.p,
+                                     (features || batched) ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
+    if (batched) HIP_TRY(mipgen_launch_svr_batch(h->stream, n, h->cand_feats.p, h->cand_records.p, h->model.p, h->n_sv, h->gamma, h->rho, h->cand_scores.p));
     if (scores) HIP_TRY(hipMemcpyAsync(scores, h->cand_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (records) HIP_TRY(hipMemcpyAsync(records, h->cand_records.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     if (features) HIP_TRY(hipMemcpyAsync(features, h->cand_feats.p, (size_t)n * MIPGEN_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -305,3 +305,79 @@ extern "C" hipError_t mipgen_launch_long_range(hipStream_t stream, int n, const 
     hipLaunchKernelGGL(k_long_range, dim3(n), dim3(256), 0, stream, seqs, offs, lens, denoms, *M, out_dev);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_svr_batch: the RBF-SVR of a LIST of candidates from their 192 features (mixed designs re-score every condensed survivor).
+// k_candidates walks the whole model per candidate (n_sv x 192 doubles from L2 per candidate: ~0.4 us each, bound by model traffic).
+// Here a workgroup takes 32 candidates and streams the model through LDS in chunks of 64 support vectors, so a model row is read
+// once per 32 candidates; a thread owns 4 candidates x 2 support vectors (6 LDS reads feed 8 subtract + multiply-add pairs per
+// dimension: FP64-issue bound, not LDS bound).  Same arithmetic as svm.cpp:329-368, 2511-2515: sum_j (x_j - sv_j)^2 in index order per
+// (candidate, SV), exp(-gamma d2), coefficient-weighted sum (the order of that last sum differs from the reference's: ~1e-13).
+// ---------------------------------------------------------------------------------------------------------
+#define SB_CANDS 32
+#define SB_SVS 64
+#define SB_PITCH 193                 // doubles per staged row (192 features + 1: odd pitch spreads the banks)
+
+__global__ __launch_bounds__(256) void k_svr_batch(int n, const double* __restrict__ feats, const uint64_t* __restrict__ records,
+                                                   const double* __restrict__ model, int n_sv, double gamma, double rho, double* __restrict__ scores)
+{
+    extern __shared__ __align__(16) double sm[];
+    double* X = sm;                                   // [SB_CANDS][SB_PITCH]
+    double* S = X + SB_CANDS * SB_PITCH;              // [SB_SVS][SB_PITCH]
+    double* aux = S + SB_SVS * SB_PITCH;              // [SB_SVS][2]: coef, extra |sv|^2 of libsvm indices > 192
+    double* red = aux + SB_SVS * 2;                   // [32 sgrps][SB_CANDS]
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * SB_CANDS;
+    for (int i = tid; i < SB_CANDS * MIPGEN_N_FEATURES; i += 256) {
+        const int c = i / MIPGEN_N_FEATURES, j = i - c * MIPGEN_N_FEATURES;
+        X[c * SB_PITCH + j] = (c0 + c < n) ? feats[(int64_t)(c0 + c) * MIPGEN_N_FEATURES + j] : 0.0;
+    }
+    const int cg = tid & 7, sg = tid >> 3;            // 8 candidate groups of 4, 32 SV lanes of 2
+    const double* x0 = X + (cg * 4 + 0) * SB_PITCH; const double* x1 = x0 + SB_PITCH; const double* x2 = x1 + SB_PITCH; const double* x3 = x2 + SB_PITCH;
+    double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, sum3 = 0.0;
+    for (int s0 = 0; s0 < n_sv; s0 += SB_SVS) {
+        __syncthreads();
+        for (int i = tid; i < SB_SVS * MIPGEN_N_FEATURES; i += 256) {
+            const int s = i / MIPGEN_N_FEATURES, j = i - s * MIPGEN_N_FEATURES;
+            S[s * SB_PITCH + j] = (s0 + s < n_sv) ? model[(int64_t)(s0 + s) * SV_ROW + j] : 0.0;
+        }
+        if (tid < SB_SVS) {
+            aux[2 * tid] = (s0 + tid < n_sv) ? model[(int64_t)(s0 + tid) * SV_ROW + SVR_COEF] : 0.0;       // padding rows: coefficient 0
+            aux[2 * tid + 1] = (s0 + tid < n_sv) ? model[(int64_t)(s0 + tid) * SV_ROW + SVR_N_EXTRA] : 0.0;
+        }
+        __syncthreads();
+        const double* va = S + (sg * 2) * SB_PITCH; const double* vb = va + SB_PITCH;
+        double d0a = 0, d1a = 0, d2a = 0, d3a = 0, d0b = 0, d1b = 0, d2b = 0, d3b = 0;
+#pragma unroll 4
+        for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
+            const double a = va[j], b = vb[j], p0 = x0[j], p1 = x1[j], p2 = x2[j], p3 = x3[j];
+            double t;
+            t = p0 - a; d0a = fma(t, t, d0a); t = p1 - a; d1a = fma(t, t, d1a); t = p2 - a; d2a = fma(t, t, d2a); t = p3 - a; d3a = fma(t, t, d3a);
+            t = p0 - b; d0b = fma(t, t, d0b); t = p1 - b; d1b = fma(t, t, d1b); t = p2 - b; d2b = fma(t, t, d2b); t = p3 - b; d3b = fma(t, t, d3b);
+        }
+        const double ca = aux[4 * sg], ea = aux[4 * sg + 1], cb = aux[4 * sg + 2], eb = aux[4 * sg + 3];
+        sum0 += ca * exp(-gamma * (d0a + ea)) + cb * exp(-gamma * (d0b + eb));
+        sum1 += ca * exp(-gamma * (d1a + ea)) + cb * exp(-gamma * (d1b + eb));
+        sum2 += ca * exp(-gamma * (d2a + ea)) + cb * exp(-gamma * (d2b + eb));
+        sum3 += ca * exp(-gamma * (d3a + ea)) + cb * exp(-gamma * (d3b + eb));
+    }
+    __syncthreads();
+    red[sg * SB_CANDS + cg * 4 + 0] = sum0; red[sg * SB_CANDS + cg * 4 + 1] = sum1; red[sg * SB_CANDS + cg * 4 + 2] = sum2; red[sg * SB_CANDS + cg * 4 + 3] = sum3;
+    __syncthreads();
+    if (tid < SB_CANDS && c0 + tid < n) {
+        double s = 0.0;
+        for (int k = 0; k < 32; k++) s += red[k * SB_CANDS + tid];
+        scores[c0 + tid] = (MIPGEN_REC_FLAGS(records[c0 + tid]) & MIPGEN_FLAG_VALID) ? s - rho : 0.0;     // a candidate the bounds skips remove scores 0, as in k_candidates
+    }
+}
+
+extern "C" hipError_t mipgen_launch_svr_batch(hipStream_t stream, int n, const double* feats, const uint64_t* records, const double* model, int n_sv, double gamma,
+                                              double rho, double* scores)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t lds = (size_t)(SB_CANDS * SB_PITCH + SB_SVS * SB_PITCH + SB_SVS * 2 + 32 * SB_CANDS) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)k_svr_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_svr_batch, dim3((n + SB_CANDS - 1) / SB_CANDS), dim3(256), lds, stream, n, feats, records, model, n_sv, gamma, rho, scores);
+    return hipGetLastError();
+}

@@ -627,3 +627,37 @@ def test_collapse_on_device(name, genome):
     acc.score_condense_all(method)
     assert np.array_equal(acc.download_collapsed(-1), np.concatenate(per_window))
     acc.close()
+
+
+def test_batched_candidate_rescoring(genome):
+    """Lists of >= 256 candidates take the batched SVR kernel (features per candidate, then the model streamed through LDS once per 32
+    candidates): same scores as the one-workgroup-per-candidate kernel and as the oracle, incl. guard / zero-copy / invalid candidates."""
+    meta = H.load_design("mixed_small")
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_200.model")
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    om = po.Model(mp)
+    grids = acc.upload(regions)
+    rng = np.random.default_rng(6)
+    A = P.n_arm_pairs
+    cands = []
+    for ri, g in enumerate(grids):
+        for idx in rng.choice(g.count, size=700, replace=False):
+            a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
+            ki, pi = rest % g.n_sizes, rest // g.n_sizes
+            cands.append((ri, g.first_pos + int(pi), P.max_capture_size - (g.first_size_index + int(ki)) * P.capture_increment, P.arm_ext[int(a)], P.arm_lig[int(a)], int(strand)))
+    cands.append((0, 3, 130, 20, 22, 0))                                    # fails the bounds skips
+    batched, rec_b, _, _ = acc.score_candidates(cands, capi.SCORE_SVR)
+    single = np.concatenate([acc.score_candidates(cands[i:i + 100], capi.SCORE_SVR)[0] for i in range(0, len(cands), 100)])
+    assert np.nanmax(np.abs(batched - single)) < 1e-11
+    assert batched[-1] == 0.0 and (capi.rec_flags(rec_b[-1:]) & capi.FLAG_VALID)[0] == 0
+    n_guard = 0
+    for k in rng.choice(len(cands) - 1, size=250, replace=False):
+        c = cands[int(k)]
+        sk, d = po.design(P, regions[c[0]], (0,) + c[1:])
+        so, _, _ = po.score_designed(d, capi.SCORE_SVR, np.array(regions[c[0]].c.long_range_content[:]), om)
+        assert abs(batched[int(k)] - so) <= 1e-5 or (np.isnan(so) and np.isnan(batched[int(k)])), (c, batched[int(k)], so)
+        n_guard += int((capi.rec_flags(rec_b[int(k):int(k) + 1]) & capi.FLAG_GUARD)[0] != 0)
+    acc.close()
