@@ -21,6 +21,7 @@
  *   mipgen.cpp:426-437,494-497  score-dependent early exits (replay)               mipgen_accel_replay_condense()
  *   mipgen.cpp:1670-1746 condense_mips                                             mipgen_accel_replay_condense()
  *   mipgen.cpp:1616-1649 collapse_mips                                             mipgen_accel_collapse()
+ *   mipgen.cpp:765-794   print_details (all_mips records)                          mipgen_accel_format_all_mips()
  *   mipgen.cpp:558-596,825-835 arm-oligo copy numbers through bwa                  mipgen_accel_count_oligo_copies()  (opt-in, exact matches)
  *   mipgen.cpp:412-524   tile_regions in -silent_mode (enumerate + score + condense of    mipgen_accel_score_condense_all()
  *                        every region, nothing kept per candidate)
@@ -286,6 +287,22 @@ int mipgen_accel_collapse(mipgen_accel* h);
 int mipgen_accel_region_bases(const mipgen_accel* h, int32_t region, int64_t* first_entry, int32_t* n_bases);
 /* window >= 0: the entries of that window's regions; window < 0: the whole batch (after mipgen_accel_score_condense_all) */
 int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* best_scan_index, int64_t capacity);
+
+/* ---- section 8f-4: the all_mips records of a window, formatted on the device -----------------------------------------------------
+ * print_details (mipgen.cpp:765-794) for every candidate the replay marked as constructed, in the reference's generation order
+ * (position, capture size, arm pair, plus then minus), numbered from first_index + 1 (the running all_mip_counter, mipgen.cpp:474,488):
+ * 20 tab-separated columns, scores as printf("%g"), copy numbers from the copy table, mip_sequence = lig + middle + ext.
+ * Call after mipgen_accel_replay_condense on the scored window; names[i] describes region i of that window. */
+typedef struct mipgen_record_names {
+    const char* chr;                 /* Featurev5::chr */
+    const char* label;               /* Featurev5::label */
+    int32_t feature_start;           /* start_position - 1 (mipgen.cpp:788) */
+    int32_t feature_stop;            /* stop_position (:789) */
+} mipgen_record_names;
+int mipgen_accel_format_all_mips(mipgen_accel* h, const mipgen_record_names* names, const char* middle, int64_t first_index,
+                                 int64_t* n_records, int64_t* n_bytes);
+/* the text of the last mipgen_accel_format_all_mips (n_bytes bytes, no terminator) */
+int mipgen_accel_download_text(mipgen_accel* h, char* dst, int64_t capacity);
 
 /* ---- section 8f-3 (opt-in): arm-oligo copy numbers without the bwa round trip ----------------------------------------------------
  * Replaces check_copy_numbers / find_copy's oligo half (mipgen.cpp:825-835 writes every arm oligo to a FASTQ file, :558-596 reads bwa's

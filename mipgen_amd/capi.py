@@ -68,6 +68,10 @@ class Survivor(C.Structure):
     _fields_ = [("cand_index", C.c_int64), ("score", C.c_double), ("record", C.c_uint64)]
 
 
+class RecordNames(C.Structure):
+    _fields_ = [("chr", C.c_char_p), ("label", C.c_char_p), ("feature_start", C.c_int32), ("feature_stop", C.c_int32)]
+
+
 SURVIVOR_DTYPE = np.dtype([("cand_index", "<i8"), ("score", "<f8"), ("record", "<u8")])
 INTS_FIELDS = [f[0] for f in CandidateInts._fields_]
 
@@ -289,12 +293,14 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_download_collapsed.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     lib.mipgen_accel_count_oligo_copies.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, C.c_int32, i32p,
                                                     C.POINTER(C.POINTER(C.c_int32))]
+    lib.mipgen_accel_format_all_mips.argtypes = [vp, C.POINTER(RecordNames), C.c_char_p, C.c_int64, i64p, i64p]
+    lib.mipgen_accel_download_text.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
     for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies"):
+                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "format_all_mips", "download_text"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -311,7 +317,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_set_window_candidates", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
-    "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies",
+    "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
 ]
 
 
@@ -417,6 +423,20 @@ class Accel:
         self._check(self.lib.mipgen_accel_count_oligo_copies(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
                                                              rl.ctypes.data_as(C.POINTER(C.c_int32)), nl, la.ctypes.data_as(C.POINTER(C.c_int32)), op))
         return [{int(k): o[i] for i, k in enumerate(lengths)} for o in outs]
+
+    def format_all_mips(self, names: Sequence[Tuple[str, str, int, int]], middle: bytes, first_index: int = 0) -> Tuple[bytes, int]:
+        """all_mips records of the window replayed last, formatted on the device: (text, number of records)."""
+        arr = (RecordNames * max(len(names), 1))()
+        keep = []
+        for i, (chrom, label, fs, fe) in enumerate(names):
+            a, b = chrom.encode(), label.encode()
+            keep += [a, b]
+            arr[i] = RecordNames(a, b, fs, fe)
+        nrec, nb = C.c_int64(), C.c_int64()
+        self._check(self.lib.mipgen_accel_format_all_mips(self.h, arr, middle, first_index, C.byref(nrec), C.byref(nb)))
+        buf = C.create_string_buffer(max(nb.value, 1))
+        self._check(self.lib.mipgen_accel_download_text(self.h, buf, nb.value))
+        return buf.raw[:nb.value], nrec.value
 
     def collapse(self) -> None:
         self._check(self.lib.mipgen_accel_collapse(self.h))

@@ -40,6 +40,13 @@ hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_p
 size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn);
 hipError_t mipgen_launch_logistic_dense(hipStream_t, int n_tiles, size_t lds_bytes, const DevParams*, const DevRegion*, const SvrTile*, const uint8_t*,
                                         const int32_t*, const uint8_t*, const HostConsts*, double*, uint64_t*);
+struct FmtRegion { int32_t chr_off, chr_len, label_off, label_len, feature_start, feature_stop; int64_t rb0; };
+struct FmtConst { char middle[96]; int32_t middle_len; int32_t n_regions; int64_t first_index; };
+hipError_t mipgen_launch_fmt_count(hipStream_t, int64_t n_rb, int r0, const FmtConst*, const FmtRegion*, const DevParams*, const DevRegion*, const uint8_t* emitted, int64_t* cnt);
+hipError_t mipgen_launch_fmt_records(hipStream_t, int write, int64_t n_rb, int r0, const FmtConst*, const FmtRegion*, const char* pool, const DevParams*, const DevRegion*,
+                                     const char* letters, const int32_t* copy, const double* scores, const uint64_t* records, const uint8_t* emitted,
+                                     const int64_t* rank0, const int64_t* off, int64_t* len_out, char* text);
+hipError_t mipgen_scan_i64(hipStream_t, void* temp, size_t* temp_bytes, const int64_t* in, int64_t* out, int64_t n);
 struct KmerParams { int32_t n_k; int32_t k[MIPGEN_MAX_OLIGO]; int32_t kmax; int32_t pad; uint64_t cap_mask; };
 hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, const KmerParams*, uint64_t* keys);
 hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, unsigned int* counts);
@@ -117,6 +124,12 @@ struct mipgen_accel {
     std::vector<mipgen_grid> grids;
     DevBuf<DevRegion> regions;
     DevBuf<uint8_t> bases, unmap;
+    DevBuf<char> letters;                     // the region strings as given (record formatting prints them; `bases` keeps only classes)
+    // device-side all_mips formatting (section 8f-4)
+    DevBuf<FmtRegion> fmt_regions;
+    DevBuf<char> fmt_pool, fmt_text, fmt_temp;
+    DevBuf<int64_t> fmt_a, fmt_b, fmt_c, fmt_d;
+    int64_t fmt_bytes = -1;
     DevBuf<int32_t> copy;
     DevBuf<LogTile> log_tiles;
     DevBuf<SvrTile> svr_tiles, ld_tiles;      // dense SVR tiles; tiles of the table-based dense logistic kernel (same shape, own sizes)
@@ -311,6 +324,8 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->model.release(); h->regions.release(); h->bases.release(); h->unmap.release(); h->copy.release();
     h->log_tiles.release(); h->svr_tiles.release(); h->ld_tiles.release(); h->scores.release(); h->records.release();
     h->emitted.release(); h->survivors.release(); h->emitted_per_region.release(); h->pos_region.release(); h->pos_local.release();
+    h->letters.release(); h->fmt_regions.release(); h->fmt_pool.release(); h->fmt_text.release(); h->fmt_temp.release();
+    h->fmt_a.release(); h->fmt_b.release(); h->fmt_c.release(); h->fmt_d.release();
     h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
     h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();
@@ -482,12 +497,14 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     if (pos_total > INT32_MAX) return fail(MIPGEN_E_INVALID, "batch has %lld scan positions (max %d): split the design", (long long)pos_total, INT32_MAX);
     // encode + pack on the host
     std::vector<uint8_t> hb((size_t)std::max<int64_t>(seq_total, 1));
+    std::vector<char> hl((size_t)std::max<int64_t>(seq_total, 1));
     std::vector<int32_t> hc((size_t)std::max<int64_t>(copy_total, 1));
     std::vector<uint8_t> hu((size_t)std::max<int64_t>(unmap_total, 1));
     for (int i = 0; i < n; i++) {
         const mipgen_region& R = regions[i];
         const DevRegion& d = h->hregions[i];
         uint8_t* b = &hb[(size_t)d.seq_off];
+        memcpy(&hl[(size_t)d.seq_off], R.seq, (size_t)R.seq_len);
         for (int k = 0; k < R.seq_len; k++) {
             uint8_t v = base_code(R.seq[k]);
             const char m = R.masked_seq ? R.masked_seq[k] : R.seq[k];
@@ -507,6 +524,9 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         if (R.unmappable) memcpy(&hu[(size_t)d.unmap_off], R.unmappable, (size_t)D.n_sizes_all * R.seq_len);
     }
     // inputs -> HBM (everything the kernels read stays resident for the whole batch)
+    if (h->letters.reserve(hl.size())) return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(h->letters.p, hl.data(), hl.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
         h->survivors.reserve((size_t)std::max<int64_t>(2 * pos_total, 1)) || h->emitted_per_region.reserve((size_t)std::max(n, 1)) ||
         h->pos_region.reserve((size_t)std::max<int64_t>(pos_total, 1)) || h->pos_local.reserve((size_t)std::max<int64_t>(pos_total, 1)))
@@ -682,7 +702,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
     h->log_span_max = span_max; h->svr_lds = svr_lds;
-    h->scored = false; h->replayed = false; h->collapsed_valid = false;
+    h->scored = false; h->replayed = false; h->collapsed_valid = false; h->fmt_bytes = -1;
     h->ev_used.assign(h->windows.size(), 0);
 #ifdef MIPGEN_DIAG
     fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates in %zu window(s), %zu record tiles (LDS %zu B), %zu SVR tiles x %d threads (LDS %zu B)\n", n,
@@ -1016,6 +1036,74 @@ int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* be
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (count) HIP_TRY(hipMemcpy(best_scan_index, h->collapsed.p + first, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MIPGEN_OK;
+}
+
+// ---- section 8f-4: all_mips records formatted on the device -----------------------------------------------------------------------
+int mipgen_accel_format_all_mips(mipgen_accel* h, const mipgen_record_names* names, const char* middle, int64_t first_index, int64_t* n_records, int64_t* n_bytes)
+{
+    if (!h || !middle || !n_records || !n_bytes) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (!h->replayed || !h->mask_valid || h->cur_window < 0) return fail(MIPGEN_E_STATE, "format_all_mips needs mipgen_accel_replay_condense on the scored window first");
+    const Window& W = h->windows[(size_t)h->cur_window];
+    const int nr = W.r1 - W.r0;
+    if (nr > 0 && !names) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (strlen(middle) >= sizeof(((FmtConst*)0)->middle)) return fail(MIPGEN_E_INVALID, "middle sequence too long");
+    HIP_TRY(hipSetDevice(h->device));
+    FmtConst FC;
+    memset(&FC, 0, sizeof FC);
+    FC.middle_len = (int32_t)strlen(middle); memcpy(FC.middle, middle, (size_t)FC.middle_len);
+    FC.n_regions = nr; FC.first_index = first_index;
+    std::vector<FmtRegion> fr((size_t)std::max(nr, 1));
+    std::string pool;
+    int64_t n_rb = 0;
+    for (int i = 0; i < nr; i++) {
+        const DevRegion& d = h->hregions[(size_t)(W.r0 + i)];
+        FmtRegion& f = fr[(size_t)i];
+        const char* chr = names[i].chr ? names[i].chr : ""; const char* label = names[i].label ? names[i].label : "";
+        f.chr_off = (int32_t)pool.size(); f.chr_len = (int32_t)strlen(chr); pool += chr;
+        f.label_off = (int32_t)pool.size(); f.label_len = (int32_t)strlen(label); pool += label;
+        f.feature_start = names[i].feature_start; f.feature_stop = names[i].feature_stop;
+        f.rb0 = n_rb;
+        n_rb += (int64_t)d.n_pos * d.n_sizes;
+    }
+    *n_records = 0; *n_bytes = 0; h->fmt_bytes = 0;
+    if (n_rb == 0) return MIPGEN_OK;
+    if (n_rb + 1 > INT32_MAX) return fail(MIPGEN_E_INVALID, "window too large for record formatting (%lld row blocks)", (long long)n_rb);
+    if (h->fmt_regions.reserve(fr.size()) || h->fmt_pool.reserve(std::max<size_t>(pool.size(), 1)) || h->fmt_a.reserve((size_t)n_rb + 1) || h->fmt_b.reserve((size_t)n_rb + 1) ||
+        h->fmt_c.reserve((size_t)n_rb + 1) || h->fmt_d.reserve((size_t)n_rb + 1))
+        return MIPGEN_E_NOMEM;
+    size_t temp_bytes = 0;
+    HIP_TRY(mipgen_scan_i64(h->stream, nullptr, &temp_bytes, h->fmt_a.p, h->fmt_b.p, n_rb + 1));
+    if (h->fmt_temp.reserve(temp_bytes + 16)) return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(h->fmt_regions.p, fr.data(), fr.size() * sizeof(FmtRegion), hipMemcpyHostToDevice, h->stream));
+    if (!pool.empty()) HIP_TRY(hipMemcpyAsync(h->fmt_pool.p, pool.data(), pool.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->fmt_a.p + n_rb, 0, sizeof(int64_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->fmt_c.p + n_rb, 0, sizeof(int64_t), h->stream));
+    // records per row block -> ranks; bytes per row block -> offsets; then the bytes
+    HIP_TRY(mipgen_launch_fmt_count(h->stream, n_rb, W.r0, &FC, h->fmt_regions.p, h->dp, h->regions.p, h->emitted.p, h->fmt_a.p));
+    HIP_TRY(mipgen_scan_i64(h->stream, h->fmt_temp.p, &temp_bytes, h->fmt_a.p, h->fmt_b.p, n_rb + 1));
+    HIP_TRY(mipgen_launch_fmt_records(h->stream, 0, n_rb, W.r0, &FC, h->fmt_regions.p, h->fmt_pool.p, h->dp, h->regions.p, h->letters.p, h->copy.p, h->scores.p,
+                                      h->records.p, h->emitted.p, h->fmt_b.p, nullptr, h->fmt_c.p, nullptr));
+    HIP_TRY(mipgen_scan_i64(h->stream, h->fmt_temp.p, &temp_bytes, h->fmt_c.p, h->fmt_d.p, n_rb + 1));
+    int64_t totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&totals[0], h->fmt_b.p + n_rb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&totals[1], h->fmt_d.p + n_rb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->fmt_text.reserve((size_t)std::max<int64_t>(totals[1], 1))) return MIPGEN_E_NOMEM;
+    HIP_TRY(mipgen_launch_fmt_records(h->stream, 1, n_rb, W.r0, &FC, h->fmt_regions.p, h->fmt_pool.p, h->dp, h->regions.p, h->letters.p, h->copy.p, h->scores.p,
+                                      h->records.p, h->emitted.p, h->fmt_b.p, h->fmt_d.p, nullptr, h->fmt_text.p));
+    *n_records = totals[0]; *n_bytes = totals[1]; h->fmt_bytes = totals[1];
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_download_text(mipgen_accel* h, char* dst, int64_t capacity)
+{
+    if (!h || (!dst && capacity > 0)) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (h->fmt_bytes < 0) return fail(MIPGEN_E_STATE, "mipgen_accel_format_all_mips has not run on this window");
+    if (capacity < h->fmt_bytes) return fail(MIPGEN_E_INVALID, "text capacity %lld < %lld bytes", (long long)capacity, (long long)h->fmt_bytes);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->fmt_bytes) HIP_TRY(hipMemcpy(dst, h->fmt_text.p, (size_t)h->fmt_bytes, hipMemcpyDeviceToHost));
     return MIPGEN_OK;
 }
 

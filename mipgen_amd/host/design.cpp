@@ -257,6 +257,8 @@ struct WindowResult {
     std::vector<double> scores;
     std::vector<uint64_t> records;
     std::vector<uint8_t> mask;
+    std::vector<char> text;                      // the window's all_mips records, formatted on the device (single-worker runs)
+    bool has_text = false;
     bool last = false;
     int error = 0;
     std::string msg;
@@ -302,8 +304,9 @@ struct SurvivorRescorer {                        // the SVR scores the worker co
     }
 };
 
-void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch)
+void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool device_text)
 {
+    int64_t all_before = 0;                      // all_mip_counter at the start of the next window (device_text: this worker sees every window)
     auto fail_out = [&](int code, const std::string& msg) {
         std::unique_ptr<WindowResult> r(new WindowResult());
         r->error = code; r->msg = msg; r->last = true;
@@ -356,11 +359,26 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch)
         }
         res->collapsed.resize((size_t)std::max<int64_t>(res->col_off[(size_t)wn], 1));
         if (mipgen_accel_download_collapsed(h, w, res->collapsed.data(), (int64_t)res->collapsed.size())) { bail(19); return; }
-        if (!o.silent) {
+        const bool text = !o.silent && device_text;
+        if (!o.silent && !text) {
             res->scores.resize((size_t)nc); res->records.resize((size_t)nc); res->mask.resize((size_t)nc);
             if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
         }
-        if (mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), o.silent ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
+        if (mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), (o.silent || text) ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
+        if (text) {
+            // print_details on the device: the records leave the GPU as text, the dense results never do
+            std::vector<mipgen_record_names> names((size_t)wn);
+            for (int bi = 0; bi < wn; bi++) {
+                const Region& r = d->regions[(size_t)(r0 + wr0 + bi)];
+                names[(size_t)bi] = mipgen_record_names{r.chr.c_str(), r.label.c_str(), r.start - 1, r.stop};
+            }
+            int64_t n_rec = 0, n_bytes = 0;
+            if (mipgen_accel_format_all_mips(h, names.data(), o.middle.c_str(), all_before, &n_rec, &n_bytes)) { bail(19); return; }
+            res->text.resize((size_t)n_bytes);
+            if (mipgen_accel_download_text(h, res->text.data(), n_bytes)) { bail(19); return; }
+            res->has_text = true;
+            all_before += n_rec;
+        }
         for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
         if (o.score_method == MIPGEN_SCORE_MIXED) {
             // every survivor of the window through the SVR in one call (the pick stage re-scores a subset of them, mipgen.cpp:1523-1527,1873-1877)
@@ -430,13 +448,14 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     std::vector<std::thread> threads;
     for (int k = 0; k < n_devices; k++) {
         chans.emplace_back(new Channel());
-        threads.emplace_back(worker, d, k % visible, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get());
+        threads.emplace_back(worker, d, k % visible, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get(), n_devices == 1);
     }
     int rc = 0;
     for (int k = 0; k < n_devices && rc == 0; k++) {
         for (;;) {
             std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
             if (w->error) { rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
+            if (w->has_text) d->out.all.write(w->text.data(), (std::streamsize)w->text.size());     // numbered by the device from this window's first index
             int64_t pos0 = 0;
             for (int bi = 0; bi < w->r1 - w->r0 && rc == 0; bi++) {
                 const mipgen_grid& g = w->grids[(size_t)bi];

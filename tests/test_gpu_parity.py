@@ -661,3 +661,35 @@ def test_batched_candidate_rescoring(genome):
         assert abs(batched[int(k)] - so) <= 1e-5 or (np.isnan(so) and np.isnan(batched[int(k)])), (c, batched[int(k)], so)
         n_guard += int((capi.rec_flags(rec_b[int(k):int(k) + 1]) & capi.FLAG_GUARD)[0] != 0)
     acc.close()
+
+
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small"])
+def test_all_mips_records_formatted_on_device(name, genome):
+    """mipgen_accel_format_all_mips: the window's constructed candidates as print_details writes them (mipgen.cpp:765-794), numbered in
+    generation order - byte for byte the reference binary's all_mips file (less its header; the reference's uninitialised masking byte of
+    mapping-failed records normalised, tests/helpers.py), also when the batch is cut into windows numbered on from each other."""
+    meta = H.load_design(name)
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
+    ref = [H.normalise_flags(l) for l in H.ref_lines(meta, "all_mips")[1:]]
+    for cap in (0, 1):
+        acc = capi.Accel(P)
+        if meta["model"]:
+            acc.load_model_file(_model_path(meta))
+        if cap:
+            acc.set_window_candidates(int(max(po.grid(P, r).count for r in regions)) + 1)
+        acc.upload(regions)
+        text, first = b"", 0
+        for w in range(acc.window_count()):
+            wi = acc.window_info(w)
+            acc.score_window(w, method)
+            acc.replay_condense()
+            names = [("1", regions[i].label, regions[i].start - 1, regions[i].stop) for i in range(wi["first_region"], wi["first_region"] + wi["n_regions"])]
+            t, n = acc.format_all_mips(names, H.middle_of(meta["tags"]), first)
+            text += t; first += n
+        acc.close()
+        got = text.split(b"\n")
+        assert got[-1] == b"" and len(got) - 1 == len(ref) == first
+        bad = [i for i, (a, b) in enumerate(zip(got, ref)) if a != b]
+        assert not bad, (name, cap, bad[0], got[bad[0]][:160], ref[bad[0]][:160])
