@@ -7,7 +7,7 @@
  * The coefficients are the trained model, not code; they are restated here once and consumed by the
  * oracle (same evaluation order as the reference, for bit-exact CPU parity) and by the HIP kernels
  * (which regroup the same terms by sequence window).  A mistranscription is caught by
- * tests/test_oracle_vs_reference.py, which compares against the compiled reference.
+ * tests/test_oracle_golden.py, which compares the oracle with known answers of the compiled reference (tests/golden/candidates.npz).
  */
 #ifndef MIPGEN_LOGISTIC_MODEL_H
 #define MIPGEN_LOGISTIC_MODEL_H

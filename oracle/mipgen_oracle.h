@@ -4,7 +4,7 @@
  * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library; the product (include/mipgen_accel.h, mipgen_amd/) never does.
  *
- * Parity status: PINNED.  Every function here is checked (tests/test_oracle_vs_reference.py) against the
+ * Parity status: PINNED.  Every function here is checked (tests/test_oracle_golden.py, tests/test_host_select_cpu.py) against the
  * real reference compiled from /root/reference by oracle/Makefile (oracle/_ref), and against the golden
  * vectors under tests/golden/ that were generated from that same build (tests/golden/make_golden.py).
  * The reference's own tests hold nothing for this path; the trained model

@@ -159,7 +159,8 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
     w = "/tmp/mipgen_golden_" + d["name"]
     shutil.rmtree(w, ignore_errors=True)
     os.makedirs(w + "/genome")
-    synth.write_fasta(w + "/genome/chr1.fa", "chr1", genome)
+    chrom = d.get("chrom", "1")
+    synth.write_fasta(w + f"/genome/chr{chrom}.fa", "chr" + chrom, genome)
     ivs = [synth.Interval(*iv) for iv in d["ivs"]]
     synth.write_bed(w + "/regions.bed", ivs)
     shutil.copy(w + "/regions.bed", out + "/regions.bed")
@@ -184,6 +185,7 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
     meta["genome"] = genome_name
     if genome_name != "genome_chr1.fa.gz":
         meta["extra"] = list(d.get("extra", []))
+        meta["chrom"] = d.get("chrom", "1")
         meta["arm_lengths"] = d.get("arm_lengths")
     meta["sha256"] = {}
     meta["lines"] = {}
@@ -235,6 +237,18 @@ def main() -> None:
     for d in DESIGNS2:
         if not only or d["name"] in only:
             gen_design(genome2, d, "genome2_chr1.fa.gz")
+    # BASELINE configs[0]: the practice62 stand-in for practice_genes.bed (62 exon-like regions on a 400 kb chromosome "7"), capture 162-162,
+    # logistic scoring - the reference's own CPU-runnable case
+    from mipgen_amd import workloads
+    g7, ivs7 = workloads.practice62()
+    with gzip.GzipFile(os.path.join(HERE, "genome_practice62_chr7.fa.gz"), "wb", mtime=0) as gz:
+        gz.write(b">chr7\n")
+        for i in range(0, len(g7), 60):
+            gz.write(g7[i:i + 60] + b"\n")
+    d1 = dict(name="practice62_config1", method="logistic", ivs=[(iv.chrom, iv.bed_start, iv.bed_end, iv.label) for iv in ivs7], minC=162, maxC=162,
+              sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="unique", model=None, extra=[], chrom="7")
+    if not only or d1["name"] in only:
+        gen_design(g7, d1, "genome_practice62_chr7.fa.gz")
 
 
 if __name__ == "__main__":

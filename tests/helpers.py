@@ -116,7 +116,8 @@ def prepare_cli_workdir(meta: dict, work: str, fai: bool = False) -> List[str]:
     model is placed: mipgen.cpp:137-138,409).  fai=True: no -genome_dir; the region sequences come from <index>.fai instead."""
     os.makedirs(os.path.join(work, "genome"), exist_ok=True)
     genome = golden_genome(meta.get("genome", "genome_chr1.fa.gz"))
-    synth.write_fasta(os.path.join(work, "genome", "chr1.fa"), "chr1", genome)
+    chrom = meta.get("chrom", "1")
+    synth.write_fasta(os.path.join(work, "genome", f"chr{chrom}.fa"), "chr" + chrom, genome)
     shutil.copy(os.path.join(meta["dir"], "regions.bed"), os.path.join(work, "regions.bed"))
     exe = os.path.join(work, "mipgen")
     if not os.path.lexists(exe):
@@ -134,9 +135,9 @@ def prepare_cli_workdir(meta: dict, work: str, fai: bool = False) -> List[str]:
         argv += ["-arm_length_sums", ",".join(map(str, meta["sums"]))]
     if fai:
         # a multi-line FASTA with its .fai index (name, length, offset, bases per line, bytes per line), as `samtools faidx` writes it
-        synth.write_fasta(index, "chr1", genome, width=60)
+        synth.write_fasta(index, "chr" + chrom, genome, width=60)
         with open(index + ".fai", "w") as fh:
-            fh.write(f"chr1\t{len(genome)}\t6\t60\t61\n")
+            fh.write(f"chr{chrom}\t{len(genome)}\t{len(chrom) + 5}\t60\t61\n")
     else:
         argv += ["-genome_dir", os.path.join(work, "genome")]
     if meta["snps"]:
