@@ -207,6 +207,202 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same for designs with at most 64 arm pairs (the reference's defaults give 25): one row fits one wavefront, and the walk over the
+// arm-sum lists of a row turns into lane-parallel work.  Inside a list nothing depends on the lists before it (previous_plus_score /
+// previous_minus_score / skip_ahead are reset at :435-436), so every lane finds the constructed pair before it in ITS list, tests the
+// :494 heuristic and masks itself off behind the first hit - all lists of the row at once, one wave shuffle per row.  What does chain
+// through the lists is previous_best_score (:434,495); it can only switch a list off once some list's last pair scored above the upper
+// threshold, so the scalar chain over the lists runs for those rows alone.  Rows are loaded REPLAY_ROWS at a time: a position costs
+// ceil(n_sizes / REPLAY_ROWS) dependent round trips to memory in the replay and as many per strand in the condense fold, not one per row.
+// ---------------------------------------------------------------------------------------------------------
+#define REPLAY_ROWS 8
+
+__global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
+    int total_pos, int lds_pitch, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions,
+    const int32_t* __restrict__ pos_region, const int32_t* __restrict__ pos_local, const double* __restrict__ scores,
+    const uint64_t* __restrict__ records, const int32_t* __restrict__ copy, int64_t cand_base, uint8_t* __restrict__ emitted,
+    mipgen_survivor* __restrict__ survivors, unsigned long long* __restrict__ emitted_per_region)
+{
+    extern __shared__ uint64_t s_masks[];                                  // [wave][size index]: emitted lanes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gp = blockIdx.x * REPLAY_WAVES + wave;
+    if (gp >= total_pos) return;
+    uint64_t* emask = s_masks + (size_t)wave * lds_pitch;
+    const int ri = pos_region[gp], pi = pos_local[gp];
+    const DevRegion& R = regions[ri];
+    const int A = P->n_pairs, nK = R.n_sizes;
+    const int64_t per_pos = (int64_t)nK * A * 2;
+    const int64_t base = R.out_off + (int64_t)pi * per_pos;
+    const double upper = P->upper, lower = P->lower;
+    const bool heuristic = P->score_method == MIPGEN_SCORE_LOGISTIC && P->logistic_heuristic;
+    const uint64_t lane_bit = 1ull << lane, below_me = lane_bit - 1;
+
+    // my pair, and the lanes of my arm-sum list
+    const bool in = lane < A;
+    const int e = in ? P->arm_ext[lane] : 1, l = in ? P->arm_lig[lane] : 1, gend = in ? P->group_end[lane] : 0;
+    const uint64_t list_ends = __ballot(in && lane + 1 == gend);           // the last pair of every list
+    const uint64_t min_lists = __ballot(in && e + l == P->min_sum);        // pairs of the list :434 never switches off
+    const uint64_t ends_below = list_ends & below_me;
+    const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
+    const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;
+    const uint64_t seg_below = seg & below_me, seg_above = seg & ~below_me & ~lane_bit;
+
+    // ---- replay, mipgen.cpp:426-497 ---------------------------------------------------------------------
+    unsigned long long n_emitted = 0;
+    double pbs = 0.0;                                                        // previous_best_score (:426)
+    for (int k0 = 0; k0 < nK; k0 += REPLAY_ROWS) {
+        double bp[REPLAY_ROWS], bm[REPLAY_ROWS];
+        uint64_t br[REPLAY_ROWS];
+        if (pbs > upper) {                                                   // :430 - nothing more is constructed at this position
+            if (lane < REPLAY_ROWS && k0 + lane < nK) emask[k0 + lane] = 0;
+            continue;
+        }
+#pragma unroll
+        for (int q = 0; q < REPLAY_ROWS; q++) {
+            const bool on = in && k0 + q < nK;
+            const int64_t idx = base + ((int64_t)(k0 + q) * 2) * A + lane;
+            bp[q] = on ? scores[idx] : 0.0; bm[q] = on ? scores[idx + A] : 0.0; br[q] = on ? records[idx] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < REPLAY_ROWS; q++) {
+            const int ki = k0 + q;
+            if (ki >= nK) break;
+            uint64_t emit_all = 0;
+            if (!(pbs > upper)) {                                            // :430
+                const double plus = bp[q], minus = bm[q];
+                const bool valid = (MIPGEN_REC_FLAGS(br[q]) & MIPGEN_FLAG_VALID) != 0;           // :443-444 (0 outside the row)
+                const uint64_t vmask = __ballot(valid);
+                bool mine = valid;
+                if (heuristic && vmask) {
+                    // the pair before me in my list that was constructed: its truncated scores are what :494 compares against
+                    const uint64_t below = vmask & seg_below;
+                    const int src = below ? top_bit(below) : lane;
+                    const double pp = __shfl(plus, src, 64), pm = __shfl(minus, src, 64);
+                    const int ip = below ? to_int_x86(pp) : 0, im = below ? to_int_x86(pm) : 0;
+                    const bool cond = valid && plus < (double)ip && minus < (double)im;           // :494
+                    const uint64_t cmask = __ballot(cond);
+                    mine = valid && !(cmask & seg_below);                    // the first hit of a list is still constructed, nothing behind it
+                }
+                emit_all = __ballot(mine);
+                if (emit_all) {
+                    const double pb = (minus > plus) ? minus : plus;         // :495 if I am the last pair constructed in my list
+                    const bool last_of_list = mine && !(emit_all & seg_above);
+                    if (!__ballot(last_of_list && pb > upper)) {
+                        pbs = readlane_d(pb, top_bit(emit_all));             // no list of this row can switch a later one off
+                    } else {
+                        uint64_t ends = list_ends;
+                        int a0 = 0;
+                        while (ends) {                                       // the chain through previous_best_score, list by list
+                            const int a1 = __builtin_ctzll(ends) + 1;
+                            ends &= ends - 1;
+                            const uint64_t sg = (a1 >= 64 ? ~0ull : (1ull << a1) - 1) & ~((1ull << a0) - 1);
+                            if (pbs > upper && !((min_lists >> a0) & 1)) emit_all &= ~sg;          // :434
+                            else if (emit_all & sg) pbs = readlane_d(pb, top_bit(emit_all & sg));
+                            a0 = a1;
+                        }
+                    }
+                    n_emitted += 2ull * (unsigned)__builtin_popcountll(emit_all);
+                    if (emitted && (emit_all & lane_bit)) {
+                        const int64_t idx = base + ((int64_t)ki * 2) * A + lane;
+                        emitted[idx] = 1; emitted[idx + A] = 1;
+                    }
+                }
+            }
+            if (lane == 0) emask[ki] = emit_all;
+        }
+    }
+    if (n_emitted && lane == 0) atomicAdd(&emitted_per_region[ri], n_emitted);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");              // the lane masks written above are read by every lane below
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- condense, mipgen.cpp:1670-1746 -------------------------------------------------------------------
+    const int target_copy = P->target_arm_copy;
+    const int64_t max_product = P->max_arm_copy_product;
+    const double thr = P->masked_arm_threshold;
+    const double arm_sum = (double)(l + e);
+    int chosen_copy = 0;
+    double chosen_masked = 0.0;                                                      // per position, not per strand (:1677-1680)
+    const int k_top = ((nK - 1) / REPLAY_ROWS) * REPLAY_ROWS;
+    for (int s = 0; s < 2; s++) {
+        int64_t best_idx = -1;
+        double best_score = 0.0;
+        uint64_t best_rec = 0;
+        int best_snp = 0;
+        bool stop = false;
+        for (int k0 = k_top; k0 >= 0 && !stop; k0 -= REPLAY_ROWS) {                  // newest first (push_front, :475,489)
+            uint64_t em[REPLAY_ROWS], br[REPLAY_ROWS];
+            double bs[REPLAY_ROWS];
+#pragma unroll
+            for (int q = 0; q < REPLAY_ROWS; q++) {
+                em[q] = k0 + q < nK ? emask[k0 + q] : 0;
+                const bool mine = (em[q] & lane_bit) != 0;
+                const int64_t idx = base + ((int64_t)(k0 + q) * 2 + s) * A + lane;
+                br[q] = mine ? records[idx] : 0; bs[q] = mine ? scores[idx] : 0.0;
+            }
+#pragma unroll
+            for (int q = REPLAY_ROWS - 1; q >= 0; q--) {
+                if (stop || !em[q]) continue;
+                const int ki = k0 + q;
+                const bool mine = (em[q] & lane_bit) != 0;
+                const uint64_t r = br[q];
+                const double sc = bs[q];
+                int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+                if (mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0) {
+                    // the record's 16-bit fields saturate; the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,1692,1709):
+                    // fetch the true values from the copy table
+                    const int C = P->max_capture - (R.k0 + ki) * P->inc, p = R.first_pos + pi, ss = C - e - l;
+                    const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
+                    const int se = P->len_slot[e], sl = P->len_slot[l];
+                    const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
+                    ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
+                    lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
+                }
+                const bool ok = mine && !((int64_t)ext_copy * lig_copy > max_product) && !(MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING);   // :1689-1690
+                const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
+                const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / arm_sum;
+                const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
+                uint64_t pending = __ballot(ok);
+                while (pending) {
+                    // every pending lane evaluates the take rules against the current state; the first taker in fold order (highest pair
+                    // index first) is applied, the lanes after it are re-evaluated
+                    bool take = false, update_chosen = true, stops = false;
+                    if (best_idx < 0) take = true;                                                                    // :1695
+                    else if (cur_masked > thr && cur_masked < chosen_masked) take = true;                             // :1701
+                    else if (cur_copy > target_copy && cur_copy < chosen_copy) take = true;                           // :1709
+                    else if (cur_copy <= target_copy) {
+                        if (sc < lower && sc > best_score) take = true;                                               // :1717
+                        else if (sc > lower) {
+                            if (snp < best_snp) take = true;                                                          // :1725
+                            else if (snp == best_snp && sc > best_score) { take = true; update_chosen = false; stops = sc > upper; }   // :1731-1737
+                        }
+                    }
+                    const uint64_t tmask = __ballot(take) & pending;
+                    if (!tmask) break;
+                    const int f = top_bit(tmask);
+                    best_idx = base + ((int64_t)ki * 2 + s) * A + f;
+                    best_score = readlane_d(sc, f);
+                    best_rec = readlane_u64(r, f);
+                    best_snp = (int)MIPGEN_REC_SNP_COUNT(best_rec);
+                    if (__builtin_amdgcn_readlane((int)update_chosen, f)) {
+                        chosen_masked = readlane_d(cur_masked, f);
+                        chosen_copy = __builtin_amdgcn_readlane(cur_copy, f);
+                    }
+                    if (__builtin_amdgcn_readlane((int)stops, f)) { stop = true; break; }
+                    pending &= (1ull << f) - 1;
+                }
+            }
+        }
+        if (lane == 0) {
+            mipgen_survivor out;
+            out.cand_index = best_idx < 0 ? -1 : best_idx + cand_base; out.score = best_score; out.record = best_rec;
+            survivors[2 * (int64_t)gp + s] = out;
+        }
+    }
+}
+
+
 extern "C" hipError_t mipgen_launch_replay_condense(
     hipStream_t stream, int n_regions, int total_pos, const DevParams* P, int n_pairs, int n_sizes_max, const DevRegion* regions,
     const int32_t* pos_region, const int32_t* pos_local, const double* scores, const uint64_t* records, const int32_t* copy, int64_t cand_base,
@@ -217,8 +413,13 @@ extern "C" hipError_t mipgen_launch_replay_condense(
     const int n_chunks = (n_pairs + 63) / 64;
     const int pitch = n_sizes_max * n_chunks;
     const size_t lds = (size_t)REPLAY_WAVES * pitch * sizeof(uint64_t);
-    hipLaunchKernelGGL(k_replay_condense, dim3((total_pos + REPLAY_WAVES - 1) / REPLAY_WAVES), dim3(REPLAY_WAVES * 64), lds, stream, total_pos,
-                       n_chunks, pitch, P, regions, pos_region, pos_local, scores, records, copy, cand_base, emitted, survivors, emitted_per_region);
+    const dim3 grid((total_pos + REPLAY_WAVES - 1) / REPLAY_WAVES), block(REPLAY_WAVES * 64);
+    if (n_chunks == 1)
+        hipLaunchKernelGGL(k_replay_condense_narrow, grid, block, lds, stream, total_pos, pitch, P, regions, pos_region, pos_local, scores, records, copy,
+                           cand_base, emitted, survivors, emitted_per_region);
+    else
+        hipLaunchKernelGGL(k_replay_condense, grid, block, lds, stream, total_pos, n_chunks, pitch, P, regions, pos_region, pos_local, scores, records,
+                           copy, cand_base, emitted, survivors, emitted_per_region);
     return hipGetLastError();
 }
 
