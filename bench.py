@@ -355,7 +355,7 @@ def main() -> None:
                 traffic_src = os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
-        kern = "k_svr_dense" if method == "svr" else "k_records_logistic<true>"
+        kern = "k_svr_dense" if method == "svr" else "k_logistic_dense"
         if method == "svr":
             ent = table_entries_min(P, grids)
             # FP64 operations the window-separable algorithm needs per support vector: 3 per candidate (multiply + FMA on table factors)
@@ -426,7 +426,7 @@ def main() -> None:
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
             lk = float(np.mean(ks))
-            extra.append({"what": "same batch, logistic scoring (k_records_logistic<true> + replay/condense)", "value": n_cand * reps / d1, "unit": "candidates/s",
+            extra.append({"what": "same batch, logistic scoring (k_logistic_dense + replay/condense)", "value": n_cand * reps / d1, "unit": "candidates/s",
                           "ms_per_step": d1 / reps * 1e3, "k_records_logistic_ms": lk,
                           "roofline": {"bound": "hbm", "achieved": alg_bytes / (lk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": alg_bytes / (lk * 1e-3) / 1e9 / HBM_PEAK_GBS}})

@@ -577,6 +577,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     // ---- tiles, window by window ----
     std::vector<LogTile> lt;
     std::vector<SvrTile> st;
+    std::vector<double> st_cost;
     const int Lmax = std::max(D.e_max, D.l_max);
     int span_max = 0;
     size_t svr_lds = 0;
@@ -662,8 +663,24 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
             for (const Run& r : best_runs)
                 for (int p0 = 0; p0 < d.n_pos; p0 += r.np) {
                     const int npt = std::min(r.np, d.n_pos - p0);
-                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); }
+                    // run time of the tile in wavefront-cycles per SV group (measured shares of the three stages): table entries, scan span,
+                    // candidate steps (all lanes of the block step, whatever the tile holds)
+                    const int Cmax_t = Cmax - r.ki0 * D.inc, ssmax = Cmax_t - D.min_sum, ssr = (r.kc - 1) * D.inc + D.max_sum - D.min_sum + 1;
+                    const double ent = (npt + (npt + ssr - 1)) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)npt * ssr;
+                    const double cost = 19.0 * ent + 100.0 * (npt + ssmax + 2 * Lmax) + 75000.0;
+                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); st_cost.push_back(cost); }
                 }
+        }
+        // longest tiles first: workgroups are dispatched in index order as compute units free up, so the short tiles fill the end of the
+        // launch (k_svr_dense takes tile blockIdx / n_split: consecutive tiles already land on different XCDs)
+        {
+            const size_t t0 = (size_t)w.svr_tile0, n = st.size() - t0;
+            std::vector<size_t> order(n);
+            for (size_t k = 0; k < n; k++) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st_cost[t0 + a] > st_cost[t0 + b]; });
+            std::vector<SvrTile> sorted(n);
+            for (size_t k = 0; k < n; k++) sorted[k] = st[t0 + order[k]];
+            std::copy(sorted.begin(), sorted.end(), st.begin() + (ptrdiff_t)t0);
         }
         w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0; w.n_col_tiles = (int)ct.size() - w.col_tile0;
         w.n_ld_tiles = (int)ldt.size() - w.ld_tile0;
