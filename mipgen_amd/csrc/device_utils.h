@@ -96,4 +96,36 @@ __device__ inline void block_exclusive_scan_u64(uint64_t* data, int n, uint64_t*
     __syncthreads();
 }
 
+// The same for three arrays of equal length at once: one pass, three barriers instead of nine, the three wave scans interleaved.
+// scratch: at least 3 * 16 u64 in LDS.
+__device__ inline void block_exclusive_scan3_u64(uint64_t* d0, uint64_t* d1, uint64_t* d2, int n, uint64_t* scratch)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int chunk = (n + nt - 1) / nt;
+    const int lo = tid * chunk;
+    const int hi = min(lo + chunk, n);
+    uint64_t t0 = 0, t1 = 0, t2 = 0;
+    for (int i = lo; i < hi; i++) { t0 += d0[i]; t1 += d1[i]; t2 += d2[i]; }
+    uint64_t i0 = t0, i1 = t1, i2 = t2;
+    const int lane = tid & (WAVE - 1), wid = tid / WAVE, nw = (nt + WAVE - 1) / WAVE;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint64_t u0 = shfl_up_u64(i0, d), u1 = shfl_up_u64(i1, d), u2 = shfl_up_u64(i2, d);
+        if (lane >= d) { i0 += u0; i1 += u1; i2 += u2; }
+    }
+    if (lane == WAVE - 1) { scratch[wid] = i0; scratch[16 + wid] = i1; scratch[32 + wid] = i2; }
+    __syncthreads();
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    for (int w = 0; w < wid; w++) { w0 += scratch[w]; w1 += scratch[16 + w]; w2 += scratch[32 + w]; }
+    uint64_t r0 = w0 + i0 - t0, r1 = w1 + i1 - t1, r2 = w2 + i2 - t2;
+    for (int i = lo; i < hi; i++) {
+        const uint64_t v0 = d0[i], v1 = d1[i], v2 = d2[i];
+        d0[i] = r0; d1[i] = r1; d2[i] = r2;
+        r0 += v0; r1 += v1; r2 += v2;
+    }
+    if (tid == nt - 1) { d0[n] = r0 + 0; d1[n] = r1; d2[n] = r2; }      // the last thread's running sums are the totals (its chunk ends the array or is empty)
+    __syncthreads();
+    (void)nw;
+}
+
 __device__ __forceinline__ int comp_code(int c) { return c < 4 ? 3 - c : c; }

@@ -18,6 +18,7 @@
 #include "device_utils.h"
 #include "logistic_device.h"
 #include "logistic_groups.h"
+#include "exp2_tab.h"
 
 #define LD_THREADS 512
 #define LD_ARM_STRIDE 9              // doubles per arm-window entry: 8 values + one packed 64-bit word
@@ -29,40 +30,59 @@ extern "C" size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, in
     const int nq = np + ssr - 1;
     const int span = np + ssmax + 2 * Lmax + 2;
     size_t b = 0;
-    b += (size_t)3 * (span + 1) * 8 + 64;                       // W0..W2 prefix words + scan scratch
+    b += (size_t)3 * (span + 1) * 8 + 48 * 8;                   // W0..W2 prefix words + scan scratch
+    b += 102 * 8;                                                // log10 of the copy numbers 0..100 (101 = "more than 100")
     const int n_max = n_up > n_dn ? n_up : n_dn;                 // both strands reuse the tables: sized for either role assignment
     b += (size_t)np * n_max * LD_ARM_STRIDE * 8;                 // upstream arm windows
     b += (size_t)nq * n_max * LD_ARM_STRIDE * 8;                 // downstream arm windows
     b += (size_t)np * ssr * LD_INS_STRIDE * 8;                   // insert windows
     b += (size_t)np * n_max * 2 + 16;                            // mappability masks of the upstream windows (bit per capture size of the tile)
     b += (size_t)span + 16;                                      // bases
+    b += 256 * 8;                                                // 2^(j/256) table of the exponential
     return (b + 15) & ~(size_t)15;
 }
 
 namespace {
 
-// packed integer word of an arm window
-//   bits  0..31  copy number (as the table holds it; 1 when there is no table)
-//   bits 32..39  masked-sequence N count      40..47 SNP count      48..55 SNPs without an alternate-allele arm
-//   bit  56      an SNP with an alternate-allele arm      bit 57  N or '-' in the window (guard)
-//   bits 58..62  junction code 4*b0+b1 of the oriented ligation arm, 16 = not ACGT (ligation-role windows only)
-__device__ __forceinline__ uint64_t pack_word(int copy, uint32_t masked, uint32_t snp_any, uint32_t snp_bad, bool snp_ok, bool guard, uint32_t jc)
+// Integer word of an arm window, laid out so that a candidate's record is (almost) the sum of its two windows' words:
+//   low dword   copy number saturated to 16 bits, in the record's field of the window's ROLE (extension: bits 0..15, ligation: 16..31)
+//   high dword  bits 0..7 masked-sequence N count | 8..15 SNP count | role nibble (extension: bits 16..19, ligation: 20..23):
+//               guard (N or '-' in the window), an SNP with an alternate-allele arm, an SNP without one, copy number <= 0
+//               | bits 24..31 the record's junction byte (ligation role: 4*b0+b1 of the oriented arm, 255 = not ACGT; extension role: 0)
+// The two nibbles never overlap and the counts are <= 30 each, so the 32-bit ADD of the two high dwords carries nothing across fields.
+__device__ __forceinline__ uint64_t pack_word(bool lig_role, int copy, uint32_t masked, uint32_t snp_any, uint32_t snp_bad, bool snp_ok, bool guard, uint32_t jc)
 {
-    return (uint64_t)(uint32_t)copy | ((uint64_t)min(masked, 255u) << 32) | ((uint64_t)min(snp_any, 255u) << 40) | ((uint64_t)min(snp_bad, 255u) << 48) |
-           ((uint64_t)snp_ok << 56) | ((uint64_t)guard << 57) | ((uint64_t)jc << 58);
+    const uint32_t c16 = (uint32_t)min(max(copy, 0), 65535);
+    const uint32_t nib = (uint32_t)guard | ((uint32_t)snp_ok << 1) | ((uint32_t)(snp_bad != 0) << 2) | ((uint32_t)(copy <= 0) << 3);
+    const uint32_t lo = lig_role ? c16 << 16 : c16;
+    const uint32_t hi = min(masked, 255u) | (min(snp_any, 255u) << 8) | (nib << (lig_role ? 20 : 16)) | (lig_role ? (jc < 16 ? jc : 255u) << 24 : 0u);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
+
+__device__ const double EXP2_TAB[256] = EXP2_TAB_VALUES;
 
 }  // namespace
 
-__global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
+__global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, const SvrTile* __restrict__ tiles, int n_tiles,
     const uint8_t* __restrict__ bases, const int32_t* __restrict__ copy, const uint8_t* __restrict__ unmap,
-    const HostConsts* __restrict__ HC, double* __restrict__ scores, uint64_t* __restrict__ records)
+    const HostConsts* __restrict__ HC, double* __restrict__ scores, uint64_t* __restrict__ records
+#ifdef MIPGEN_DIAG
+    , unsigned long long* __restrict__ prof
+#endif
+    )
 {
+#ifdef MIPGEN_DIAG
+    unsigned long long pc[5] = {0, 0, 0, 0, 0}, tq = __builtin_readcyclecounter();
+#define LD_STAMP(k) { const unsigned long long tn = __builtin_readcyclecounter(); pc[k] += tn - tq; tq = tn; }
+#else
+#define LD_STAMP(k)
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const SvrTile tile = tiles[xcd_remap(blockIdx.x, n_tiles)];
     const DevRegion& R = regions[tile.region];
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE, NW = LD_THREADS / WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), NW = LD_THREADS / WAVE;
+    const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);       // a scalar: the row arithmetic of the candidate loop stays on the scalar unit
     const int A = P->n_pairs, nK = R.n_sizes, inc = P->inc;
     const int Lmax = max(P->e_max, P->l_max);
     const int Cmax_t = P->max_capture - (R.k0 + tile.ki0) * inc, Cmin_t = Cmax_t - (tile.kc - 1) * inc;
@@ -76,18 +96,22 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
     uint64_t* W0 = (uint64_t*)smem;
     uint64_t* W1 = W0 + (span + 1);
     uint64_t* W2 = W1 + (span + 1);
-    uint64_t* scratch = W2 + (span + 1);                               // 8
-    double* TU = (double*)(scratch + 8);
+    uint64_t* scratch = W2 + (span + 1);                               // 48
+    double* LG = (double*)(scratch + 48);                              // log10(copy), as log_copy_dev gives it
+    double* TU = LG + 102;
     double* TD = TU + (size_t)np * n_max * LD_ARM_STRIDE;
     double* TT = TD + (size_t)nq * n_max * LD_ARM_STRIDE;
     uint16_t* UM = (uint16_t*)(TT + (size_t)np * ssr * LD_INS_STRIDE);
     uint8_t* sb = (uint8_t*)(UM + (size_t)np * n_max + 8);
+    double* XT = (double*)(smem + ((((size_t)(sb - smem) + span + 15) & ~(size_t)15)));   // 2^(j/256)
+    for (int i = tid; i < 256; i += LD_THREADS) XT[i] = EXP2_TAB[i];
 
     // ---- stage bases and the packed prefix words (as k_records_logistic) ---------------------------------------------------------
     for (int i = tid; i < span; i += LD_THREADS) {
         const int ri = lo + i - R.seq_start;
         sb[i] = (ri >= 0 && ri < R.seq_len) ? bases[R.seq_off + ri] : (uint8_t)BASE_OTHER;
     }
+    for (int i = tid; i < 102; i += LD_THREADS) LG[i] = i <= 100 ? HC->log10_tab[i] : 2.0;      // SVMipv4.cpp:173-174: copy > 100 ? 2 : log10(copy)
     __syncthreads();
     for (int i = tid; i < span; i += LD_THREADS) {
         const uint8_t b = sb[i];
@@ -102,9 +126,8 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
         W2[i] = (uint64_t)sw | ((uint64_t)(c >= 4) << 16);
     }
     __syncthreads();
-    block_exclusive_scan_u64(W0, span, scratch);
-    block_exclusive_scan_u64(W1, span, scratch);
-    block_exclusive_scan_u64(W2, span, scratch);
+    block_exclusive_scan3_u64(W0, W1, W2, span, scratch);
+    LD_STAMP(0)
 
     // Both strands of the tile, one after the other: the '+' and '-' rows of a (position, capture size) are neighbours in the result
     // arrays (912 bytes together), so writing them from the same compute unit a few microseconds apart lets L2 merge them into full lines
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
         // oriented base contents: the reverse complement swaps A<->T and C<->G
         const double rl = 1.0 / (double)len, dl = (double)len;
         const double a_c = (double)(minus ? nT : nA) * rl, g_c = (double)(minus ? nC : nG) * rl, gc_c = (double)(nC + nG) * rl;
-        const double lcopy = log_copy_dev(HC, cp);
+        const double lcopy = cp > 100 ? 2.0 : (cp >= 0 ? LG[cp] : __longlong_as_double(0x7FF8000000000000LL));   // as log_copy_dev
         if (!lig_role) {
             e[0] = MLG_FE(a_c, g_c, gc_c, dl, lcopy);
             e[1] = MLG_G_LG(a_c, g_c, gc_c, dl, lcopy); e[2] = MLG_G_LLC(a_c, g_c, gc_c, dl, lcopy); e[3] = MLG_G_LLEN(a_c, g_c, gc_c, dl, lcopy);
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
             e[1] = g_c; e[2] = lcopy; e[3] = js; e[4] = a_c;
             e[5] = MLG_HL_BPS(gc_c, g_c, js, a_c, dl, lcopy); e[6] = MLG_HL_TA(gc_c, g_c, js, a_c, dl, lcopy); e[7] = MLG_HL_TGC(gc_c, g_c, js, a_c, dl, lcopy);
         }
-        ((uint64_t*)e)[8] = pack_word(cp, f16(d1, 0), f16(d1, 1), f16(d1, 2), f16(d1, 3) != 0, nBad != 0, jc);
+        ((uint64_t*)e)[8] = pack_word(lig_role, cp, f16(d1, 0), f16(d1, 1), f16(d1, 2), f16(d1, 3) != 0, nBad != 0, jc);
         if (up) {
             // mapping flag, mipgen.cpp:615-625: the MIP starts at its upstream arm on either strand; one bit per capture size of the tile
             uint32_t mask = 0;
@@ -169,6 +192,7 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
             UM[wl * n_up + li] = (uint16_t)mask;
         }
     }
+    LD_STAMP(1)
     // ---- insert-window entries (position pl, scan size ssmin + ssi) ------------------------------------------------------------------------
     for (int w = tid; w < np * ssr; w += LD_THREADS) {
         const int pl = w / ssr, ssi = w - pl * ssr, ss = ssmin + ssi, bi = Lmax + pl;
@@ -185,11 +209,16 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
         const double ta = (double)(minus ? tT : tA) * rn, tg = (double)(minus ? tC : tG) * rn, tgc = (double)(tC + tG) * rn;
         t[0] = MLG_FT(bps, tlen, ta, tgc, tg); t[1] = bps; t[2] = tgc; t[3] = ta;
     }
+    LD_STAMP(2)
     __syncthreads();
+    LD_STAMP(3)
 
     // ---- candidates: one (position, capture size) row per wavefront pass, lanes on the arm pairs ----------------------------------------
     const double thr = P->masked_arm_threshold;
     const double x0 = MIPGEN_LOGISTIC_C0 - MIPGEN_LOGISTIC_C1;
+    constexpr double xc[4] = EXP2_TAB_POLY;
+    const double EXP_MAGIC = 6755399441055744.0;                        // 1.5 * 2^52: rounds to an integer, which lands in the low mantissa bits
+    const double k256 = HC->ln_base * (1.4426950408889634074 * 256.0);   // exponent -> units of 1/256 of a binary order
     const int n_rows = np * tile.kc;
     for (int a0 = 0; a0 < A; a0 += WAVE) {
         const int a = a0 + lane;
@@ -222,54 +251,85 @@ __global__ __launch_bounds__(LD_THREADS) void k_logistic_dense(
             const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) && ss > 0;
             uint64_t rec = 0;
             double score = 0.0;
-            if (valid) {
+            if (valid) {                                                   // the only divergent branch of the row; everything inside is selects
                 const uint32_t ua = tu_a + __umul24((uint32_t)pl, u_pitch) + u_off;
                 const uint32_t da = td_a + __umul24((uint32_t)(pl + ss - ssmin), d_pitch) + d_off;
                 lds_cd* T = (lds_cd*)(unsigned long)(tt_a + __umul24((uint32_t)pl, t_pitch) + (uint32_t)(ss - ssmin) * (LD_INS_STRIDE * 8));
                 lds_cd* Ee = (lds_cd*)(unsigned long)(minus ? da : ua);    // extension-role entry
                 lds_cd* Le = (lds_cd*)(unsigned long)(minus ? ua : da);    // ligation-role entry
                 const uint64_t we = ((lds_cq*)Ee)[8], wl_ = ((lds_cq*)Le)[8];
-                const int ext_copy = (int)(uint32_t)we, lig_copy = (int)(uint32_t)wl_;
-                const bool guard = ((we | wl_) >> 57) & 1;
-                const bool mapping = (UM[pl * n_up + u_col] >> kci) & 1;
-                const uint32_t masked_n = (uint32_t)((we >> 32) & 0xFF) + (uint32_t)((wl_ >> 32) & 0xFF);
-                uint32_t flags = MIPGEN_FLAG_VALID | (guard ? MIPGEN_FLAG_GUARD : 0u), snp_count = 0;
-                if (mapping) flags |= MIPGEN_FLAG_MAPPING;                  // early return of design_mip: masking / SNP fields stay at their defaults
-                else {
-                    if ((int)masked_n >= mthr) flags |= MIPGEN_FLAG_MASKING;                                        // :610,626
-                    snp_count = (uint32_t)((we >> 40) & 0xFF) + (uint32_t)((wl_ >> 40) & 0xFF);
-                    const uint32_t snp_bad = (uint32_t)((we >> 48) & 0xFF) + (uint32_t)((wl_ >> 48) & 0xFF);
-                    if (snp_bad != 0 || snp_count > 1) flags |= MIPGEN_FLAG_SNP;                                   // :690-693,759-760
-                    if (((we | wl_) >> 56) & 1) flags |= MIPGEN_FLAG_HAS_SNP_MIP;
+                const uint32_t um = UM[pl * n_up + u_col];
+                // ---- exponent (no dependence on the integer words) ----
+                double x = x0 + Ee[0];
+                x += Le[0];
+                x += T[0];
+                x = fma(Le[1], Ee[1], x);                                  // LG  * gLG
+                x = fma(Le[2], Ee[2], x);                                  // LLC * gLLC
+                x = fma(dl_lig, Ee[3], x);                                 // LLEN * gLLEN
+                x = fma(Le[3], Ee[4], x);                                  // JS  * gJS
+                x = fma(Le[4], Ee[5], x);                                  // LA  * gLA
+                x = fma(T[1], Ee[6] + Le[5], x);                           // BPS * (hE + hL)
+                x = fma(T[2], Ee[7] + Le[7], x);                           // TGC * (hE + hL)
+                x = fma(T[3], Le[6], x);                                   // TA  * hL
+                // ---- record: the sum of the two windows' words, then the flag logic of design_mip ----
+                const uint32_t lo32 = (uint32_t)we | (uint32_t)wl_;
+                const uint32_t m = (uint32_t)(we >> 32) + (uint32_t)(wl_ >> 32);
+                const uint32_t nib = (m >> 16) | (m >> 20);               // bit 0 guard, 1 SNP with an alternate-allele arm, 2 SNP without, 3 copy <= 0
+                const uint32_t masked_n = m & 0xFFu, snp_all = (m >> 8) & 0xFFu;
+                const bool mapping = (um >> kci) & 1;                       // early return of design_mip: masking / SNP fields stay at their defaults
+                const bool guard = nib & 1;
+                uint32_t flags = MIPGEN_FLAG_VALID | ((nib & 1) << 1);      // MIPGEN_FLAG_GUARD = 2
+                uint32_t f2 = ((int)masked_n >= mthr ? MIPGEN_FLAG_MASKING : 0u)                                          // :610,626
+                              | (((nib & 4) || snp_all > 1) ? MIPGEN_FLAG_SNP : 0u)                                      // :690-693,759-760
+                              | ((nib & 2) << 4);                                                                        // MIPGEN_FLAG_HAS_SNP_MIP = 0x20
+                flags |= mapping ? MIPGEN_FLAG_MAPPING : f2;
+                const uint32_t snp_count = mapping ? 0u : snp_all;
+                const uint32_t hi32 = masked_n | (snp_count << 8) | (flags << 16) | (m & 0xFF000000u);
+                rec = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+                // ---- score = b^x / (1 + b^x), b = 2.71828 (SVMipv4.cpp:247): 2^(t/256) = 2^n * T[j] * (1 + r p(r)) with a 256-entry table ----
+                const double t = x * k256;
+                if (!(fabs(t) < 256000.0)) {                               // overflowing exponent (never seen: the libm route keeps the reference's inf / NaN)
+                    const double y = exp(x * HC->ln_base);
+                    score = y / (1.0 + y);
+                } else {
+                    const double tm = t + EXP_MAGIC;
+                    const int ti = __double2loint(tm);
+                    const double Tj = ((lds_cd*)XT)[ti & 255];
+                    const double r = t - (tm - EXP_MAGIC);
+                    double pp = fma(xc[3], r, xc[2]);
+                    pp = fma(pp, r, xc[1]);
+                    pp = fma(pp, r, xc[0]);
+                    const double y0 = fma(pp * r, Tj, Tj);
+                    const double y = __hiloint2double(__double2hiint(y0) + ((ti & ~255) << 12), __double2loint(y0));
+                    const double d = 1.0 + y;
+                    double rc = __builtin_amdgcn_rcp(d);
+                    rc = fma(fma(-d, rc, 1.0), rc, rc);
+                    const double q = y * rc;
+                    score = fma(fma(-d, q, y), rc, q);                     // one correction of the quotient: within an ulp of the division
                 }
-                const uint32_t jraw = (uint32_t)((wl_ >> 58) & 31);
-                const uint32_t jc = jraw < 16 ? jraw : 255u;
-                const uint32_t ec = (uint32_t)min(max(ext_copy, 0), 65535), lc = (uint32_t)min(max(lig_copy, 0), 65535);
-                rec = (uint64_t)ec | ((uint64_t)lc << 16) | ((uint64_t)min(masked_n, 255u) << 32) | ((uint64_t)min(snp_count, 255u) << 40) |
-                      ((uint64_t)flags << 48) | ((uint64_t)jc << 56);
+                if (nib & 8) score = __longlong_as_double(0xFFF8000000000000LL);   // a copy number <= 0: log10(0) = -inf (or NaN) meets terms of both signs: NaN
                 if (guard) score = -1000.0;                                // SVMipv4.cpp:116
-                else if (ext_copy <= 0 || lig_copy <= 0) score = __longlong_as_double(0xFFF8000000000000LL);   // log10(0) = -inf (or NaN) meets terms of both signs: NaN
-                else {
-                    double x = x0 + Ee[0];
-                    x += Le[0];
-                    x += T[0];
-                    x = fma(Le[1], Ee[1], x);                              // LG  * gLG
-                    x = fma(Le[2], Ee[2], x);                              // LLC * gLLC
-                    x = fma(dl_lig, Ee[3], x);                             // LLEN * gLLEN
-                    x = fma(Le[3], Ee[4], x);                              // JS  * gJS
-                    x = fma(Le[4], Ee[5], x);                              // LA  * gLA
-                    x = fma(T[1], Ee[6] + Le[5], x);                       // BPS * (hE + hL)
-                    x = fma(T[2], Ee[7] + Le[7], x);                       // TGC * (hE + hL)
-                    x = fma(T[3], Le[6], x);                               // TA  * hL
-                    score = logistic_from_exponent_rcp(HC, x);
-                }
             }
             records[out] = rec;
             scores[out] = score;
         }
     }
+    LD_STAMP(4)
     }   // strand
+#ifdef MIPGEN_DIAG
+    if (prof && lane == 0 && blockIdx.x < 512) for (int k = 0; k < 5; k++) prof[(blockIdx.x * 8 + wid) * 5 + k] = pc[k];
+#endif
 }
+
+#ifdef MIPGEN_DIAG
+static unsigned long long* g_ld_prof = nullptr;   // diagnostic builds only: cycles per stage, 512 blocks x 8 waves x 5
+extern "C" int mipgen_logistic_debug_dump(unsigned long long* host, int n)
+{
+    if (!g_ld_prof || n > 512 * 8 * 5) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpy(host, g_ld_prof, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" hipError_t mipgen_launch_logistic_dense(hipStream_t stream, int n_tiles, size_t lds_bytes, const DevParams* P, const DevRegion* regions,
                                                    const SvrTile* tiles, const uint8_t* bases, const int32_t* copy, const uint8_t* unmap,
@@ -278,6 +338,11 @@ extern "C" hipError_t mipgen_launch_logistic_dense(hipStream_t stream, int n_til
     if (n_tiles <= 0) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)k_logistic_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
+#ifdef MIPGEN_DIAG
+    if (!g_ld_prof && hipMalloc((void**)&g_ld_prof, 512 * 8 * 5 * sizeof(unsigned long long)) != hipSuccess) g_ld_prof = nullptr;
+    hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records, g_ld_prof);
+#else
     hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records);
+#endif
     return hipGetLastError();
 }
