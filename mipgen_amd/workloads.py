@@ -34,13 +34,16 @@ def practice62(seed: int = 20140101, genome_len: int = 400_000, n_regions: int =
 
 
 def svr_model_path(cache_dir: str, genome: bytes, n_sv: int, seed: int = 7, gamma: Optional[float] = None,
-                   coef_scale: float = 1.0) -> str:
+                   coef_scale: float = 1.0, rho: Optional[float] = None) -> str:
     os.makedirs(cache_dir, exist_ok=True)
-    tag = f"svr_syn_{n_sv}_s{seed}" + (f"_g{gamma:g}" if gamma is not None else "") + (f"_c{coef_scale:g}" if coef_scale != 1.0 else "")
+    tag = (f"svr_syn_{n_sv}_s{seed}" + (f"_g{gamma:g}" if gamma is not None else "") + (f"_c{coef_scale:g}" if coef_scale != 1.0 else "")
+           + (f"_r{rho:g}" if rho is not None else ""))
     path = os.path.join(cache_dir, tag + ".model")
     if not os.path.exists(path):
         tmp = path + f".tmp{os.getpid()}"
         kw = {} if gamma is None else {"gamma": gamma}
+        if rho is not None:
+            kw["rho"] = rho
         synth.synthetic_svr_model(tmp, genome, n_sv, seed=seed, coef_scale=coef_scale, **kw)
         os.replace(tmp, path)
     return path
