@@ -47,9 +47,11 @@ hipError_t mipgen_launch_fmt_records(hipStream_t, int write, int64_t n_rb, int r
                                      const char* letters, const int32_t* copy, const double* scores, const uint64_t* records, const uint8_t* emitted,
                                      const int64_t* rank0, const int64_t* off, int64_t* len_out, char* text);
 hipError_t mipgen_scan_i64(hipStream_t, void* temp, size_t* temp_bytes, const int64_t* in, int64_t* out, int64_t n);
-struct KmerParams { int32_t n_k; int32_t k[MIPGEN_MAX_OLIGO]; int32_t kmax; int32_t pad; uint64_t cap_mask; };
-hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, const KmerParams*, uint64_t* keys);
-hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, unsigned int* counts);
+struct KmerParams { int32_t n_k; int32_t k[MIPGEN_MAX_OLIGO]; int32_t kmax; int32_t filter_bits; uint64_t cap_mask; };   // as in kernels_kmer.hip
+hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, const KmerParams*, uint64_t* keys, uint32_t* filter);
+hipError_t mipgen_launch_kmer_fold(hipStream_t, const uint32_t* filter, int filter_bits, uint32_t* folded);
+hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, const uint32_t* filter,
+                                    const uint32_t* folded, unsigned int* counts, int n_cu);
 hipError_t mipgen_launch_kmer_lookup(hipStream_t, const char* seq, int64_t len, const KmerParams*, const uint64_t* keys, const unsigned int* counts, int32_t* out);
 hipError_t mipgen_launch_collapse(hipStream_t, int n_tiles, const CollapseTile* tiles, const DevParams*, const DevRegion*, const int64_t* region_pos0,
                                   const int64_t* region_base0, const mipgen_survivor* survivors, const int32_t* copy, int64_t cand_base, int32_t* collapsed);
@@ -1174,16 +1176,20 @@ int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char
     uint64_t cap = 1024;
     while (cap < 2 * (uint64_t)total) cap <<= 1;
     KP.cap_mask = cap - 1;
+    // Bloom filter of the regions' canonical kmin-mers: ~32 bits per region position (2-3 % false positives), at least the size of its LDS fold
+    KP.filter_bits = 18;
+    while (KP.filter_bits < 30 && (1ull << KP.filter_bits) < 32ull * (uint64_t)total) KP.filter_bits++;
     int64_t gmax = 0;
     for (int c = 0; c < n_chrom; c++) gmax = std::max(gmax, chrom_lens[c]);
     DevBuf<char> dq, dg;
     DevBuf<uint64_t> dkeys;
     DevBuf<unsigned int> dcounts;
+    DevBuf<uint32_t> dfilter, dfolded;
     DevBuf<int32_t> dout;
     const size_t tab = (size_t)cap * (size_t)n_lengths;
     int rc = 0;
-    if (dq.reserve((size_t)total) || dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || dkeys.reserve(tab) || dcounts.reserve(tab) || dout.reserve((size_t)total * (size_t)n_lengths)) rc = MIPGEN_E_NOMEM;
-    auto cleanup = [&]() { dq.release(); dg.release(); dkeys.release(); dcounts.release(); dout.release(); };
+    if (dq.reserve((size_t)total) || dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || dkeys.reserve(tab) || dcounts.reserve(tab) || dfilter.reserve((size_t)1 << (KP.filter_bits - 5)) || dfolded.reserve((size_t)1 << 13) || dout.reserve((size_t)total * (size_t)n_lengths)) rc = MIPGEN_E_NOMEM;
+    auto cleanup = [&]() { dq.release(); dg.release(); dkeys.release(); dcounts.release(); dfilter.release(); dfolded.release(); dout.release(); };
     hipEvent_t e0 = nullptr, e1 = nullptr;
 #define KTRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return fail(MIPGEN_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
     if (rc) { cleanup(); return rc; }
@@ -1191,14 +1197,16 @@ int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char
     KTRY(hipMemcpyAsync(dq.p, q.data(), (size_t)total, hipMemcpyHostToDevice, h->stream));
     KTRY(hipMemsetAsync(dkeys.p, 0xFF, tab * sizeof(uint64_t), h->stream));
     KTRY(hipMemsetAsync(dcounts.p, 0, tab * sizeof(unsigned int), h->stream));
-    KTRY(mipgen_launch_kmer_insert(h->stream, dq.p, total, &KP, dkeys.p));
+    KTRY(hipMemsetAsync(dfilter.p, 0, ((size_t)1 << (KP.filter_bits - 5)) * sizeof(uint32_t), h->stream));
+    KTRY(mipgen_launch_kmer_insert(h->stream, dq.p, total, &KP, dkeys.p, dfilter.p));
+    KTRY(mipgen_launch_kmer_fold(h->stream, dfilter.p, KP.filter_bits, dfolded.p));
     double ms_total = 0.0;
     int64_t gbytes = 0;
     for (int c = 0; c < n_chrom; c++) {                                // one streaming pass per chromosome: 1 byte per genome base
         if (chrom_lens[c] <= 0) continue;
         KTRY(hipMemcpyAsync(dg.p, chrom_seqs[c], (size_t)chrom_lens[c], hipMemcpyHostToDevice, h->stream));
         KTRY(hipEventRecord(e0, h->stream));
-        KTRY(mipgen_launch_kmer_count(h->stream, dg.p, chrom_lens[c], &KP, dkeys.p, dcounts.p));
+        KTRY(mipgen_launch_kmer_count(h->stream, dg.p, chrom_lens[c], &KP, dkeys.p, dfilter.p, dfolded.p, dcounts.p, h->n_cu));
         KTRY(hipEventRecord(e1, h->stream));
         KTRY(hipEventSynchronize(e1));
         float ms = 0.f;

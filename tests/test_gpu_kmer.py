@@ -49,6 +49,23 @@ def test_copy_counter_vs_dictionary_counter():
     acc.close()
 
 
+def test_copy_counter_large_design_takes_the_unfolded_filter():
+    """More than 2^16 region positions: the LDS fold of the Bloom filter is skipped and every genome position tests the full bitmap
+    (kernels_kmer.hip: use_fold); same counts as the dictionary counter."""
+    g1, g2 = _genome_with_repeats(seed=5)
+    P = capi.make_params(152, 162)
+    acc = capi.Accel(P)
+    lengths = sorted({e for e, _ in capi.arm_pairs_of(P)} | {l for _, l in capi.arm_pairs_of(P)})
+    regions = [g1[i:i + 2000].upper() for i in range(0, 58_000, 2000)] + [g2[i:i + 2000].upper() for i in range(0, 38_000, 2000)]
+    assert sum(len(r) + 1 for r in regions) * 32 > 1 << 21
+    got = acc.count_oligo_copies([g1, g2], regions, lengths)
+    for ri in (2, 6, 15, 20, 39):                             # incl. the regions holding the planted repeats
+        exp = po.count_oligo_copies([g1, g2], regions[ri], lengths)
+        for k in lengths:
+            assert np.array_equal(got[ri][k], exp[k]), (ri, k, np.nonzero(got[ri][k] != exp[k])[0][:5])
+    acc.close()
+
+
 def test_cli_with_gpu_copy_counter(tmp_path):
     """`mipgen ... -gpu_copy_counter on`: no bwa is run (the -bwa path does not even exist), the copy columns of all_mips are the exact
     occurrence counts of the printed arm sequences in the genome, and the design still tiles."""
