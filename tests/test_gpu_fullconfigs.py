@@ -1,0 +1,263 @@
+"""GPU: BASELINE.json configs[2] at its FULL size - all 1,000 regions of 5,000 bp, capture 120-250 (27 sizes x 57 arm pairs x 2 strands at
+5.2 M scan starts = 1.6e10 dense candidates), the logistic scan of the mixed design - through the silent fused path
+(mipgen_accel_score_condense_all: score -> replay of the early exits -> condense, window by window).  At this size the dense results
+(272 GB) do not fit HBM at once, so the result windows are exercised for real.  Checked through size-independent properties:
+
+  * the survivors do not depend on how the batch is cut into result windows, nor on how the regions are sharded over handles (= ranks);
+  * structural invariants of every survivor (its candidate lies in the row block of its own scan position and strand, it is valid,
+    not mapping-failed, and its score is the dense score the record came with);
+  * three regions drawn at random are re-scored alone, their dense grids replayed + condensed by the ORACLE
+    (/root/reference/mipgen.cpp:426-497, 1670-1746): identical survivors and emitted counts.
+"""
+import numpy as np
+import pytest
+
+from mipgen_amd import capi, workloads
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+N_REGIONS = 1000
+
+
+def _relative(surv, grids, pos0):
+    """cand_index relative to the region's own grid (batch layouts differ between shardings)."""
+    out = surv["cand_index"].copy()
+    for g, (a, b) in zip(grids, zip(pos0[:-1], pos0[1:])):
+        s = out[2 * a:2 * b]
+        s[s >= 0] -= g.offset
+    return out
+
+
+@pytest.fixture(scope="module")
+def full5k():
+    genome = workloads.regions5k_genome()
+    ivs = workloads.regions5k_intervals(N_REGIONS)
+    P = capi.make_params(120, 250, score_method=capi.SCORE_LOGISTIC)
+    regions = workloads.build_regions5k(None, genome, ivs, P, with_lrc=False)
+    acc = capi.Accel(P)
+    grids = acc.upload(regions)
+    n_win_auto = acc.window_count()
+    acc.score_condense_all(capi.SCORE_LOGISTIC)
+    emitted, surv = acc.download_survivors()
+    pos0 = np.concatenate([[0], np.cumsum([g.n_pos for g in grids])])
+    out = dict(P=P, regions=regions, grids=grids, emitted=emitted.copy(), surv=surv.copy(), pos0=pos0, n_win_auto=n_win_auto)
+    acc.close()                                            # its result windows hold most of the HBM: free them for the handles of the tests
+    yield out
+
+
+def test_full_config3_size_and_invariants(full5k):
+    P, grids, surv, emitted, pos0 = (full5k[k] for k in ("P", "grids", "surv", "emitted", "pos0"))
+    total = sum(g.count for g in grids)
+    assert len(grids) == N_REGIONS and total > 1.5e10 and all(g.n_sizes == 27 for g in grids)
+    assert full5k["n_win_auto"] >= 2                       # 16 B/candidate x 1.6e10 > 288 GB of HBM: the windows are real
+    assert surv.shape[0] == 2 * pos0[-1]
+    A = P.n_arm_pairs
+    rel = _relative(surv, grids, pos0)
+    have = rel >= 0
+    assert have.mean() > 0.5
+    per_pos = 27 * 2 * A
+    slot = np.arange(surv.shape[0])
+    pos_in_region = slot // 2 - np.repeat(pos0[:-1], 2 * np.diff(pos0))
+    assert np.array_equal(rel[have] // per_pos, pos_in_region[have])             # the survivor of a scan position is one of ITS candidates
+    assert np.array_equal((rel[have] // A) & 1, (slot & 1)[have])                # slot parity = strand
+    flags = capi.rec_flags(surv["record"][have])
+    assert np.all(flags & capi.FLAG_VALID) and not np.any(flags & capi.FLAG_MAPPING)
+    # emitted <= valid dense candidates, > 0 everywhere, and the early exits did remove candidates
+    assert np.all(emitted > 0) and emitted.sum() < total
+    # a scan position whose '+' slot is empty has an empty '-' slot only if nothing was constructed there... the two strands are emitted together
+    both = have.reshape(-1, 2)
+    assert (both[:, 0] | both[:, 1]).mean() > 0.9
+
+
+def test_windows_and_shards_do_not_change_the_survivors(full5k):
+    P, regions, grids, pos0 = (full5k[k] for k in ("P", "regions", "grids", "pos0"))
+    ref_rel = _relative(full5k["surv"], grids, pos0)
+    # (a) the same batch cut into ~8 windows
+    acc = capi.Accel(P)
+    acc.set_window_candidates(2_000_000_000)
+    g2 = acc.upload(regions)
+    assert acc.window_count() >= 8
+    acc.score_condense_all(capi.SCORE_LOGISTIC)
+    e2, s2 = acc.download_survivors()
+    assert np.array_equal(e2, full5k["emitted"])
+    assert np.array_equal(_relative(s2, g2, pos0), ref_rel)
+    assert np.array_equal(s2["record"], full5k["surv"]["record"]) and np.array_equal(s2["score"], full5k["surv"]["score"], equal_nan=True)
+    acc.close()
+    # (b) three contiguous shards on separate handles (what three ranks would hold), concatenated in region order
+    cuts = [0, 333, 700, N_REGIONS]
+    parts, emitted = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        a = capi.Accel(P)
+        gs = a.upload(regions[lo:hi])
+        a.score_condense_all(capi.SCORE_LOGISTIC)
+        e, s = a.download_survivors()
+        p0 = np.concatenate([[0], np.cumsum([g.n_pos for g in gs])])
+        parts.append((_relative(s, gs, p0), s["record"].copy(), s["score"].copy()))
+        emitted.append(e.copy())
+        a.close()
+    assert np.array_equal(np.concatenate(emitted), full5k["emitted"])
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), ref_rel)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), full5k["surv"]["record"])
+    assert np.array_equal(np.concatenate([p[2] for p in parts]), full5k["surv"]["score"], equal_nan=True)
+
+
+def test_sampled_regions_against_the_oracle(full5k):
+    P, regions, grids, pos0, surv, emitted = (full5k[k] for k in ("P", "regions", "grids", "pos0", "surv", "emitted"))
+    rng = np.random.default_rng(2024)
+    acc = capi.Accel(P)
+    for ri in sorted(rng.choice(N_REGIONS, 3, replace=False).tolist()):
+        rd = regions[ri]
+        _, scores, records = acc.score_regions([rd], capi.SCORE_LOGISTIC)
+        n_emit, omask = po.replay_region(P, rd, scores, records)
+        osurv = po.condense_region(P, rd, scores, records, omask)
+        mine = surv[2 * pos0[ri]:2 * pos0[ri + 1]]
+        assert emitted[ri] == n_emit
+        assert np.array_equal(np.where(mine["cand_index"] >= 0, mine["cand_index"] - grids[ri].offset, -1), osurv["cand_index"]), ri
+        assert np.array_equal(mine["record"], osurv["record"]) and np.array_equal(mine["score"], osurv["score"], equal_nan=True)
+        # and the survivor's score is the dense score of its candidate
+        ok = osurv["cand_index"] >= 0
+        assert np.array_equal(scores[osurv["cand_index"][ok]], mine["score"][ok], equal_nan=True)
+    acc.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# configs[3]: the whole synthetic exome (200,000 exon-like intervals on 24 chromosomes, 300 Mb), capture 150-170, SVR n_sv = 1024
+# ----------------------------------------------------------------------------------------------------------------------------------
+CACHE = "/tmp/mipgen_test_cache"
+TOL = 1e-5
+
+
+def _decode(P, g, idx):
+    A = P.n_arm_pairs
+    a = idx % A
+    row = idx // A
+    strand = row & 1
+    rest = row >> 1
+    ki, pi = rest % g.n_sizes, rest // g.n_sizes
+    return (0, g.first_pos + int(pi), P.max_capture_size - (g.first_size_index + int(ki)) * P.capture_increment,
+            P.arm_ext[int(a)], P.arm_lig[int(a)], int(strand))
+
+
+@pytest.fixture(scope="module")
+def exome_full():
+    chrom_len, ivs = workloads.exome_layout()
+    P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
+    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 1024, rho=-2.2)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    regions = workloads.build_exome(acc, chrom_len, ivs, P)
+    grids = acc.upload(regions)
+    acc.score_condense_all(capi.SCORE_SVR)
+    emitted, surv = acc.download_survivors()
+    pos0 = np.concatenate([[0], np.cumsum([g.n_pos for g in grids])])
+    out = dict(P=P, regions=regions, grids=grids, emitted=emitted.copy(), surv=surv.copy(), pos0=pos0, model=mp, ivs=ivs)
+    acc.close()
+    yield out
+
+
+def test_full_exome_svr(exome_full):
+    """2.5e10 dense candidates scored by the RBF-SVR in one fused pass.  Invariants of every survivor; a contiguous shard of 2,000 exons
+    scored alone (another handle = another rank) gives the same survivors; three exons against the oracle (replay + condense over the
+    dense grid of the exon scored alone, and the oracle's own libsvm arithmetic on sampled candidates)."""
+    P, regions, grids, surv, emitted, pos0 = (exome_full[k] for k in ("P", "regions", "grids", "surv", "emitted", "pos0"))
+    assert len(grids) == 200_000 and sum(g.count for g in grids) > 2.0e10
+    assert len({g.n_sizes for g in grids}) >= 3                               # the static skip leaves 1..5 capture sizes on short exons
+    A = P.n_arm_pairs
+    rel = _relative(surv, grids, pos0)
+    have = rel >= 0
+    slot = np.arange(surv.shape[0])
+    per_pos = np.repeat(np.array([g.n_sizes * 2 * A for g in grids]), 2 * np.diff(pos0))
+    pos_in_region = slot // 2 - np.repeat(pos0[:-1], 2 * np.diff(pos0))
+    assert np.array_equal(rel[have] // per_pos[have], pos_in_region[have])
+    assert np.array_equal((rel[have] // A) & 1, (slot & 1)[have])
+    assert np.all(capi.rec_flags(surv["record"][have]) & capi.FLAG_VALID)
+    assert 0 < emitted.sum() <= sum(g.count for g in grids)
+    # a shard alone
+    lo, hi = 70_000, 72_000
+    a = capi.Accel(P)
+    a.load_model_file(exome_full["model"])
+    gs = a.upload(regions[lo:hi])
+    a.score_condense_all(capi.SCORE_SVR)
+    e, s = a.download_survivors()
+    p0 = np.concatenate([[0], np.cumsum([g.n_pos for g in gs])])
+    assert np.array_equal(e, emitted[lo:hi])
+    assert np.array_equal(_relative(s, gs, p0), rel[2 * pos0[lo]:2 * pos0[hi]])
+    ref = surv[2 * pos0[lo]:2 * pos0[hi]]
+    assert np.array_equal(s["record"], ref["record"])
+    d = np.abs(s["score"] - ref["score"])                                     # a different SV split of the launch: sums in a different order
+    assert np.nanmax(d) < 1e-9
+    # the oracle on three exons
+    om = po.Model(exome_full["model"])
+    rng = np.random.default_rng(7)
+    sizes = np.array([g.count for g in grids])
+    pool = np.nonzero((sizes > 2_000) & (sizes < 400_000))[0]
+    for ri in sorted(rng.choice(pool, 3, replace=False).tolist()):
+        rd = regions[ri]
+        g1, scores, records = a.score_regions([rd], capi.SCORE_SVR)
+        n_emit, omask = po.replay_region(P, rd, scores, records)
+        osurv = po.condense_region(P, rd, scores, records, omask)
+        mine = surv[2 * pos0[ri]:2 * pos0[ri + 1]]
+        assert emitted[ri] == n_emit, ri
+        assert np.array_equal(np.where(mine["cand_index"] >= 0, mine["cand_index"] - grids[ri].offset, -1), osurv["cand_index"]), ri
+        assert np.array_equal(mine["record"], osurv["record"])
+        valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
+        lrc = np.array(rd.c.long_range_content[:])
+        for idx in rng.choice(valid, size=min(40, valid.size), replace=False):
+            sk, dsg = po.design(P, rd, _decode(P, g1[0], int(idx)))
+            assert not sk
+            so, _, _ = po.score_designed(dsg, capi.SCORE_SVR, lrc, om)
+            assert abs(scores[idx] - so) <= TOL or (np.isnan(scores[idx]) and np.isnan(so)), (ri, int(idx), scores[idx], so)
+    a.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# configs[4]: the exome with SNP masking (1 SNP / 300 bp) and the full 120-250 capture sweep (the 4,4 smMIP tags only change the
+# printed probe sequence, mipgen.cpp:790-792): 1.35e11 dense candidates, logistic scoring, ~10 result windows
+# ----------------------------------------------------------------------------------------------------------------------------------
+def test_full_exome_snps_full_sweep_logistic():
+    chrom_len, ivs = workloads.exome_layout()
+    P = capi.make_params(120, 250, score_method=capi.SCORE_LOGISTIC)
+    acc = capi.Accel(P)
+    regions = workloads.build_exome(None, chrom_len, ivs, P, snps=True, with_lrc=False)
+    grids = acc.upload(regions)
+    total = sum(g.count for g in grids)
+    assert total > 1.2e11 and acc.window_count() >= 8
+    acc.score_condense_all(capi.SCORE_LOGISTIC)
+    emitted, surv = acc.download_survivors()
+    pos0 = np.concatenate([[0], np.cumsum([g.n_pos for g in grids])])
+    assert surv.shape[0] == 2 * pos0[-1] and 0 < emitted.sum() < total
+    have = surv["cand_index"] >= 0
+    rec = surv["record"][have]
+    assert np.all(capi.rec_flags(rec) & capi.FLAG_VALID)
+    assert (capi.rec_snp_count(rec) > 0).sum() > 100_000                       # condensed survivors that sit on SNPs exist ...
+    assert (capi.rec_snp_count(rec) == 0).mean() > 0.5                         # ... but the fold prefers SNP-free arms (mipgen.cpp:1725)
+    # shards anywhere in the batch, alone on a second handle, give the same survivors; three of their exons go through the oracle
+    rng = np.random.default_rng(99)
+    a = capi.Accel(P)
+    for lo in (1_000, 123_456):
+        hi = lo + 500
+        gs = a.upload(regions[lo:hi])
+        a.score_condense_all(capi.SCORE_LOGISTIC)
+        e, s = a.download_survivors()
+        p0 = np.concatenate([[0], np.cumsum([g.n_pos for g in gs])])
+        assert np.array_equal(e, emitted[lo:hi])
+        assert np.array_equal(_relative(s, gs, p0), _relative(surv[2 * pos0[lo]:2 * pos0[hi]].copy(), grids[lo:hi], pos0[lo:hi + 1] - pos0[lo]))
+        assert np.array_equal(s["record"], surv["record"][2 * pos0[lo]:2 * pos0[hi]])
+        assert np.array_equal(s["score"], surv["score"][2 * pos0[lo]:2 * pos0[hi]], equal_nan=True)
+        sizes = np.array([g.count for g in gs])
+        for k in rng.choice(np.nonzero(sizes < 3_000_000)[0], 2, replace=False).tolist():
+            ri = lo + int(k)
+            rd = regions[ri]
+            _, scores, records = a.score_regions([rd], capi.SCORE_LOGISTIC)
+            _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_LOGISTIC, None)
+            assert np.array_equal(records, or_), ri
+            with np.errstate(invalid="ignore"):
+                assert np.all((np.abs(scores - os_) <= TOL) | (np.isnan(scores) & np.isnan(os_))), ri
+            n_emit, omask = po.replay_region(P, rd, scores, records)
+            osurv = po.condense_region(P, rd, scores, records, omask)
+            mine = surv[2 * pos0[ri]:2 * pos0[ri + 1]]
+            assert emitted[ri] == n_emit
+            assert np.array_equal(np.where(mine["cand_index"] >= 0, mine["cand_index"] - grids[ri].offset, -1), osurv["cand_index"]), ri
+            assert np.array_equal(mine["record"], osurv["record"])
+    a.close()
+    acc.close()
