@@ -640,7 +640,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                     const int kc = ki1 - ki0;
                     const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
                     const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum, ssr = ssmax - ssmin + 1;
-                    int np = std::max(1, std::min({lanes / kc, 64, d.n_pos}));
+                    int np = std::max(1, std::min(lanes / kc, d.n_pos));       // every lane of a pair chunk owns one (position, capture size)
                     size_t lds_t = 0;
                     for (; np >= 1; np--) {
                         lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
@@ -650,6 +650,9 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
                     // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping):
                     // taken when it costs few positions
                     { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 10 >= np * 9) { np = np_cf; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
+                    // the same number of tiles, evenly filled (the last tile of a region is not a stub that costs a full table stage)
+                    { const int nt = (d.n_pos + np - 1) / np, np_even = (d.n_pos + nt - 1) / nt;
+                      if (np_even < np) { np = np_even; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
                     runs.push_back({ki0, kc, np});
                     lds_r = std::max(lds_r, lds_t);
                     const double tiles = std::ceil((double)d.n_pos / np);
