@@ -386,6 +386,8 @@ def main() -> None:
             "config": {"workload": desc, "n_sv": n_sv, "regions_rank0": len(regions), "dense_candidates_rank0": n_cand,
                        "dense_candidates_all_ranks": total_cand, "result_windows_rank0": acc.window_count(),
                        "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()),
+                       # reference-equivalent rate: candidates the reference would have constructed, per second (rank 0's share)
+                       "emitted_candidates_per_s_rank0": float(emitted.sum()) * args.steps / dt,
                        "survivors_gathered_per_step": survivors_gathered},
             "roofline": roof,
             "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},
