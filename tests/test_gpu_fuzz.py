@@ -73,3 +73,49 @@ def test_random_configuration(cfg):
                 so, _, _ = po.score_designed(dsg, method, np.array(rd.c.long_range_content[:]), om if method == capi.SCORE_SVR else None)
                 assert abs(scores[idx] - so) <= TOL or (np.isnan(scores[idx]) and np.isnan(so)), (cfg[:4], cand, scores[idx], so)
         acc.close()
+
+
+def _pair_lists():
+    """Arm-pair lists of many shapes: one pair, one list, lists of unequal length, exactly 63 / 64 pairs (the single-wavefront replay,
+    kernels_replay.hip: k_replay_condense_narrow) and 65 / 100 pairs (the chunked kernel), grouped by arm sum as the reference walks them."""
+    def by_sums(sums, e_lo, e_hi, l_lo, l_hi, cap=None):
+        out = []
+        for s in sums:
+            out += [(e, s - e) for e in range(e_lo, e_hi + 1) if l_lo <= s - e <= l_hi]
+        return out[:cap] if cap else out
+    return {
+        "A1": [(20, 22)],
+        "A2_one_list": [(19, 23), (20, 22)],
+        "A7_two_lists": by_sums([44, 41], 18, 22, 20, 24),
+        "A57_default": None,
+        "A63": by_sums(range(50, 40, -1), 16, 27, 18, 30, cap=63),
+        "A64": by_sums(range(50, 40, -1), 16, 27, 18, 30, cap=64),
+        "A65": by_sums(range(50, 40, -1), 16, 27, 18, 30, cap=65),
+        "A100": by_sums(range(52, 38, -1), 16, 28, 18, 30, cap=100),
+    }
+
+
+@pytest.mark.parametrize("name", list(_pair_lists()))
+@pytest.mark.parametrize("heuristic", [True, False])
+def test_replay_condense_over_pair_list_shapes(name, heuristic):
+    """Replay of the early exits (mipgen.cpp:426-497) + condense (:1670-1746) against the oracle for arm-pair lists of every shape, with the
+    logistic heuristic on and off, hashed copy numbers (copy-driven takes) and an N run (guard scores) in reach."""
+    pairs = _pair_lists()[name]
+    genome = bytearray(H.golden_genome())
+    genome[9000:9008] = b"NNNNNNNN"
+    genome = bytes(genome)
+    P = capi.make_params(150, 165, score_method=capi.SCORE_LOGISTIC, arm_pairs=pairs, logistic_heuristic=heuristic)
+    acc = capi.Accel(P)
+    rd = capi.build_region(genome, "1", 8950, 9150, P, bwa_mode="hashed", label=name)
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_LOGISTIC)
+    acc.replay_condense()
+    emitted, surv, mask = acc.download_replay()
+    n_emit, omask = po.replay_region(P, rd, scores, records)
+    assert emitted[0] == n_emit and np.array_equal(mask, omask), (name, heuristic)
+    osurv = po.condense_region(P, rd, scores, records, omask)
+    assert np.array_equal(surv["cand_index"], osurv["cand_index"]), (name, heuristic)
+    assert np.array_equal(surv["record"], osurv["record"])
+    assert np.array_equal(surv["score"], osurv["score"], equal_nan=True)
+    if heuristic and P.n_arm_pairs > 2:
+        assert n_emit < int(((capi.rec_flags(records) & capi.FLAG_VALID) != 0).sum())      # the heuristic exit did fire
+    acc.close()
