@@ -30,7 +30,6 @@ hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t
 hipError_t mipgen_launch_candidates(hipStream_t, int n, const DevParams*, const DevRegion*, const mipgen_candidate*, const uint8_t*,
                                     const int32_t*, const uint8_t*, const HostConsts*, const double* model, int n_sv, double gamma,
                                     double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*);
-hipError_t mipgen_launch_svr_batch(hipStream_t, int n, const double* feats, const uint64_t* records, const double* model, int n_sv, double gamma, double rho, double* scores);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
@@ -48,6 +47,10 @@ hipError_t mipgen_launch_fmt_records(hipStream_t, int write, int64_t n_rb, int r
                                      const int64_t* rank0, const int64_t* off, int64_t* len_out, char* text);
 hipError_t mipgen_scan_i64(hipStream_t, void* temp, size_t* temp_bytes, const int64_t* in, int64_t* out, int64_t n);
 struct KmerParams { int32_t n_k; int32_t k[MIPGEN_MAX_OLIGO]; int32_t kmax; int32_t filter_bits; uint64_t cap_mask; };   // as in kernels_kmer.hip
+hipError_t mipgen_launch_features_batch(hipStream_t, int n, const DevParams*, const DevRegion*, const mipgen_candidate*, const uint8_t* bases, const int32_t* copy,
+                                        const uint8_t* unmap, const HostConsts*, uint64_t* records, double* features);
+hipError_t mipgen_launch_svr_gemm(hipStream_t, int n, const double* feats, const uint64_t* records, const double* model_t, const double* sv_norm,
+                                  const double* sv_coef, const double* center, int n_sv_pad, double gamma, double rho, double* scores);
 hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, const KmerParams*, uint64_t* keys, uint32_t* filter);
 hipError_t mipgen_launch_kmer_fold(hipStream_t, const uint32_t* filter, int filter_bits, uint32_t* folded);
 hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, const uint32_t* filter,
@@ -157,6 +160,8 @@ struct mipgen_accel {
     DevBuf<CollapseTile> col_tiles;
     DevBuf<int32_t> collapsed;
     bool collapsed_valid = false;
+    DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
+    int n_sv_pad = 0;
     double kmer_count_ms = -1.0;             // genome pass of the last mipgen_accel_count_oligo_copies
     int64_t kmer_genome_bytes = 0;
     bool replayed = false, mask_valid = false;
@@ -323,7 +328,7 @@ void mipgen_accel_destroy(mipgen_accel* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->model.release(); h->regions.release(); h->bases.release(); h->unmap.release(); h->copy.release();
+    h->model.release(); h->model_t.release(); h->sv_norm.release(); h->sv_coef.release(); h->sv_center.release(); h->regions.release(); h->bases.release(); h->unmap.release(); h->copy.release();
     h->log_tiles.release(); h->svr_tiles.release(); h->ld_tiles.release(); h->scores.release(); h->records.release();
     h->emitted.release(); h->survivors.release(); h->emitted_per_region.release(); h->pos_region.release(); h->pos_local.release();
     h->letters.release(); h->fmt_regions.release(); h->fmt_pool.release(); h->fmt_text.release(); h->fmt_temp.release();
@@ -339,6 +344,37 @@ void mipgen_accel_destroy(mipgen_accel* h)
 }
 
 // ---- model ----------------------------------------------------------------------------------------------------
+// The list scorer's view of the model (kernels_svr_gemm.hip): support vectors centred on their mean and transposed to [feature][SV], the
+// centred squared norms (+ the squares of libsvm indices > 192, which candidates never have: svm.cpp:359-363), the coefficients; the SV
+// count padded to a multiple of 64 with zero-coefficient columns.
+static int build_list_model(mipgen_accel* h, const std::vector<double>& rows, int n_sv)
+{
+    const int pad = std::max(64, (n_sv + 63) / 64 * 64);
+    std::vector<double> center(MIPGEN_N_FEATURES, 0.0), mt((size_t)MIPGEN_N_FEATURES * pad, 0.0), sn((size_t)pad, 0.0), cf((size_t)pad, 0.0);
+    for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
+        double s = 0.0;
+        for (int i = 0; i < n_sv; i++) s += rows[(size_t)i * SV_ROW + j];
+        center[(size_t)j] = n_sv ? s / n_sv : 0.0;
+    }
+    for (int i = 0; i < n_sv; i++) {
+        double q = 0.0;
+        for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
+            const double v = rows[(size_t)i * SV_ROW + j] - center[(size_t)j];
+            mt[(size_t)j * pad + i] = v;
+            q += v * v;
+        }
+        sn[(size_t)i] = q + rows[(size_t)i * SV_ROW + SVR_N_EXTRA];
+        cf[(size_t)i] = rows[(size_t)i * SV_ROW + SVR_COEF];
+    }
+    if (h->model_t.reserve(mt.size()) || h->sv_norm.reserve(sn.size()) || h->sv_coef.reserve(cf.size()) || h->sv_center.reserve(center.size())) return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpy(h->model_t.p, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->sv_norm.p, sn.data(), sn.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->sv_coef.p, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->sv_center.p, center.data(), center.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->n_sv_pad = pad;
+    return MIPGEN_OK;
+}
+
 int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double rho, const double* coef, const double* sv)
 {
     if (!h || n_sv < 0 || (n_sv > 0 && (!coef || !sv))) return fail(MIPGEN_E_INVALID, "bad model arguments");
@@ -365,7 +401,7 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
     if (h->model.reserve(rows.size())) return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho;
-    return MIPGEN_OK;
+    return build_list_model(h, rows, n_sv);
 }
 
 // libsvm 3.17 text model (grammar: svm.cpp:2779-2962)
@@ -435,6 +471,7 @@ int mipgen_accel_load_model_file(mipgen_accel* h, const char* path)
         }
         HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
         h->s_guard = sg - rho;
+        return build_list_model(h, rows, total_sv);
     }
     return MIPGEN_OK;
 }
@@ -930,14 +967,20 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
         (features && h->cand_feats.reserve((size_t)n * MIPGEN_N_FEATURES)) || (ints && h->cand_ints.reserve((size_t)n)))
         return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpyAsync(h->cand_in.p, cands, (size_t)n * sizeof(mipgen_candidate), hipMemcpyHostToDevice, h->stream));
-    // long SVR lists (a mixed design re-scores every condensed survivor): features per candidate first, then the model streamed through LDS
-    // once per 32 candidates (k_svr_batch) instead of once per candidate
+    // long SVR lists (a mixed design re-scores every condensed survivor): features + records by k_features_batch (a wavefront per candidate),
+    // then all candidate x support-vector distances through the FP64 matrix cores (k_svr_gemm) instead of one model walk per candidate
     const bool batched = method == MIPGEN_SCORE_SVR && n >= 256 && scores;
     if (batched && h->cand_feats.reserve((size_t)n * MIPGEN_N_FEATURES)) return MIPGEN_E_NOMEM;
-    HIP_TRY(mipgen_launch_candidates(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
-                                     h->model.p, h->n_sv, h->gamma, h->rho, method, batched ? nullptr : h->cand_scores.p, h->cand_records.p,
-                                     (features || batched) ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
-    if (batched) HIP_TRY(mipgen_launch_svr_batch(h->stream, n, h->cand_feats.p, h->cand_records.p, h->model.p, h->n_sv, h->gamma, h->rho, h->cand_scores.p));
+    if (batched && !ints)
+        // lists: one wavefront per candidate for the features + records, then the matrix-core scorer
+        HIP_TRY(mipgen_launch_features_batch(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->cand_records.p,
+                                             h->cand_feats.p));
+    else
+        HIP_TRY(mipgen_launch_candidates(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
+                                         h->model.p, h->n_sv, h->gamma, h->rho, method, batched ? nullptr : h->cand_scores.p, h->cand_records.p,
+                                         (features || batched) ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
+    if (batched) HIP_TRY(mipgen_launch_svr_gemm(h->stream, n, h->cand_feats.p, h->cand_records.p, h->model_t.p, h->sv_norm.p, h->sv_coef.p, h->sv_center.p, h->n_sv_pad,
+                                            h->gamma, h->rho, h->cand_scores.p));
     if (scores) HIP_TRY(hipMemcpyAsync(scores, h->cand_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (records) HIP_TRY(hipMemcpyAsync(records, h->cand_records.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     if (features) HIP_TRY(hipMemcpyAsync(features, h->cand_feats.p, (size_t)n * MIPGEN_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, h->stream));

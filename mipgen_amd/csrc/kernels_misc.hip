@@ -54,6 +54,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     mipgen_candidate_ints* __restrict__ ints_out)
 {
     __shared__ uint8_t s_ext[MIPGEN_MAX_OLIGO + 2], s_lig[MIPGEN_MAX_OLIGO + 2], s_ins[MAX_INSERT + 2];
+    __shared__ uint8_t s_raw[2][MIPGEN_MAX_OLIGO + 2];     // the arms' bytes as stored (code | masked bit | SNP class), in genome order
     __shared__ int s_cnt[128];          // 0..83 insert mers, 84..103 ext mers, 104..123 lig mers
     __shared__ double s_x[MIPGEN_N_FEATURES];
     __shared__ double s_red[CAND_THREADS / WAVE];
@@ -84,24 +85,31 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     };
     // oriented sequences (codes); complement + reverse on '-'
     for (int i = tid; i < e; i += CAND_THREADS) {
-        int b = base_at(minus ? ext_start + e - 1 - i : ext_start + i) & BASE_CODE_MASK;
+        const int off = minus ? e - 1 - i : i;
+        const uint8_t raw = base_at(ext_start + off);
+        s_raw[0][off] = raw;
+        const int b = raw & BASE_CODE_MASK;
         s_ext[i] = (uint8_t)(minus ? comp_code(b) : b);
     }
     for (int i = tid; i < l; i += CAND_THREADS) {
-        int b = base_at(minus ? lig_start + l - 1 - i : lig_start + i) & BASE_CODE_MASK;
+        const int off = minus ? l - 1 - i : i;
+        const uint8_t raw = base_at(lig_start + off);
+        s_raw[1][off] = raw;
+        const int b = raw & BASE_CODE_MASK;
         s_lig[i] = (uint8_t)(minus ? comp_code(b) : b);
     }
     for (int i = tid; i < ss; i += CAND_THREADS) {
         int b = base_at(minus ? p + ss - 1 - i : p + i) & BASE_CODE_MASK;
         s_ins[i] = (uint8_t)(minus ? comp_code(b) : b);
     }
+    __syncthreads();
     // integer record fields (design_mip, mipgen.cpp:606-760)
     if (tid == 0) {
         int masked_n = 0, snp_any = 0, snp_bad = 0, snp_ok = 0, bad = 0;
         for (int arm = 0; arm < 2; arm++) {
-            int s0 = arm == 0 ? ext_start : lig_start, n = arm == 0 ? e : l;
+            const int n = arm == 0 ? e : l;
             for (int i = 0; i < n; i++) {
-                uint8_t b = base_at(s0 + i);
+                const uint8_t b = s_raw[arm][i];
                 int code = b & BASE_CODE_MASK, snp = (b >> BASE_SNP_SHIFT) & 3;
                 masked_n += (b & BASE_MASKED_BIT) != 0;
                 snp_any += snp != 0; snp_bad += snp == 2; snp_ok += snp == 1;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
         const int eA = s_cnt[84 + 0], eC = s_cnt[84 + 5], eG = s_cnt[84 + 10], eT = s_cnt[84 + 15];
         const int lA = s_cnt[104 + 0], lC = s_cnt[104 + 5], lG = s_cnt[104 + 10], lT = s_cnt[104 + 15];
         const int tA = s_cnt[0], tC = s_cnt[21], tG = s_cnt[42], tT = s_cnt[63];
-        const int run = run_count_slow(s_ins, 0, ss, false);
+        const int run = (ints_out || method == MIPGEN_SCORE_LOGISTIC) ? run_count_slow(s_ins, 0, ss, false) : 1;   // a serial walk of the insert: only where it is used
         if (ints_out) {
             mipgen_candidate_ints o;
             o.ext_a = eA; o.ext_c = eC; o.ext_g = eG; o.ext_t = eT;
@@ -239,6 +247,159 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
         for (int w = 0; w < CAND_THREADS / WAVE; w++) s += s_red[w];
         scores[blockIdx.x] = s - rho;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_features_batch: the 192 features + the integer record of every candidate of a LIST, one WAVEFRONT per candidate (the list scorer's
+// front end: kernels_svr_gemm.hip).  Same values as k_candidates (SVMipv4.cpp:60-113, mipgen.cpp:606-760) - the mer counts come from an LDS
+// histogram filled by one pass over the oriented sequences (a lane per start position, three atomic increments) instead of one lane per
+// mer walking the whole sequence, the record's counts from wave ballots over the arms' bytes.
+// ---------------------------------------------------------------------------------------------------------
+#define FB_WAVES 4
+
+__global__ __launch_bounds__(FB_WAVES * 64) void k_features_batch(
+    int n, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, const mipgen_candidate* __restrict__ cands,
+    const uint8_t* __restrict__ bases, const int32_t* __restrict__ copy, const uint8_t* __restrict__ unmap, const HostConsts* __restrict__ HC,
+    uint64_t* __restrict__ records, double* __restrict__ features)
+{
+    __shared__ uint8_t s_ext_a[FB_WAVES][MIPGEN_MAX_OLIGO + 2], s_lig_a[FB_WAVES][MIPGEN_MAX_OLIGO + 2], s_ins_a[FB_WAVES][MAX_INSERT + 2];
+    __shared__ int s_cnt_a[FB_WAVES][128];          // 0..83 insert mers, 84..103 ext mers, 104..123 lig mers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci = blockIdx.x * FB_WAVES + wave;
+    if (ci >= n) return;
+    uint8_t* s_ext = s_ext_a[wave]; uint8_t* s_lig = s_lig_a[wave]; uint8_t* s_ins = s_ins_a[wave];
+    int* s_cnt = s_cnt_a[wave];
+    const mipgen_candidate c = cands[ci];
+    const DevRegion& R = regions[c.region];
+    const int p = c.scan_start, C = c.capture_size, e = c.ext_len, l = c.lig_len;
+    const bool minus = c.strand != 0;
+    const int ss = C - e - l;
+    const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) &&
+                       ss > 0 && ss <= MAX_INSERT && e <= MIPGEN_MAX_OLIGO && l <= MIPGEN_MAX_OLIGO && e >= 2 && l >= 2;
+    double* fo = features + (int64_t)ci * MIPGEN_N_FEATURES;
+    if (!valid) {
+        if (lane == 0) records[ci] = 0;
+        for (int j = lane; j < MIPGEN_N_FEATURES; j += 64) fo[j] = 0.0;
+        return;
+    }
+    const int ext_start = minus ? p + ss : p - e;
+    const int lig_start = minus ? p - l : p + ss;
+    auto base_at = [&](int pos) -> uint8_t {
+        const int ri = pos - R.seq_start;
+        return (ri >= 0 && ri < R.seq_len) ? bases[R.seq_off + ri] : (uint8_t)BASE_OTHER;
+    };
+    s_cnt[lane] = 0; s_cnt[lane + 64] = 0;
+    // arms: lane i holds byte i of the arm in genome order; oriented codes go to LDS
+    const uint8_t raw_e = lane < e ? base_at(ext_start + lane) : (uint8_t)0, raw_l = lane < l ? base_at(lig_start + lane) : (uint8_t)0;
+    if (lane < e) { const int b = raw_e & BASE_CODE_MASK; s_ext[minus ? e - 1 - lane : lane] = (uint8_t)(minus ? comp_code(b) : b); }
+    if (lane < l) { const int b = raw_l & BASE_CODE_MASK; s_lig[minus ? l - 1 - lane : lane] = (uint8_t)(minus ? comp_code(b) : b); }
+    for (int i = lane; i < ss; i += 64) {
+        const int b = base_at(minus ? p + ss - 1 - i : p + i) & BASE_CODE_MASK;
+        s_ins[i] = (uint8_t)(minus ? comp_code(b) : b);
+    }
+    // integer record fields (design_mip, mipgen.cpp:606-760): counts over the arms' bytes by wave ballots
+    const bool in_e = lane < e, in_l = lane < l;
+    auto cnt2 = [&](bool pe, bool pl) -> int { return __builtin_popcountll(__ballot(in_e && pe)) + __builtin_popcountll(__ballot(in_l && pl)); };
+    const int snp_e = (raw_e >> BASE_SNP_SHIFT) & 3, snp_l = (raw_l >> BASE_SNP_SHIFT) & 3;
+    const int code_e = raw_e & BASE_CODE_MASK, code_l = raw_l & BASE_CODE_MASK;
+    const int masked_n = cnt2((raw_e & BASE_MASKED_BIT) != 0, (raw_l & BASE_MASKED_BIT) != 0);
+    const int snp_any = cnt2(snp_e != 0, snp_l != 0), snp_bad = cnt2(snp_e == 2, snp_l == 2), snp_ok = cnt2(snp_e == 1, snp_l == 1);
+    const int bad = cnt2(code_e == BASE_N || code_e == BASE_DASH, code_l == BASE_N || code_l == BASE_DASH);
+    int ext_copy = 1, lig_copy = 1;
+    if (R.copy_off >= 0) {
+        const int se = P->len_slot[e], sl = P->len_slot[l];
+        const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
+        ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
+        lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
+    }
+    bool mapping = false;
+    {
+        const int k = (P->max_capture - C) / P->inc;
+        if (R.unmap_off >= 0 && P->check_copy_number && k >= 0 && k < P->n_sizes_all) {
+            const int ms = (minus ? lig_start : ext_start) - R.seq_start;
+            if (ms >= 0 && ms < R.seq_len) mapping = unmap[R.unmap_off + (int64_t)k * R.seq_len + ms] != 0;
+        }
+    }
+    uint32_t flags = MIPGEN_FLAG_VALID | (bad ? MIPGEN_FLAG_GUARD : 0u);
+    int snp_count = 0;
+    if (mapping) flags |= MIPGEN_FLAG_MAPPING;
+    else {
+        if ((double)masked_n / (double)(l + e) > P->masked_arm_threshold) flags |= MIPGEN_FLAG_MASKING;
+        snp_count = snp_any;
+        if (snp_bad != 0 || snp_count > 1) flags |= MIPGEN_FLAG_SNP;
+        if (snp_ok != 0) flags |= MIPGEN_FLAG_HAS_SNP_MIP;
+    }
+    const bool guard = bad != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int j0 = s_lig[0], j1 = s_lig[1];
+    const int jc = (j0 < 4 && j1 < 4) ? 4 * j0 + j1 : 255;
+    if (lane == 0) {
+        const uint32_t ec = (uint32_t)min(max(ext_copy, 0), 65535), lc = (uint32_t)min(max(lig_copy, 0), 65535);
+        records[ci] = (uint64_t)ec | ((uint64_t)lc << 16) | ((uint64_t)min(masked_n, 255) << 32) | ((uint64_t)min(snp_count, 255) << 40) |
+                      ((uint64_t)flags << 48) | ((uint64_t)(uint32_t)jc << 56);
+    }
+    // mer histogram: a lane per window start; windows touching a non-ACGT code count nowhere (count_mer compares codes 0..3)
+    for (int i = lane; i < ss; i += 64) {
+        const int x = s_ins[i];
+        if (x < 4) {
+            atomicAdd(&s_cnt[21 * x], 1);
+            if (i + 1 < ss) {
+                const int y = s_ins[i + 1];
+                if (y < 4) {
+                    atomicAdd(&s_cnt[21 * x + 1 + 5 * y], 1);
+                    if (i + 2 < ss) { const int z = s_ins[i + 2]; if (z < 4) atomicAdd(&s_cnt[21 * x + 1 + 5 * y + 1 + z], 1); }
+                }
+            }
+        }
+    }
+    if (lane < e) {
+        const int x = s_ext[lane];
+        if (x < 4) { atomicAdd(&s_cnt[84 + 5 * x], 1); if (lane + 1 < e) { const int y = s_ext[lane + 1]; if (y < 4) atomicAdd(&s_cnt[84 + 5 * x + 1 + y], 1); } }
+    }
+    if (lane < l) {
+        const int x = s_lig[lane];
+        if (x < 4) { atomicAdd(&s_cnt[104 + 5 * x], 1); if (lane + 1 < l) { const int y = s_lig[lane + 1]; if (y < 4) atomicAdd(&s_cnt[104 + 5 * x + 1 + y], 1); } }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 192 features, SVMipv4.cpp:72-112 (the arithmetic of k_candidates, three features per lane)
+    for (int f = lane; f < MIPGEN_N_FEATURES; f += 64) {
+        double v;
+        if (guard) v = 0.0;
+        else if (f < F_LRC) {                         // ext block
+            if (f == F_EXT_LEN) v = (double)e;
+            else if (f == F_EXT_GC) v = ((double)s_cnt[84 + 10] + (double)s_cnt[84 + 5]) / (double)(uint64_t)((uint64_t)e - 1 + 1);
+            else { int idx = f < F_EXT_GC ? f : f - 1; int k = (idx % 5) ? 2 : 1; v = (double)s_cnt[84 + idx] / ((double)(uint64_t)((uint64_t)e - k) + 1.); }
+        } else if (f < F_INS) v = R.lrc[f - F_LRC];
+        else if (f < F_LIG) {                         // insert block
+            const int g = f - F_INS;
+            if (f == F_INS_LEN) v = (double)ss;
+            else if (f == F_INS_GC) v = ((double)s_cnt[42] + (double)s_cnt[21]) / ((double)(uint64_t)((uint64_t)ss - 1) + 1.);
+            else {
+                int idx = g < 63 ? g : g - 1;
+                int r = idx % 21; int k = r == 0 ? 1 : (((r - 1) % 5) == 0 ? 2 : 3);
+                v = (double)s_cnt[idx] / ((double)(uint64_t)((uint64_t)ss - k) + 1.);
+            }
+        } else if (f < F_JUNC) {                      // lig block
+            const int g = f - F_LIG;
+            if (f == F_LIG_LEN) v = (double)l;
+            else if (f == F_LIG_GC) v = ((double)s_cnt[104 + 10] + (double)s_cnt[104 + 5]) / ((double)(uint64_t)((uint64_t)l - 1) + 1.);
+            else { int idx = g < 15 ? g : g - 1; int k = (idx % 5) ? 2 : 1; v = (double)s_cnt[104 + idx] / ((double)(uint64_t)((uint64_t)l - k) + 1.); }
+        } else if (f < F_LEC) v = (jc == f - F_JUNC) ? 1.0 : 0.0;
+        else v = log_copy_dev(HC, f == F_LEC ? ext_copy : lig_copy);
+        fo[f] = v;
+    }
+}
+
+extern "C" hipError_t mipgen_launch_features_batch(hipStream_t stream, int n, const DevParams* P, const DevRegion* regions, const mipgen_candidate* cands,
+                                                   const uint8_t* bases, const int32_t* copy, const uint8_t* unmap, const HostConsts* HC, uint64_t* records,
+                                                   double* features)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_features_batch, dim3((n + FB_WAVES - 1) / FB_WAVES), dim3(FB_WAVES * 64), 0, stream, n, P, regions, cands, bases, copy, unmap, HC, records,
+                       features);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t mipgen_launch_candidates(
@@ -306,78 +467,3 @@ extern "C" hipError_t mipgen_launch_long_range(hipStream_t stream, int n, const 
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_svr_batch: the RBF-SVR of a LIST of candidates from their 192 features (mixed designs re-score every condensed survivor).
-// k_candidates walks the whole model per candidate (n_sv x 192 doubles from L2 per candidate: ~0.4 us each, bound by model traffic).
-// Here a workgroup takes 32 candidates and streams the model through LDS in chunks of 64 support vectors, so a model row is read
-// once per 32 candidates; a thread owns 4 candidates x 2 support vectors (6 LDS reads feed 8 subtract + multiply-add pairs per
-// dimension: FP64-issue bound, not LDS bound).  Same arithmetic as svm.cpp:329-368, 2511-2515: sum_j (x_j - sv_j)^2 in index order per
-// (candidate, SV), exp(-gamma d2), coefficient-weighted sum (the order of that last sum differs from the reference's: ~1e-13).
-// ---------------------------------------------------------------------------------------------------------
-#define SB_CANDS 32
-#define SB_SVS 64
-#define SB_PITCH 193                 // doubles per staged row (192 features + 1: odd pitch spreads the banks)
-
-__global__ __launch_bounds__(256) void k_svr_batch(int n, const double* __restrict__ feats, const uint64_t* __restrict__ records,
-                                                   const double* __restrict__ model, int n_sv, double gamma, double rho, double* __restrict__ scores)
-{
-    extern __shared__ __align__(16) double sm[];
-    double* X = sm;                                   // [SB_CANDS][SB_PITCH]
-    double* S = X + SB_CANDS * SB_PITCH;              // [SB_SVS][SB_PITCH]
-    double* aux = S + SB_SVS * SB_PITCH;              // [SB_SVS][2]: coef, extra |sv|^2 of libsvm indices > 192
-    double* red = aux + SB_SVS * 2;                   // [32 sgrps][SB_CANDS]
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * SB_CANDS;
-    for (int i = tid; i < SB_CANDS * MIPGEN_N_FEATURES; i += 256) {
-        const int c = i / MIPGEN_N_FEATURES, j = i - c * MIPGEN_N_FEATURES;
-        X[c * SB_PITCH + j] = (c0 + c < n) ? feats[(int64_t)(c0 + c) * MIPGEN_N_FEATURES + j] : 0.0;
-    }
-    const int cg = tid & 7, sg = tid >> 3;            // 8 candidate groups of 4, 32 SV lanes of 2
-    const double* x0 = X + (cg * 4 + 0) * SB_PITCH; const double* x1 = x0 + SB_PITCH; const double* x2 = x1 + SB_PITCH; const double* x3 = x2 + SB_PITCH;
-    double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, sum3 = 0.0;
-    for (int s0 = 0; s0 < n_sv; s0 += SB_SVS) {
-        __syncthreads();
-        for (int i = tid; i < SB_SVS * MIPGEN_N_FEATURES; i += 256) {
-            const int s = i / MIPGEN_N_FEATURES, j = i - s * MIPGEN_N_FEATURES;
-            S[s * SB_PITCH + j] = (s0 + s < n_sv) ? model[(int64_t)(s0 + s) * SV_ROW + j] : 0.0;
-        }
-        if (tid < SB_SVS) {
-            aux[2 * tid] = (s0 + tid < n_sv) ? model[(int64_t)(s0 + tid) * SV_ROW + SVR_COEF] : 0.0;       // padding rows: coefficient 0
-            aux[2 * tid + 1] = (s0 + tid < n_sv) ? model[(int64_t)(s0 + tid) * SV_ROW + SVR_N_EXTRA] : 0.0;
-        }
-        __syncthreads();
-        const double* va = S + (sg * 2) * SB_PITCH; const double* vb = va + SB_PITCH;
-        double d0a = 0, d1a = 0, d2a = 0, d3a = 0, d0b = 0, d1b = 0, d2b = 0, d3b = 0;
-#pragma unroll 4
-        for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
-            const double a = va[j], b = vb[j], p0 = x0[j], p1 = x1[j], p2 = x2[j], p3 = x3[j];
-            double t;
-            t = p0 - a; d0a = fma(t, t, d0a); t = p1 - a; d1a = fma(t, t, d1a); t = p2 - a; d2a = fma(t, t, d2a); t = p3 - a; d3a = fma(t, t, d3a);
-            t = p0 - b; d0b = fma(t, t, d0b); t = p1 - b; d1b = fma(t, t, d1b); t = p2 - b; d2b = fma(t, t, d2b); t = p3 - b; d3b = fma(t, t, d3b);
-        }
-        const double ca = aux[4 * sg], ea = aux[4 * sg + 1], cb = aux[4 * sg + 2], eb = aux[4 * sg + 3];
-        sum0 += ca * exp(-gamma * (d0a + ea)) + cb * exp(-gamma * (d0b + eb));
-        sum1 += ca * exp(-gamma * (d1a + ea)) + cb * exp(-gamma * (d1b + eb));
-        sum2 += ca * exp(-gamma * (d2a + ea)) + cb * exp(-gamma * (d2b + eb));
-        sum3 += ca * exp(-gamma * (d3a + ea)) + cb * exp(-gamma * (d3b + eb));
-    }
-    __syncthreads();
-    red[sg * SB_CANDS + cg * 4 + 0] = sum0; red[sg * SB_CANDS + cg * 4 + 1] = sum1; red[sg * SB_CANDS + cg * 4 + 2] = sum2; red[sg * SB_CANDS + cg * 4 + 3] = sum3;
-    __syncthreads();
-    if (tid < SB_CANDS && c0 + tid < n) {
-        double s = 0.0;
-        for (int k = 0; k < 32; k++) s += red[k * SB_CANDS + tid];
-        scores[c0 + tid] = (MIPGEN_REC_FLAGS(records[c0 + tid]) & MIPGEN_FLAG_VALID) ? s - rho : 0.0;     // a candidate the bounds skips remove scores 0, as in k_candidates
-    }
-}
-
-extern "C" hipError_t mipgen_launch_svr_batch(hipStream_t stream, int n, const double* feats, const uint64_t* records, const double* model, int n_sv, double gamma,
-                                              double rho, double* scores)
-{
-    if (n <= 0) return hipSuccess;
-    const size_t lds = (size_t)(SB_CANDS * SB_PITCH + SB_SVS * SB_PITCH + SB_SVS * 2 + 32 * SB_CANDS) * sizeof(double);
-    hipError_t e = hipFuncSetAttribute((const void*)k_svr_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_svr_batch, dim3((n + SB_CANDS - 1) / SB_CANDS), dim3(256), lds, stream, n, feats, records, model, n_sv, gamma, rho, scores);
-    return hipGetLastError();
-}

@@ -630,8 +630,9 @@ def test_collapse_on_device(name, genome):
 
 
 def test_batched_candidate_rescoring(genome):
-    """Lists of >= 256 candidates take the batched SVR kernel (features per candidate, then the model streamed through LDS once per 32
-    candidates): same scores as the one-workgroup-per-candidate kernel and as the oracle, incl. guard / zero-copy / invalid candidates."""
+    """Lists of >= 256 candidates take the list path (k_features_batch: a wavefront per candidate, then k_svr_gemm: distances through the
+    FP64 matrix cores): same features / records / scores as the one-workgroup-per-candidate kernel and as the oracle, incl. guard /
+    zero-copy / invalid candidates."""
     meta = H.load_design("mixed_small")
     P = H.design_params(meta)
     regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
@@ -649,9 +650,13 @@ def test_batched_candidate_rescoring(genome):
             ki, pi = rest % g.n_sizes, rest // g.n_sizes
             cands.append((ri, g.first_pos + int(pi), P.max_capture_size - (g.first_size_index + int(ki)) * P.capture_increment, P.arm_ext[int(a)], P.arm_lig[int(a)], int(strand)))
     cands.append((0, 3, 130, 20, 22, 0))                                    # fails the bounds skips
-    batched, rec_b, _, _ = acc.score_candidates(cands, capi.SCORE_SVR)
-    single = np.concatenate([acc.score_candidates(cands[i:i + 100], capi.SCORE_SVR)[0] for i in range(0, len(cands), 100)])
-    assert np.nanmax(np.abs(batched - single)) < 1e-11
+    batched, rec_b, feat_b, _ = acc.score_candidates(cands, capi.SCORE_SVR, want_features=True)
+    parts = [acc.score_candidates(cands[i:i + 100], capi.SCORE_SVR, want_features=True) for i in range(0, len(cands), 100)]
+    single = np.concatenate([q[0] for q in parts])
+    assert np.nanmax(np.abs(batched - single)) < 1e-10
+    # the list path's feature / record kernel (one wavefront per candidate, histogram mer counts) against the per-candidate kernel: bit for bit
+    assert np.array_equal(rec_b, np.concatenate([q[1] for q in parts]))
+    assert np.array_equal(feat_b, np.concatenate([q[2] for q in parts]), equal_nan=True)
     assert batched[-1] == 0.0 and (capi.rec_flags(rec_b[-1:]) & capi.FLAG_VALID)[0] == 0
     n_guard = 0
     for k in rng.choice(len(cands) - 1, size=250, replace=False):
