@@ -437,6 +437,33 @@ def main() -> None:
                           "ms_per_step": d1 / reps * 1e3, "k_records_logistic_ms": lk,
                           "roofline": {"bound": "hbm", "achieved": alg_bytes / (lk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": alg_bytes / (lk * 1e-3) / 1e9 / HBM_PEAK_GBS}})
+            # mixed designs (BASELINE configs[2]): the condensed survivors of the logistic scan re-scored by the SVR as ONE list - features per
+            # candidate (k_features_batch), then all candidate x SV distances on the FP64 matrix cores (k_svr_gemm)
+            acc.load_model_file(model_path)
+            _, lsurv = acc.download_survivors()
+            A = P.n_arm_pairs
+            lc = []
+            pos = 0
+            for ri, gr in enumerate(acc.grids):
+                sv = lsurv[2 * pos:2 * (pos + gr.n_pos)]
+                idx = sv["cand_index"][sv["cand_index"] >= 0] - gr.offset
+                a_ = idx % A; row = idx // A; st = row & 1; rest = row >> 1; ki = rest % gr.n_sizes; pi = rest // gr.n_sizes
+                lc += [(ri, gr.first_pos + int(pi[k]), P.max_capture_size - (gr.first_size_index + int(ki[k])) * P.capture_increment,
+                        P.arm_ext[int(a_[k])], P.arm_lig[int(a_[k])], int(st[k])) for k in range(idx.shape[0])]
+                pos += gr.n_pos
+            if len(lc) >= 256:
+                acc.score_candidates(lc, capi.SCORE_SVR)
+                acc.score_candidates(lc, capi.SCORE_SVR)
+                gms, fms = acc.last_kernel_ms(5), acc.last_kernel_ms(6)
+                nsv_l = acc.model_info()[0]
+                fl = 2.0 * len(lc) * ((nsv_l + 63) // 64 * 64) * 192
+                extra.append({"what": f"mixed-mode re-scoring of the {len(lc)} condensed survivors of the logistic scan as one list (n_sv={nsv_l})",
+                              "value": len(lc) / ((fms + gms) * 1e-3), "unit": "re-scored candidates/s (the two kernels; HIP events)",
+                              "k_features_batch_ms": fms, "k_svr_gemm_ms": gms,
+                              "roofline": {"bound": "mfma", "achieved": fl / (gms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": fl / (gms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "kernel": "k_svr_gemm",
+                                           "note": "v_mfma_f64_16x16x4f64 flops of the candidate x SV products / HIP-event kernel time; the FP64 matrix "
+                                                   "peak of MI355X equals its vector peak (78.6 TFLOP/s); the kernel also takes one exp2 per pair"}})
             # arm-oligo copy numbers by exact k-mer counting - one streaming pass over the genome (1 B / base)
             from mipgen_amd import synth
             gsz = 64 << 20

@@ -328,7 +328,8 @@ int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
 /* ---- instrumentation ------------------------------------------------------------------------------ */
 /* HIP-event time (ms) of the kernels of the last scoring call (summed over its windows), measured on the handle's stream;
  * negative if unavailable.  which: 0 = dense SVR kernel, 1 = records + scoring kernels, 2 = records / logistic kernel,
- * 3 = replay + condense; 4 = genome pass of the last mipgen_accel_count_oligo_copies (always recorded). */
+ * 3 = replay + condense; 4 = genome pass of the last mipgen_accel_count_oligo_copies (always recorded);
+ * 5 / 6 = the matrix-core SVR kernel / the feature kernel of the last mipgen_accel_score_candidates call on a list (>= 256 SVR candidates). */
 double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which);
 /* enable/disable per-call event timing (it inserts two hipEventRecord per call) */
 int mipgen_accel_set_timing(mipgen_accel* h, int32_t enabled);

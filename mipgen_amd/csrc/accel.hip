@@ -163,6 +163,7 @@ struct mipgen_accel {
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
     int n_sv_pad = 0;
     double kmer_count_ms = -1.0;             // genome pass of the last mipgen_accel_count_oligo_copies
+    double list_feat_ms = -1.0, list_svr_ms = -1.0;   // k_features_batch / k_svr_gemm of the last list call (timing enabled)
     int64_t kmer_genome_bytes = 0;
     bool replayed = false, mask_valid = false;
     // sparse scratch
@@ -971,6 +972,9 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
     // then all candidate x support-vector distances through the FP64 matrix cores (k_svr_gemm) instead of one model walk per candidate
     const bool batched = method == MIPGEN_SCORE_SVR && n >= 256 && scores;
     if (batched && h->cand_feats.reserve((size_t)n * MIPGEN_N_FEATURES)) return MIPGEN_E_NOMEM;
+    hipEvent_t le[3] = {nullptr, nullptr, nullptr};
+    const bool time_list = batched && !ints && h->timing;
+    if (time_list) { for (hipEvent_t& e : le) HIP_TRY(hipEventCreate(&e)); HIP_TRY(hipEventRecord(le[0], h->stream)); }
     if (batched && !ints)
         // lists: one wavefront per candidate for the features + records, then the matrix-core scorer
         HIP_TRY(mipgen_launch_features_batch(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->cand_records.p,
@@ -979,13 +983,20 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
         HIP_TRY(mipgen_launch_candidates(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
                                          h->model.p, h->n_sv, h->gamma, h->rho, method, batched ? nullptr : h->cand_scores.p, h->cand_records.p,
                                          (features || batched) ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
+    if (time_list) HIP_TRY(hipEventRecord(le[1], h->stream));
     if (batched) HIP_TRY(mipgen_launch_svr_gemm(h->stream, n, h->cand_feats.p, h->cand_records.p, h->model_t.p, h->sv_norm.p, h->sv_coef.p, h->sv_center.p, h->n_sv_pad,
                                             h->gamma, h->rho, h->cand_scores.p));
+    if (time_list) HIP_TRY(hipEventRecord(le[2], h->stream));
     if (scores) HIP_TRY(hipMemcpyAsync(scores, h->cand_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (records) HIP_TRY(hipMemcpyAsync(records, h->cand_records.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     if (features) HIP_TRY(hipMemcpyAsync(features, h->cand_feats.p, (size_t)n * MIPGEN_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (ints) HIP_TRY(hipMemcpyAsync(ints, h->cand_ints.p, (size_t)n * sizeof(mipgen_candidate_ints), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (time_list) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, le[0], le[1]) == hipSuccess && hipEventElapsedTime(&b, le[1], le[2]) == hipSuccess) { h->list_feat_ms = a; h->list_svr_ms = b; }
+        for (hipEvent_t e : le) (void)hipEventDestroy(e);
+    }
     return MIPGEN_OK;
 }
 
@@ -1282,6 +1293,8 @@ int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char
 double mipgen_accel_last_kernel_ms(mipgen_accel* h, int32_t which)
 {
     if (h && which == 4) return h->kmer_count_ms;
+    if (h && which == 5) return h->list_svr_ms;
+    if (h && which == 6) return h->list_feat_ms;
     if (!h || !h->timing) return -1.0;
     if (hipSetDevice(h->device) != hipSuccess) return -1.0;
     double total = 0.0;

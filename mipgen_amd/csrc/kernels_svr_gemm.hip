@@ -8,7 +8,7 @@
 //        |x - s|^2 = |x - c|^2 + |s - c|^2 - 2 (x - c).(s - c)
 // with c the mean support vector (centring keeps the three terms of the size of the distance itself: the cancellation costs ~1e-15
 // relative, against libsvm's own summation order ~1e-13).  The products run on v_mfma_f64_16x16x4f64; a wavefront owns 16 candidates
-// x 64 support vectors (four accumulator tiles), the centred candidate tile sits in LDS (bank-conflict-free pitch), the centred model is
+// x 64 support vectors (four accumulator tiles), its A operands (the centred candidate features) stay in registers, the centred model is
 // stored TRANSPOSED in HBM ([feature][support vector], 1.5 MB for 1,024 SVs: L2 resident) so that the B operands are coalesced
 // 128-byte rows read straight into registers; one exponential per (candidate, SV) follows in the epilogue of each SV tile.
 //
@@ -20,7 +20,6 @@
 #include "exp2_coef.h"
 
 #define SG_CANDS 64                  // candidates per workgroup (4 wavefronts x 16)
-#define SG_PITCH 194                 // doubles per staged candidate row: 194 * 2 = 4 (mod 64) banks -> the 64 A-operand lanes hit 64 distinct banks
 #define SG_SVT 64                    // support vectors per tile (4 MFMA tiles per wavefront)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -44,58 +43,52 @@ __device__ __forceinline__ double exp2_poly(double t)
 }  // namespace
 
 // feats [n][192]; records [n] (valid flag); model_t [192][n_sv_pad] centred; sv_norm [n_sv_pad] = |s - c|^2 (+ the squares of libsvm
-// indices > 192); sv_coef [n_sv_pad] (0 for the padding); center [192]; n_sv_pad a multiple of SG_SVT
+// indices > 192); sv_coef [n_sv_pad] (0 for the padding); center [192]; n_sv_pad a multiple of SG_SVT.
+// No LDS: a lane keeps its 48 A operands (candidate lane & 15, features (lane >> 4) + 4 t) in registers for the whole support-vector loop, so
+// three workgroups share a compute unit and the B-operand loads of one wavefront hide behind the matrix instructions of the others; the
+// four wavefronts of a workgroup read the same model rows at about the same time (L1 hits).
 __global__ __launch_bounds__(256) void k_svr_gemm(int n, const double* __restrict__ feats, const uint64_t* __restrict__ records,
                                                   const double* __restrict__ model_t, const double* __restrict__ sv_norm,
                                                   const double* __restrict__ sv_coef, const double* __restrict__ center, int n_sv_pad,
                                                   double gamma_l2e, double rho, double* __restrict__ scores)
 {
-    extern __shared__ __align__(16) double sm[];
-    double* X = sm;                                   // [SG_CANDS][SG_PITCH]: centred features (non-finite ones replaced by 0)
-    double* xn = X + SG_CANDS * SG_PITCH;             // [SG_CANDS]: |x - c|^2
-    int* special = (int*)(xn + SG_CANDS);             // [SG_CANDS]: 1 = a feature is +-inf (every kernel value is 0), 2 = a feature is NaN
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.x * SG_CANDS;
-    if (tid < SG_CANDS) special[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < SG_CANDS * MIPGEN_N_FEATURES; i += 256) {
-        const int c = i / MIPGEN_N_FEATURES, j = i - c * MIPGEN_N_FEATURES;
-        double v = (c0 + c < n) ? feats[(int64_t)(c0 + c) * MIPGEN_N_FEATURES + j] : 0.0;
-        if (!(fabs(v) <= 1.7976931348623157e308)) {                                  // log10(copy <= 0): -inf or NaN (SVMipv4.cpp:109-112)
-            atomicOr(&special[c], v != v ? 2 : 1);
-            v = center[j];
-        }
-        X[c * SG_PITCH + j] = v - center[j];
-    }
-    __syncthreads();
-    if (tid < SG_CANDS) {
-        double s = 0.0;
-        for (int j = 0; j < MIPGEN_N_FEATURES; j++) { const double v = X[tid * SG_PITCH + j]; s = fma(v, v, s); }
-        xn[tid] = s;
-    }
-    __syncthreads();
-
-    // this lane's operands: A[i][k] with i = lane & 15 (candidate wave*16 + i), k = lane >> 4; B[k][j] with j = lane & 15
+    const int c0 = blockIdx.x * SG_CANDS + wave * 16;                 // first candidate of this wavefront
+    // this lane's operands: A[i][k] with i = lane & 15, k = lane >> 4; B[k][j] with j = lane & 15
     const int li = lane & 15, lk = lane >> 4;
-    const double* xa = X + (wave * 16 + li) * SG_PITCH + lk;
+    const bool have = c0 + li < n;
+    const double* xrow = feats + (int64_t)(have ? c0 + li : 0) * MIPGEN_N_FEATURES + lk;
+    double xa[MIPGEN_N_FEATURES / 4];
+    double q = 0.0;
+    int special = 0;                                                  // 1 = a feature is +-inf (every kernel value is 0), 2 = a feature is NaN
+#pragma unroll
+    for (int t = 0; t < MIPGEN_N_FEATURES / 4; t++) {
+        double v = have ? xrow[4 * t] : 0.0;
+        const double cj = center[lk + 4 * t];
+        if (!(fabs(v) <= 1.7976931348623157e308)) { special |= v != v ? 2 : 1; v = cj; }      // log10(copy <= 0): -inf or NaN (SVMipv4.cpp:109-112)
+        v = have ? v - cj : 0.0;
+        xa[t] = v;
+        q = fma(v, v, q);
+    }
+    // |x - c|^2 and the special flags of candidate li: over the four lanes li, li + 16, li + 32, li + 48
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    special |= __shfl_xor(special, 16, 64); special |= __shfl_xor(special, 32, 64);
     // D rows of this lane: i = (lane >> 4) + 4 r
     double xr[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) xr[r] = xn[wave * 16 + lk + 4 * r];
+    for (int r = 0; r < 4; r++) xr[r] = __shfl(q, lk + 4 * r, 64);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};             // score partial sums of the lane's four candidates over its support-vector columns
-    const double two_g = 2.0 * gamma_l2e;
     for (int s0 = 0; s0 < n_sv_pad; s0 += SG_SVT) {
         double4_t d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, d2 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
         const double* bp = model_t + (int64_t)lk * n_sv_pad + s0 + li;
-#pragma unroll 4
-        for (int k = 0; k < MIPGEN_N_FEATURES; k += 4) {
-            const double a = xa[k];
-            const double* b = bp + (int64_t)k * n_sv_pad;
+#pragma unroll
+        for (int t = 0; t < MIPGEN_N_FEATURES / 4; t++) {
+            const double* b = bp + (int64_t)(4 * t) * n_sv_pad;
             const double b0 = b[0], b1 = b[16], b2 = b[32], b3 = b[48];
-            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, d1, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, d2, 0, 0, 0);
-            d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, d3, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b0, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b1, d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b2, d2, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b3, d3, 0, 0, 0);
         }
         // epilogue: K = 2^(-gamma log2(e) (|x|^2 + |s|^2 - 2 x.s)); column j = s0 + 16 t + li
 #pragma unroll
@@ -109,7 +102,6 @@ __global__ __launch_bounds__(256) void k_svr_gemm(int n, const double* __restric
             }
         }
     }
-    (void)two_g;
     // sum over the 16 lanes that share lane >> 4 (the columns), then one lane per row writes
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -117,17 +109,16 @@ __global__ __launch_bounds__(256) void k_svr_gemm(int n, const double* __restric
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
         acc[r] = v;
     }
-    if (li == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int c = wave * 16 + lk + 4 * r;
-            if (c0 + c < n) {
-                double s = acc[r] - rho;
-                if (special[c] & 2) s = __longlong_as_double(0x7FF8000000000000LL);   // a NaN feature poisons every kernel value
-                else if (special[c] & 1) s = -rho;                                     // an infinite distance: every kernel value is 0
-                if (!(MIPGEN_REC_FLAGS(records[c0 + c]) & MIPGEN_FLAG_VALID)) s = 0.0; // a candidate the bounds skips remove scores 0, as in k_candidates
-                scores[c0 + c] = s;
-            }
+    for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r;                                    // candidate c0 + row; its flags sit in lane `row`
+        const int sp = __shfl(special, row, 64);
+        if (li == 0 && c0 + row < n) {
+            double s = acc[r] - rho;
+            if (sp & 2) s = __longlong_as_double(0x7FF8000000000000LL);              // a NaN feature poisons every kernel value
+            else if (sp & 1) s = -rho;                                               // an infinite distance: every kernel value is 0
+            if (!(MIPGEN_REC_FLAGS(records[c0 + row]) & MIPGEN_FLAG_VALID)) s = 0.0; // a candidate the bounds skips remove scores 0, as in k_candidates
+            scores[c0 + row] = s;
         }
     }
 }
@@ -137,10 +128,7 @@ extern "C" hipError_t mipgen_launch_svr_gemm(hipStream_t stream, int n, const do
                                              double rho, double* scores)
 {
     if (n <= 0) return hipSuccess;
-    const size_t lds = (size_t)(SG_CANDS * SG_PITCH + SG_CANDS) * sizeof(double) + SG_CANDS * sizeof(int);
-    hipError_t e = hipFuncSetAttribute((const void*)k_svr_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_svr_gemm, dim3((n + SG_CANDS - 1) / SG_CANDS), dim3(256), lds, stream, n, feats, records, model_t, sv_norm, sv_coef, center,
+    hipLaunchKernelGGL(k_svr_gemm, dim3((n + SG_CANDS - 1) / SG_CANDS), dim3(256), 0, stream, n, feats, records, model_t, sv_norm, sv_coef, center,
                        n_sv_pad, gamma * 1.4426950408889634074, rho, scores);
     return hipGetLastError();
 }
