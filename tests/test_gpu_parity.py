@@ -698,3 +698,65 @@ def test_all_mips_records_formatted_on_device(name, genome):
         assert got[-1] == b"" and len(got) - 1 == len(ref) == first
         bad = [i for i, (a, b) in enumerate(zip(got, ref)) if a != b]
         assert not bad, (name, cap, bad[0], got[bad[0]][:160], ref[bad[0]][:160])
+
+
+def test_list_scorer_special_values(genome):
+    """The list path (k_features_batch + k_svr_gemm) on the candidates whose feature vectors are not ordinary numbers: an N in an arm (all-zero
+    vector, SVMipv4.cpp:63-68), a copy number of 0 (log10 = -inf: every kernel value 0, score -rho), a negative copy number (log10 = NaN: the
+    score is NaN) and, for contrast, copy numbers above 100 (feature 2.0).  Scores against the oracle's own libsvm arithmetic; features and
+    records bit-identical to the per-candidate kernel."""
+    g = bytearray(genome)
+    g[9_100:9_104] = b"NNNN"
+    g = bytes(g)
+    P = capi.make_params(150, 160, score_method=capi.SCORE_SVR)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_200.model")
+    om = po.Model(mp)
+    rd0 = capi.build_region(g, "1", 9_000, 9_200, P, bwa_mode="unique", label="sp", lrc=np.full(44, 0.02))
+    lengths = sorted({e for e, _ in capi.arm_pairs_of(P)} | {l for _, l in capi.arm_pairs_of(P)})
+    rng = np.random.default_rng(17)
+    copy = {}
+    for ln in lengths:
+        c = np.ones(rd0.c.seq_len, dtype=np.int32)
+        u = rng.random(rd0.c.seq_len)
+        c[u < 0.05] = 0
+        c[(u >= 0.05) & (u < 0.08)] = -3
+        c[(u >= 0.08) & (u < 0.12)] = 250
+        copy[ln] = c
+    rd = capi.RegionData(rd0.c.start_flanked, rd0.c.stop_flanked, rd0.c.seq_start, rd0.seq, masked=rd0.masked if rd0.masked is not None else rd0.seq,
+                         copy=copy, lrc=[0.02] * 44, chrom="1", label="sp",
+                         start=rd0.start, stop=rd0.stop)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    grids = acc.upload([rd])
+    gr = grids[0]
+    A = P.n_arm_pairs
+    cands = []
+    for idx in rng.choice(gr.count, size=3000, replace=False):
+        a = idx % A; row = idx // A; strand = row & 1; rest = row >> 1
+        ki, pi = rest % gr.n_sizes, rest // gr.n_sizes
+        cands.append((0, gr.first_pos + int(pi), P.max_capture_size - (gr.first_size_index + int(ki)) * P.capture_increment, P.arm_ext[int(a)], P.arm_lig[int(a)], int(strand)))
+    sc, rec, feat, _ = acc.score_candidates(cands, capi.SCORE_SVR, want_features=True)
+    parts = [acc.score_candidates(cands[i:i + 200], capi.SCORE_SVR, want_features=True) for i in range(0, len(cands), 200)]
+    assert np.array_equal(rec, np.concatenate([q[1] for q in parts]))
+    assert np.array_equal(feat, np.concatenate([q[2] for q in parts]), equal_nan=True)
+    one = np.concatenate([q[0] for q in parts])
+    assert np.array_equal(np.isnan(sc), np.isnan(one))
+    assert np.nanmax(np.abs(sc - one)) < 1e-10
+    flags = capi.rec_flags(rec)
+    valid = (flags & capi.FLAG_VALID) != 0
+    guard = valid & ((flags & capi.FLAG_GUARD) != 0)
+    assert guard.sum() > 20 and np.isnan(sc).sum() > 20 and np.isinf(feat).any() and (feat[:, 190:192] == 2.0).any()
+    rho = acc.model_info()[2]
+    zero = valid & ~guard & ~np.isnan(sc) & (np.isinf(feat[:, 190]) | np.isinf(feat[:, 191]))
+    assert zero.sum() > 20 and np.all(sc[zero] == -rho)
+    lrc = np.array(rd.c.long_range_content[:])
+    pick = np.concatenate([np.nonzero(guard)[0][:30], np.nonzero(np.isnan(sc))[0][:30], np.nonzero(zero)[0][:30], rng.choice(len(cands), 150, replace=False)])
+    for k in pick:
+        c = cands[int(k)]
+        sk, d = po.design(P, rd, (0,) + c[1:])
+        if sk:
+            assert sc[int(k)] == 0.0
+            continue
+        so, _, _ = po.score_designed(d, capi.SCORE_SVR, lrc, om)
+        assert abs(sc[int(k)] - so) <= 1e-5 or (np.isnan(so) and np.isnan(sc[int(k)])), (c, sc[int(k)], so)
+    acc.close()
