@@ -219,21 +219,23 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
 def main() -> None:
     if not (po.have_refdrv() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mipgen_ref"))):
         raise SystemExit("oracle/_ref is not built: run `make -C oracle all` where /root/reference exists")
+    only = set(sys.argv[1:])                               # names of designs to (re)generate; none = everything
     genome = synth.random_genome(20000, 101, n_run_frac=0.003, n_run_len=6)
-    with gzip.GzipFile(os.path.join(HERE, "genome_chr1.fa.gz"), "wb", mtime=0) as gz:
-        gz.write(b">chr1\n")
-        for i in range(0, len(genome), 60):
-            gz.write(genome[i:i + 60] + b"\n")
-    gen_models(genome)
-    gen_candidates(genome)
+    if not only:
+        with gzip.GzipFile(os.path.join(HERE, "genome_chr1.fa.gz"), "wb", mtime=0) as gz:
+            gz.write(b">chr1\n")
+            for i in range(0, len(genome), 60):
+                gz.write(genome[i:i + 60] + b"\n")
+        gen_models(genome)
+        gen_candidates(genome)
     for d in DESIGNS:
-        gen_design(genome, d)
+        if not only or d["name"] in only:
+            gen_design(genome, d)
     genome2 = synth.random_genome(80000, 202, n_run_frac=0.002, n_run_len=8)
     with gzip.GzipFile(os.path.join(HERE, "genome2_chr1.fa.gz"), "wb", mtime=0) as gz:
         gz.write(b">chr1\n")
         for i in range(0, len(genome2), 60):
             gz.write(genome2[i:i + 60] + b"\n")
-    only = set(sys.argv[1:])
     for d in DESIGNS2:
         if not only or d["name"] in only:
             gen_design(genome2, d, "genome2_chr1.fa.gz")
@@ -249,6 +251,11 @@ def main() -> None:
               sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="unique", model=None, extra=[], chrom="7")
     if not only or d1["name"] in only:
         gen_design(g7, d1, "genome_practice62_chr7.fa.gz")
+    # BASELINE configs[1]: the same 62 regions, capture 140-180, SVR scoring (a 64-SV synthetic model keeps the reference's run at minutes),
+    # -silent_mode on: the 15.5 M all_mips records are not written, the collapsed / picked / snp files are what is compared
+    d2 = dict(d1, name="practice62_config2_svr", method="svr", minC=140, maxC=180, model="svr_syn_64.model", extra=["-silent_mode", "on"])
+    if not only or d2["name"] in only:
+        gen_design(g7, d2, "genome_practice62_chr7.fa.gz")
 
 
 if __name__ == "__main__":
