@@ -2,6 +2,7 @@
 // driver (one libmipgen_accel handle per GPU, sequential selection stage on the calling thread).
 // Reference: /root/reference/mipgen.cpp:2021-2037 main, :293-400 query_sequences, :403-556 tile_regions.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -60,8 +61,22 @@ extern "C" {
 const char* mipgen_host_last_error(void) { return g_err; }
 int mipgen_host_last_circumstance(void) { return g_circumstance; }
 
+// $MIPGEN_TIMING=1: wall-clock seconds of the front end's stages on stderr (diagnostics of the host side only; the accelerator library
+// reads no environment)
+struct StageClock {
+    bool on = std::getenv("MIPGEN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what)
+    {
+        const auto n = std::chrono::steady_clock::now();
+        if (on) std::cerr << "[mipgen timing] " << what << ": " << std::chrono::duration<double>(n - t).count() << " s\n";
+        t = n;
+    }
+};
+
 int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
 {
+    StageClock clk;
     if (!out_d || argc < 1 || !argv) return fail(MIPGEN_HOST_E_USAGE, 1, "null argument");
     *out_d = nullptr;
     g_err[0] = 0; g_circumstance = 0;
@@ -83,14 +98,18 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         // ---- query_sequences ---------------------------------------------------------------------------------
         d->regions = load_regions(o);
         if (d->regions.empty()) { std::cerr << "[mipgen] region file could not be opened" << std::endl; throw 6; }
+        clk.lap("options + BED sort / merge");
         out.progress << "successfully loaded features for mip design; retrieving chromosomal sequence\n";
         std::cerr << "[mipgen] features loaded; retrieving chromosomal sequence\n";
         if (o.has("-genome_dir")) { if (!load_sequences_from_genome_dir(o, d->regions)) { std::cerr << "[mipgen] chromosome fasta not acquired" << std::endl; throw 7; } }
         else if (!load_sequences_from_indexed_fasta(o, d->regions)) { std::cerr << "[mipgen] chromosome fasta not acquired" << std::endl; throw 9; }
+        clk.lap("region sequences");
         if (!load_masks(o, d->regions)) std::cerr << "[mipgen] masked chromosome fasta not acquired; no repetitive bases?" << std::endl;
         out.progress << "successfully acquired chromosomal data for mip design; accessing snp file ...\n";
         std::cerr << "[mipgen] regions ready; accessing snp file\n";
+        clk.lap("TRF masks");
         load_snps(o, d->regions, d->tables);
+        clk.lap("SNPs");
         out.progress << "all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         std::cerr << "[mipgen] all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         if (gpu_copies) {
@@ -105,9 +124,11 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
             out.progress << "bwa copy number analysis finished\n";
             std::cerr << "[mipgen] bwa copy number analysis finished\n";
         }
+        clk.lap("arm copy numbers");
         open_outputs(o, out);
         for (Region& r : d->regions) attach_tables(o, d->tables, r);
         d->selector.reset(new Selector(d->o, d->tables, d->out));
+        clk.lap("per-region tables");
     } catch (int e) {
         char msg[96];
         snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);                             // mipgen.cpp:2029-2032
@@ -451,9 +472,14 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
         threads.emplace_back(worker, d, k % visible, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get(), n_devices == 1);
     }
     int rc = 0;
+    StageClock clk;
+    double t_wait = 0.0, t_select = 0.0;
     for (int k = 0; k < n_devices && rc == 0; k++) {
         for (;;) {
+            const auto tw0 = std::chrono::steady_clock::now();
             std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
+            const auto tw1 = std::chrono::steady_clock::now();
+            t_wait += std::chrono::duration<double>(tw1 - tw0).count();
             if (w->error) { rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
             if (w->has_text) d->out.all.write(w->text.data(), (std::streamsize)w->text.size());     // numbered by the device from this window's first index
             int64_t pos0 = 0;
@@ -471,9 +497,13 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                 } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
                 pos0 += g.n_pos;
             }
+            t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count();
             if (w->last || rc) break;
         }
     }
+    if (clk.on) std::cerr << "[mipgen timing] tile_regions: waiting for the device workers " << t_wait << " s, selection stage " << t_select << " s\n";
+    if (clk.on && d->selector) std::cerr << "[mipgen timing] selection stage: tables " << d->selector->stage_seconds[0] << " s, collapsed output " << d->selector->stage_seconds[1]
+                                          << " s, pick " << d->selector->stage_seconds[2] << " s, clean-up " << d->selector->stage_seconds[3] << " s\n";
     for (auto& c : chans) c->stop();
     if (rc) for (auto& c : chans) { std::lock_guard<std::mutex> lk(c->m); c->q.clear(); }
     for (auto& t : threads) t.join();

@@ -13,6 +13,7 @@
 // Candidate construction + scoring (tile_regions' loop body, design_mip, get_score, get_parameters, predict_value)
 // is NOT here: it is the accelerator's job (include/mipgen_accel.h).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <fstream>
 #include <map>
@@ -119,6 +120,65 @@ private:
     int f_ = 3, b_ = 0;
 };
 
+// chr_strand_pos_used_arm_bases of one chromosome and strand (mipgen.cpp:97,1928-1937): the bases under the arms of the MIPs picked so far.
+// The reference keeps a std::set<int> and asks it base by base; the same membership as a growing bitmap (positions are >= 0), with the
+// range question answered a word at a time - at exome scale the set holds 10^7 bases and this test is the inner loop of the pick stage.
+class UsedBases {
+public:
+    void insert(int p)
+    {
+        if (p < 0) return;
+        const size_t w = (size_t)p >> 6;
+        if (w >= bits_.size()) bits_.resize(std::max(w + 1, bits_.size() * 2), 0);
+        bits_[w] |= 1ull << (p & 63);
+    }
+    bool any(int lo, int hi) const                  // any used base in [lo, hi]
+    {
+        if (lo < 0) lo = 0;
+        if (hi < lo) return false;
+        size_t w0 = (size_t)lo >> 6, w1 = (size_t)hi >> 6;
+        if (w0 >= bits_.size()) return false;
+        if (w1 >= bits_.size()) { w1 = bits_.size() - 1; hi = (int)(w1 * 64 + 63); }
+        const uint64_t first = ~0ull << (lo & 63), last = ~0ull >> (63 - (hi & 63));
+        if (w0 == w1) return (bits_[w0] & first & last) != 0;
+        if (bits_[w0] & first) return true;
+        for (size_t w = w0 + 1; w < w1; w++) if (bits_[w]) return true;
+        return (bits_[w1] & last) != 0;
+    }
+private:
+    std::vector<uint64_t> bits_;
+};
+
+// scan_strand_best_mip / pos_strand_best_mip of the region in hand (mipgen.cpp:1616-1746, 1748-1908): [position][strand] -> candidate.
+// The reference nests two std::map; the positions of a region are one dense run, so this is a flat table from the first position with
+// an "exists" flag per position - operator[] on the reference's map CREATES the position (:1869) and later find() calls see it, which
+// the flag reproduces.  Iterate ascending with lo() / hi() + find().
+class PosTable {
+public:
+    struct Slot { bool exists = false; std::shared_ptr<Cand> m[2]; };
+    void reset(int first, int count) { first_ = first; slots_.clear(); slots_.resize((size_t)std::max(count, 0)); }
+    int lo() const { return first_; }
+    int hi() const { return first_ + (int)slots_.size(); }
+    Slot* find(int pos)
+    {
+        if (pos < first_ || pos >= hi()) return nullptr;
+        Slot& s = slots_[(size_t)(pos - first_)];
+        return s.exists ? &s : nullptr;
+    }
+    Slot& touch(int pos)                            // the reference's operator[]
+    {
+        if (slots_.empty()) { first_ = pos; slots_.resize(1); }
+        else if (pos < first_) { slots_.insert(slots_.begin(), (size_t)(first_ - pos), Slot()); first_ = pos; }
+        else if (pos >= hi()) slots_.resize((size_t)(pos - first_ + 1));
+        Slot& s = slots_[(size_t)(pos - first_)];
+        s.exists = true;
+        return s;
+    }
+private:
+    int first_ = 0;
+    std::vector<Slot> slots_;
+};
+
 class Selector {
 public:
     Selector(const Options& o, const Tables& t, Outputs& out) : o_(o), t_(t), out_(out) {}
@@ -128,11 +188,12 @@ public:
     // winning survivor per strand, or -1; n_bases of them); nullptr = collapse on the host
     void run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& survivors, Rescorer* rescorer,
                     double lower, double upper, const int32_t* collapsed = nullptr, int32_t n_bases = 0);
+    double stage_seconds[4] = {0, 0, 0, 0};      // diagnostics ($MIPGEN_TIMING): survivor + collapse tables, collapsed output, pick, clean-up
 private:
     using CandPtr = std::shared_ptr<Cand>;
     const Options& o_; const Tables& t_; Outputs& out_;
-    std::map<std::string, std::map<int, std::set<int>>> used_;             // chr_strand_pos_used_arm_bases (persists across regions)
-    std::map<int, std::map<int, CandPtr>> scan_best_, pos_best_;           // [position][strand 0/1]
+    std::map<std::string, std::map<int, UsedBases>> used_;                 // chr_strand_pos_used_arm_bases (persists across regions)
+    PosTable scan_best_, pos_best_;                                        // [position][strand 0/1]
     const Region* r_ = nullptr; Rescorer* rs_ = nullptr; double lower_ = 0, upper_ = 0;
     GlibcRand rand_;
     void collapse();

@@ -10,6 +10,7 @@
 #include <sstream>
 
 #include "mipgen_host.hpp"
+#include <chrono>
 
 namespace mipgen {
 
@@ -182,21 +183,20 @@ bool Selector::arm_used(const Cand& c, int strand) const
     if (ci == used_.end()) return false;
     auto si = ci->second.find(strand);
     if (si == ci->second.end()) return false;
-    for (int p = c.ext_start; p <= c.ext_stop; p++) if (si->second.count(p)) return true;
-    for (int p = c.lig_start; p <= c.lig_stop; p++) if (si->second.count(p)) return true;
-    return false;
+    return si->second.any(c.ext_start, c.ext_stop) || si->second.any(c.lig_start, c.lig_stop);
 }
 
 void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& surv, Rescorer* rs,
                           double lower, double upper, const int32_t* collapsed, int32_t n_bases)
 {
     r_ = &r; rs_ = rs; lower_ = lower; upper_ = upper;
-    scan_best_.clear(); pos_best_.clear();
+    const auto t0 = std::chrono::steady_clock::now();
+    scan_best_.reset(g.first_pos, g.n_pos); pos_best_.reset(g.first_pos, collapsed ? n_bases : g.n_pos);
     for (int pi = 0; pi < g.n_pos; pi++)
         for (int s = 0; s < 2; s++) {
             const mipgen_survivor& sv = surv[(size_t)(2 * pi + s)];
             if (sv.cand_index < 0) continue;
-            scan_best_[g.first_pos + pi][s] = std::make_shared<Cand>(make_cand(o_, r, g, sv.cand_index, sv.score, sv.record));
+            scan_best_.touch(g.first_pos + pi).m[s] = std::make_shared<Cand>(make_cand(o_, r, g, sv.cand_index, sv.score, sv.record));
         }
     if (collapsed) {
         // collapse_mips ran on the accelerator: per base and strand the scan-start index of the survivor the fold keeps
@@ -204,47 +204,57 @@ void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vect
             for (int s = 0; s < 2; s++) {
                 const int32_t pi = collapsed[2 * (size_t)j + s];
                 if (pi < 0) continue;
-                auto it = scan_best_.find(g.first_pos + pi);
-                if (it == scan_best_.end()) throw 21;
-                auto is = it->second.find(s);
-                if (is == it->second.end()) throw 21;
-                pos_best_[g.first_pos + j][s] = is->second;
+                PosTable::Slot* it = scan_best_.find(g.first_pos + pi);
+                if (!it || !it->m[s]) throw 21;
+                pos_best_.touch(g.first_pos + j).m[s] = it->m[s];
             }
     } else collapse();
+    const auto t1 = std::chrono::steady_clock::now();
     if (!o_.silent) output_collapsed();
     out_.progress << "mips collapsed! picking mips...\n";
     if (o_.score_method == MIPGEN_SCORE_MIXED) { lower_ = o_.svr_priority; upper_ = o_.svr_optimal; }     // mipgen.cpp:510-514
+    const auto t2 = std::chrono::steady_clock::now();
     pick();
-    scan_best_.clear(); pos_best_.clear();
+    const auto t3 = std::chrono::steady_clock::now();
+    scan_best_.reset(0, 0); pos_best_.reset(0, 0);
+    const auto t4 = std::chrono::steady_clock::now();
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    stage_seconds[0] += sec(t0, t1); stage_seconds[1] += sec(t1, t2); stage_seconds[2] += sec(t2, t3); stage_seconds[3] += sec(t3, t4);
 }
 
 // collapse_mips, mipgen.cpp:1616-1649
 void Selector::collapse()
 {
-    for (auto& ps : scan_best_)
-        for (auto& sm : ps.second) {
-            const CandPtr& m = sm.second;
-            const int strand = sm.first;
+    for (int sp = scan_best_.lo(); sp < scan_best_.hi(); sp++) {
+        PosTable::Slot* ps = scan_best_.find(sp);
+        if (!ps) continue;
+        for (int strand = 0; strand < 2; strand++) {
+            const CandPtr m = ps->m[strand];
+            if (!m) continue;
             if ((long)m->ext_copy * m->lig_copy > o_.max_arm_copy || m->ext_copy > o_.target_arm_copy || m->lig_copy > o_.target_arm_copy) continue;
             if (m->masked > o_.masked_arm_threshold) continue;
             for (int pos = m->scan_start; pos <= m->scan_stop; pos++) {
-                auto& slot = pos_best_[pos];
-                auto it = slot.find(strand);
-                if (it == slot.end()) slot[strand] = m;
-                else if (m->snp_count < it->second->snp_count) it->second = m;
-                else if (m->score > it->second->score && m->snp_count == it->second->snp_count) it->second = m;
+                CandPtr& cur = pos_best_.touch(pos).m[strand];
+                if (!cur) cur = m;
+                else if (m->snp_count < cur->snp_count) cur = m;
+                else if (m->score > cur->score && m->snp_count == cur->snp_count) cur = m;
             }
         }
+    }
 }
 
 // output_collapsed_mips, mipgen.cpp:1651-1668
 void Selector::output_collapsed()
 {
-    for (auto& ps : pos_best_)
-        for (auto& sm : ps.second) {
+    for (int p = pos_best_.lo(); p < pos_best_.hi(); p++) {
+        PosTable::Slot* ps = pos_best_.find(p);
+        if (!ps) continue;
+        for (int strand = 0; strand < 2; strand++) {
+            if (!ps->m[strand]) continue;
             out_.collapsed_counter++;
-            out_.collapsed << format_record(o_, *r_, t_, *sm.second, out_.collapsed_counter, false);
+            out_.collapsed << format_record(o_, *r_, t_, *ps->m[strand], out_.collapsed_counter, false);
         }
+    }
 }
 
 // optimize_worst_in_region, mipgen.cpp:1748-1820
@@ -252,19 +262,17 @@ Selector::CandPtr Selector::optimize_worst(std::set<int>& positions, int strand_
 {
     CandPtr worst;
     for (int pos : positions) {
-        auto pit = pos_best_.find(pos);
-        if (pit == pos_best_.end()) continue;
+        PosTable::Slot* pit = pos_best_.find(pos);
+        if (!pit) continue;
         CandPtr cur, plus, minus;
         bool plus_set = false, minus_set = false;
-        auto ip = pit->second.find(0);
-        if (ip != pit->second.end() && strand_to_use != 1) {
-            plus = ip->second;
+        if (pit->m[0] && strand_to_use != 1) {
+            plus = pit->m[0];
             plus_set = !arm_used(*plus, 0);
             if (plus_set) cur = plus;
         }
-        auto im = pit->second.find(1);
-        if (im != pit->second.end() && strand_to_use != 0) {
-            minus = im->second;
+        if (pit->m[1] && strand_to_use != 0) {
+            minus = pit->m[1];
             minus_set = !arm_used(*minus, 1);
             if (minus_set) cur = plus_set ? (plus->score > minus->score ? plus : minus) : minus;
         }
@@ -283,12 +291,12 @@ Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_
     int earliest, prelim, dir;
     if (to_end < min_scan - 10 - o_.starting_mip_overlap) {
         earliest = r_->stop_fl - min_scan + 1; prelim = earliest; dir = 1;
-        while (scan_best_.find(prelim) == scan_best_.end() && prelim <= latest) prelim++;
+        while (!scan_best_.find(prelim) && prelim <= latest) prelim++;
     } else {
         earliest = latest - o_.max_mip_overlap; prelim = latest - o_.starting_mip_overlap; dir = -1;
-        while (scan_best_.find(prelim) == scan_best_.end() && prelim >= earliest) prelim--;
+        while (!scan_best_.find(prelim) && prelim >= earliest) prelim--;
     }
-    if (scan_best_.find(prelim) == scan_best_.end()) return nullptr;
+    if (!scan_best_.find(prelim)) return nullptr;
     CandPtr next;
     int prev_extent = latest + 1;
     for (int chosen = prelim;
@@ -301,10 +309,9 @@ Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_
         else { strand_index = rand_.next() % 2; iterations = 2; }                 // the reference's libc rand(), never seeded (:1863)
         for (int i = 0; i < iterations; i++) {
             strand_index = 1 - strand_index;
-            auto& slot = scan_best_[chosen];                                       // operator[]: creates the position, as the reference does (:1869)
-            auto it = slot.find(strand_index);
-            if (it == slot.end()) continue;
-            CandPtr test = it->second;
+            PosTable::Slot& slot = scan_best_.touch(chosen);                      // operator[]: creates the position, as the reference does (:1869)
+            if (!slot.m[strand_index]) continue;
+            CandPtr test = slot.m[strand_index];
             if (o_.score_method == MIPGEN_SCORE_MIXED && rs_) test->score = rs_->svr(*test);      // in place (:1873-1877)
             prev_extent = test->scan_stop;
             if (!next || test->score > next->score || test->snp_count < next->snp_count) {
