@@ -155,7 +155,7 @@ private:
 // the flag reproduces.  Iterate ascending with lo() / hi() + find().
 class PosTable {
 public:
-    struct Slot { bool exists = false; std::shared_ptr<Cand> m[2]; };
+    struct Slot { bool exists = false; Cand* m[2] = {nullptr, nullptr}; };      // candidates live in the Selector's per-region arena
     void reset(int first, int count) { first_ = first; slots_.clear(); slots_.resize((size_t)std::max(count, 0)); }
     int lo() const { return first_; }
     int hi() const { return first_ + (int)slots_.size(); }
@@ -190,7 +190,8 @@ public:
                     double lower, double upper, const int32_t* collapsed = nullptr, int32_t n_bases = 0);
     double stage_seconds[4] = {0, 0, 0, 0};      // diagnostics ($MIPGEN_TIMING): survivor + collapse tables, collapsed output, pick, clean-up
 private:
-    using CandPtr = std::shared_ptr<Cand>;
+    using CandPtr = Cand*;                                                 // into arena_: valid until the next region
+    std::vector<Cand> arena_;                                              // the survivors of the region in hand (<= 2 per scan position)
     const Options& o_; const Tables& t_; Outputs& out_;
     std::map<std::string, std::map<int, UsedBases>> used_;                 // chr_strand_pos_used_arm_bases (persists across regions)
     PosTable scan_best_, pos_best_;                                        // [position][strand 0/1]

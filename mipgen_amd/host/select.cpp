@@ -192,11 +192,13 @@ void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vect
     r_ = &r; rs_ = rs; lower_ = lower; upper_ = upper;
     const auto t0 = std::chrono::steady_clock::now();
     scan_best_.reset(g.first_pos, g.n_pos); pos_best_.reset(g.first_pos, collapsed ? n_bases : g.n_pos);
+    arena_.clear(); arena_.reserve((size_t)2 * (size_t)std::max(g.n_pos, 0));                 // never reallocates below: the pointers stay valid
     for (int pi = 0; pi < g.n_pos; pi++)
         for (int s = 0; s < 2; s++) {
             const mipgen_survivor& sv = surv[(size_t)(2 * pi + s)];
             if (sv.cand_index < 0) continue;
-            scan_best_.touch(g.first_pos + pi).m[s] = std::make_shared<Cand>(make_cand(o_, r, g, sv.cand_index, sv.score, sv.record));
+            arena_.push_back(make_cand(o_, r, g, sv.cand_index, sv.score, sv.record));
+            scan_best_.touch(g.first_pos + pi).m[s] = &arena_.back();
         }
     if (collapsed) {
         // collapse_mips ran on the accelerator: per base and strand the scan-start index of the survivor the fold keeps
@@ -260,11 +262,11 @@ void Selector::output_collapsed()
 // optimize_worst_in_region, mipgen.cpp:1748-1820
 Selector::CandPtr Selector::optimize_worst(std::set<int>& positions, int strand_to_use)
 {
-    CandPtr worst;
+    CandPtr worst = nullptr;
     for (int pos : positions) {
         PosTable::Slot* pit = pos_best_.find(pos);
         if (!pit) continue;
-        CandPtr cur, plus, minus;
+        CandPtr cur = nullptr, plus = nullptr, minus = nullptr;
         bool plus_set = false, minus_set = false;
         if (pit->m[0] && strand_to_use != 1) {
             plus = pit->m[0];
@@ -297,7 +299,7 @@ Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_
         while (!scan_best_.find(prelim) && prelim >= earliest) prelim--;
     }
     if (!scan_best_.find(prelim)) return nullptr;
-    CandPtr next;
+    CandPtr next = nullptr;
     int prev_extent = latest + 1;
     for (int chosen = prelim;
          (!next && prev_extent > latest && chosen < r_->stop_fl && chosen > r_->start_fl - o_.min_capture) ||
