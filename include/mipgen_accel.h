@@ -223,7 +223,8 @@ int mipgen_accel_model_info(const mipgen_accel* h, int32_t* n_sv, double* gamma,
 int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, mipgen_grid* grids_out);
 /* total dense-grid candidates of the resident batch */
 int64_t mipgen_accel_batch_candidates(const mipgen_accel* h);
-/* upper bound on the candidates of one result window for the following uploads (0 = whatever fits in free device memory) */
+/* upper bound on the candidates of one result window for the following uploads (0 = automatic: what fits in free device memory, at most
+ * 2^31 candidates unless a single region is larger) */
 int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates);
 int32_t mipgen_accel_window_count(const mipgen_accel* h);
 /* regions [first_region, +n_regions), candidates [first_candidate, +n_candidates) and scan positions of window w; any output may be NULL */

@@ -579,6 +579,9 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const int64_t have = (int64_t)(h->scores.cap * 8 + h->records.cap * 8 + h->emitted.cap) + (int64_t)free_b;   // what the result arrays may grow into
         cap = std::max<int64_t>(1, (int64_t)((double)have * 0.85) / 17);
+        // 2^31 candidates keep every kernel of a window busy for tens of milliseconds; result arrays beyond that only cost allocation time
+        // (hipMalloc of 250 GB takes seconds) - unless one region alone is larger
+        cap = std::min<int64_t>(cap, std::max<int64_t>((int64_t)1 << 31, cand_max));
     }
     if (cand_max > cap && h->window_cap > 0) cap = cand_max;       // a region is never split: one oversized region is its own window
     if (cand_max > cap) return fail(MIPGEN_E_NOMEM, "a single region has %lld dense candidates; device memory holds %lld", (long long)cand_max, (long long)cap);

@@ -334,6 +334,11 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
         ch->push(std::move(r));
     };
     const Options& o = d->o;
+    // $MIPGEN_TIMING: seconds per stage of this worker
+    const bool timing = std::getenv("MIPGEN_TIMING") != nullptr;
+    double t_stage[6] = {0, 0, 0, 0, 0, 0};      // create + model, long-range content, upload, score + replay + collapse (+ downloads), text, mixed re-scores
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](int k) { const auto n_ = std::chrono::steady_clock::now(); t_stage[k] += std::chrono::duration<double>(n_ - t_prev).count(); t_prev = n_; };
     mipgen_accel* h = nullptr;
     mipgen_params ap;
     try { ap = o.accel_params(); } catch (std::exception& e) { fail_out(17, e.what()); return; }
@@ -341,6 +346,7 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
     auto bail = [&](int code) { std::string m = mipgen_accel_last_error(); mipgen_accel_destroy(h); fail_out(code, m); };
     if (o.score_method != MIPGEN_SCORE_LOGISTIC && mipgen_accel_load_model_file(h, d->model_path.c_str())) { bail(18); return; }
     const int n = r1 - r0;
+    lap(0);
     if (o.score_method != MIPGEN_SCORE_LOGISTIC) {                                                                   // mipgen.cpp:1171,1224
         std::vector<const char*> seqs((size_t)n);
         std::vector<int32_t> lens((size_t)n), starts((size_t)n), stops((size_t)n);
@@ -353,6 +359,7 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
         if (mipgen_accel_long_range_content_batch(h, n, seqs.data(), lens.data(), starts.data(), stops.data(), lrc.data())) { bail(19); return; }
         for (int i = 0; i < n; i++) memcpy(d->regions[(size_t)(r0 + i)].lrc, &lrc[(size_t)i * MIPGEN_N_LRC], sizeof(double) * MIPGEN_N_LRC);
     }
+    lap(1);
     std::vector<mipgen_region> batch((size_t)n);
     for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)(r0 + i)], batch[(size_t)i]);
     std::vector<mipgen_grid> grids((size_t)n);
@@ -360,6 +367,7 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
     mipgen_accel_set_window_candidates(h, o.silent ? 0 : (int64_t)64 << 20);
     if (const char* e = std::getenv("MIPGEN_WINDOW_CANDIDATES")) mipgen_accel_set_window_candidates(h, std::max<int64_t>(1, std::atoll(e)));   // tests force several windows
     if (mipgen_accel_upload_regions(h, batch.data(), n, grids.data())) { bail(19); return; }
+    lap(2);
     const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;               // mixed scans with logistic (:467)
     const int nw = mipgen_accel_window_count(h);
     for (int w = 0; w < nw; w++) {
@@ -386,6 +394,7 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
             if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
         }
         if (mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), (o.silent || text) ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
+        lap(3);
         if (text) {
             // print_details on the device: the records leave the GPU as text, the dense results never do
             std::vector<mipgen_record_names> names((size_t)wn);
@@ -400,6 +409,7 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
             res->has_text = true;
             all_before += n_rec;
         }
+        lap(4);
         for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
         if (o.score_method == MIPGEN_SCORE_MIXED) {
             // every survivor of the window through the SVR in one call (the pick stage re-scores a subset of them, mipgen.cpp:1523-1527,1873-1877)
@@ -422,9 +432,14 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
             if (!cands.empty() && mipgen_accel_score_candidates(h, cands.data(), (int32_t)cands.size(), MIPGEN_SCORE_SVR, sc.data(), nullptr, nullptr, nullptr)) { bail(20); return; }
             for (size_t k = 0; k < cands.size(); k++) res->svr[where[k]] = sc[k];
         }
+        lap(5);
         ch->push(std::move(res));
+        t_prev = std::chrono::steady_clock::now();                 // (time blocked on the consumer is not the worker's)
     }
     mipgen_accel_destroy(h);
+    if (timing) std::cerr << "[mipgen timing] device " << device << " worker: create + model " << t_stage[0] << " s, long-range content " << t_stage[1] << " s, upload "
+                          << t_stage[2] << " s, score + replay + collapse + downloads " << t_stage[3] << " s, record text " << t_stage[4] << " s, mixed re-scores "
+                          << t_stage[5] << " s\n";
 }
 
 }  // namespace

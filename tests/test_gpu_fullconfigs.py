@@ -1,7 +1,7 @@
 """GPU: BASELINE.json configs[2] at its FULL size - all 1,000 regions of 5,000 bp, capture 120-250 (27 sizes x 57 arm pairs x 2 strands at
 5.2 M scan starts = 1.6e10 dense candidates), the logistic scan of the mixed design - through the silent fused path
 (mipgen_accel_score_condense_all: score -> replay of the early exits -> condense, window by window).  At this size the dense results
-(272 GB) do not fit HBM at once, so the result windows are exercised for real.  Checked through size-independent properties:
+(272 GB) are produced window by window (automatic windows hold at most 2^31 candidates), so the result windows are exercised for real.  Checked through size-independent properties:
 
   * the survivors do not depend on how the batch is cut into result windows, nor on how the regions are sharded over handles (= ranks);
   * structural invariants of every survivor (its candidate lies in the row block of its own scan position and strand, it is valid,
@@ -49,7 +49,7 @@ def test_full_config3_size_and_invariants(full5k):
     P, grids, surv, emitted, pos0 = (full5k[k] for k in ("P", "grids", "surv", "emitted", "pos0"))
     total = sum(g.count for g in grids)
     assert len(grids) == N_REGIONS and total > 1.5e10 and all(g.n_sizes == 27 for g in grids)
-    assert full5k["n_win_auto"] >= 2                       # 16 B/candidate x 1.6e10 > 288 GB of HBM: the windows are real
+    assert full5k["n_win_auto"] >= 2                       # automatic windows hold at most 2^31 candidates: 1.6e10 need eight
     assert surv.shape[0] == 2 * pos0[-1]
     A = P.n_arm_pairs
     rel = _relative(surv, grids, pos0)
@@ -72,11 +72,11 @@ def test_full_config3_size_and_invariants(full5k):
 def test_windows_and_shards_do_not_change_the_survivors(full5k):
     P, regions, grids, pos0 = (full5k[k] for k in ("P", "regions", "grids", "pos0"))
     ref_rel = _relative(full5k["surv"], grids, pos0)
-    # (a) the same batch cut into ~8 windows
+    # (a) the same batch cut into ~32 windows
     acc = capi.Accel(P)
-    acc.set_window_candidates(2_000_000_000)
+    acc.set_window_candidates(500_000_000)
     g2 = acc.upload(regions)
-    assert acc.window_count() >= 8
+    assert acc.window_count() >= 30
     acc.score_condense_all(capi.SCORE_LOGISTIC)
     e2, s2 = acc.download_survivors()
     assert np.array_equal(e2, full5k["emitted"])

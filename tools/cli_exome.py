@@ -23,22 +23,31 @@ from mipgen_amd import synth, workloads  # noqa: E402
 def main() -> None:
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/mipgen_cli_exome"
+    config = sys.argv[3] if len(sys.argv) > 3 else "exome"          # or "regions5k": configs[2], 1,000 x 5 kb, capture 120-250, mixed scoring
     shutil.rmtree(work, ignore_errors=True)
     os.makedirs(os.path.join(work, "genome"))
     t0 = time.time()
-    chrom_len, ivs = workloads.exome_layout()
-    ivs = ivs[:n]
-    chroms = sorted({iv.chrom for iv in ivs})
-    for c in chroms:
-        synth.write_fasta(os.path.join(work, "genome", f"chr{c}.fa"), "chr" + c, workloads.exome_chromosome(c, chrom_len[c]))
+    if config == "regions5k":
+        g5 = workloads.regions5k_genome()
+        ivs = workloads.regions5k_intervals(min(n, 1000))
+        chroms = ["1"]
+        synth.write_fasta(os.path.join(work, "genome", "chr1.fa"), "chr1", g5)
+        capture, method = ("120", "250"), "mixed"
+    else:
+        chrom_len, ivs = workloads.exome_layout()
+        ivs = ivs[:n]
+        chroms = sorted({iv.chrom for iv in ivs})
+        for c in chroms:
+            synth.write_fasta(os.path.join(work, "genome", f"chr{c}.fa"), "chr" + c, workloads.exome_chromosome(c, chrom_len[c]))
+        capture, method = ("150", "170"), "svr"
     synth.write_bed(os.path.join(work, "exome.bed"), ivs)
     exe = os.path.join(work, "mipgen")
     os.symlink(os.path.join(ROOT, "mipgen_amd", "mipgen"), exe)
     model = workloads.svr_model_path(os.path.join(work, "cache"), workloads.practice62()[0], 1024, rho=-2.2)
     shutil.copy(model, os.path.join(work, "mipgen_svr.model"))
     print(f"inputs: {len(ivs)} intervals on {len(chroms)} chromosomes written in {time.time() - t0:.1f} s", flush=True)
-    argv = [exe, "-regions_to_scan", os.path.join(work, "exome.bed"), "-project_name", "out", "-min_capture_size", "150", "-max_capture_size", "170",
-            "-bwa_genome_index", os.path.join(work, "genome", "index.fa"), "-genome_dir", os.path.join(work, "genome"), "-score_method", "svr",
+    argv = [exe, "-regions_to_scan", os.path.join(work, "exome.bed"), "-project_name", "out", "-min_capture_size", capture[0], "-max_capture_size", capture[1],
+            "-bwa_genome_index", os.path.join(work, "genome", "index.fa"), "-genome_dir", os.path.join(work, "genome"), "-score_method", method,
             "-silent_mode", "on", "-gpu_copy_counter", "on"]
     t1 = time.time()
     p = subprocess.run(argv, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MIPGEN_TIMING="1"))
