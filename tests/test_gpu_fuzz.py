@@ -19,7 +19,7 @@ def _configs():
     rng = np.random.default_rng(20240607)
     grid = [(e, l) for e in range(16, 31) for l in range(18, 31) if 38 <= e + l <= 48]
     out = []
-    for i in range(10):
+    for i in range(int(os.environ.get("MIPGEN_FUZZ_N", "10"))):          # a longer soak: MIPGEN_FUZZ_N=200 python -m pytest tests/test_gpu_fuzz.py
         inc = int(rng.choice([1, 2, 3, 5, 7, 10]))
         lo = int(rng.integers(110, 170))
         hi = lo + inc * int(rng.integers(0, 12))
@@ -119,3 +119,51 @@ def test_replay_condense_over_pair_list_shapes(name, heuristic):
     if heuristic and P.n_arm_pairs > 2:
         assert n_emit < int(((capi.rec_flags(records) & capi.FLAG_VALID) != 0).sum())      # the heuristic exit did fire
     acc.close()
+
+
+def _replay_cases():
+    rng = np.random.default_rng(777)
+    out = []
+    for i in range(int(os.environ.get("MIPGEN_FUZZ_REPLAY_N", "6"))):
+        n_sums = int(rng.integers(1, 8))
+        sums = sorted(rng.choice(np.arange(38, 52), size=n_sums, replace=False).tolist(), reverse=True)
+        pairs = []
+        for s in sums:
+            es = [e for e in range(16, 31) if 18 <= s - e <= 30]
+            keep = rng.random(len(es)) < rng.uniform(0.3, 1.0)
+            pairs += [(e, s - e) for e, k in zip(es, keep) if k]
+        if not pairs:
+            pairs = [(20, 22)]
+        pairs = pairs[:int(rng.integers(1, 121))]
+        out.append((i, pairs, int(rng.integers(3000, 16000)), int(rng.choice([30, 90, 200])), bool(rng.integers(0, 2)), int(rng.choice([1, 2, 5])),
+                    int(rng.integers(120, 170))))
+    return out
+
+
+@pytest.mark.parametrize("case", _replay_cases(), ids=lambda c: f"r{c[0]}_A{len(c[1])}_L{c[3]}_h{int(c[4])}_inc{c[5]}")
+def test_replay_condense_random(case):
+    """Random arm-pair lists (1..120 pairs in 1..7 arm-sum lists), capture ranges, increments, region lengths: replay masks, emitted counts and
+    condensed survivors against the oracle, for the logistic scan (heuristic on / off) and for SVR scores."""
+    i, pairs, start, length, heuristic, inc, lo = case
+    genome = bytearray(H.golden_genome())
+    if i % 2 == 0:
+        genome[start + 10:start + 15] = b"NNNNN"
+    genome = bytes(genome)
+    hi = lo + inc * (i % 7)
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    for method in (capi.SCORE_LOGISTIC, capi.SCORE_SVR):
+        P = capi.make_params(lo, hi, score_method=method, capture_increment=inc, arm_pairs=pairs, logistic_heuristic=heuristic)
+        acc = capi.Accel(P)
+        if method == capi.SCORE_SVR:
+            acc.load_model_file(mp)
+        rd = capi.build_region(genome, "1", start, start + length, P, bwa_mode="hashed", label=f"r{i}", lrc=np.full(44, 0.015 * (i % 5 + 1)))
+        grids, scores, records = acc.score_regions([rd], method)
+        acc.replay_condense()
+        emitted, surv, mask = acc.download_replay()
+        n_emit, omask = po.replay_region(P, rd, scores, records)
+        assert emitted[0] == n_emit and np.array_equal(mask, omask), (case[0], method)
+        osurv = po.condense_region(P, rd, scores, records, omask)
+        assert np.array_equal(surv["cand_index"], osurv["cand_index"]), (case[0], method)
+        assert np.array_equal(surv["record"], osurv["record"])
+        assert np.array_equal(surv["score"], osurv["score"], equal_nan=True)
+        acc.close()
