@@ -349,7 +349,8 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
                 const uint64_t r = br[q];
                 const double sc = bs[q];
                 int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
-                if (mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0) {
+                const bool saturated = mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0;
+                if (__ballot(saturated) && saturated) {                    // (the uniform test first: no exec-mask bookkeeping in the common case)
                     // the record's 16-bit fields saturate; the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,1692,1709):
                     // fetch the true values from the copy table
                     const int C = P->max_capture - (R.k0 + ki) * P->inc, p = R.first_pos + pi, ss = C - e - l;
@@ -367,17 +368,20 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
                 while (pending) {
                     // every pending lane evaluates the take rules against the current state; the first taker in fold order (highest pair
                     // index first) is applied, the lanes after it are re-evaluated
-                    bool take = false, update_chosen = true, stops = false;
-                    if (best_idx < 0) take = true;                                                                    // :1695
-                    else if (cur_masked > thr && cur_masked < chosen_masked) take = true;                             // :1701
-                    else if (cur_copy > target_copy && cur_copy < chosen_copy) take = true;                           // :1709
-                    else if (cur_copy <= target_copy) {
-                        if (sc < lower && sc > best_score) take = true;                                               // :1717
-                        else if (sc > lower) {
-                            if (snp < best_snp) take = true;                                                          // :1725
-                            else if (snp == best_snp && sc > best_score) { take = true; update_chosen = false; stops = sc > upper; }   // :1731-1737
-                        }
-                    }
+                    // the else-if chain of :1695-1737 as predicates (bitwise: no divergent branches); only the last rule leaves chosen_* alone
+                    const bool rA = best_idx < 0;                                                                     // :1695
+                    const bool rB = (cur_masked > thr) & (cur_masked < chosen_masked);                                // :1701
+                    const bool rC = (cur_copy > target_copy) & (cur_copy < chosen_copy);                              // :1709
+                    const bool rD = cur_copy <= target_copy;
+                    const bool above = sc > best_score;
+                    const bool rE = (sc < lower) & above;                                                             // :1717
+                    const bool hi_sc = sc > lower;
+                    const bool rF = snp < best_snp;                                                                   // :1725
+                    const bool rG = (snp == best_snp) & above;                                                        // :1731-1737
+                    const bool early = rA | rB | rC;
+                    const bool last_rule = !early & rD & !rE & hi_sc & !rF & rG;
+                    const bool take = early | (rD & (rE | (hi_sc & (rF | rG))));
+                    const bool update_chosen = !last_rule, stops = last_rule & (sc > upper);
                     const uint64_t tmask = __ballot(take) & pending;
                     if (!tmask) break;
                     const int f = top_bit(tmask);
