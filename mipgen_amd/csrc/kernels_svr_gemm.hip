@@ -10,7 +10,7 @@
 // relative, against libsvm's own summation order ~1e-13).  The products run on v_mfma_f64_16x16x4f64; a wavefront owns 16 candidates
 // x 64 support vectors (four accumulator tiles), its A operands (the centred candidate features) stay in registers, the centred model is
 // stored TRANSPOSED in HBM ([feature][support vector], 1.5 MB for 1,024 SVs: L2 resident) so that the B operands are coalesced
-// 128-byte rows read straight into registers; one exponential per (candidate, SV) follows in the epilogue of each SV tile.
+// rows, staged through LDS once per workgroup; one exponential per (candidate, SV) follows in the epilogue of each SV tile.
 //
 // Layout of v_mfma_f64_16x16x4f64 (probed on gfx950): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[i][j] in lane
 // 16 (i mod 4) + j, register i / 4.
@@ -44,14 +44,19 @@ __device__ __forceinline__ double exp2_poly(double t)
 
 // feats [n][192]; records [n] (valid flag); model_t [192][n_sv_pad] centred; sv_norm [n_sv_pad] = |s - c|^2 (+ the squares of libsvm
 // indices > 192); sv_coef [n_sv_pad] (0 for the padding); center [192]; n_sv_pad a multiple of SG_SVT.
-// No LDS: a lane keeps its 48 A operands (candidate lane & 15, features (lane >> 4) + 4 t) in registers for the whole support-vector loop, so
-// three workgroups share a compute unit and the B-operand loads of one wavefront hide behind the matrix instructions of the others; the
-// four wavefronts of a workgroup read the same model rows at about the same time (L1 hits).
+// A lane keeps its 48 A operands (candidate lane & 15, features (lane >> 4) + 4 t) in registers for the whole support-vector loop.  The B
+// operands - the same for the four wavefronts of a workgroup - go through LDS in chunks of SG_KC features x 64 support vectors, double
+// buffered (the next chunk's global loads are in flight under the matrix instructions of the current one); the row pitch of 80 doubles
+// puts the four feature rows a wavefront reads at once into disjoint bank groups.
+#define SG_KC 48                     // features per staged chunk (12 matrix instructions per accumulator tile)
+#define SG_BP 80                     // doubles per staged row: 640 B = 32 banks (mod 64)
+
 __global__ __launch_bounds__(256) void k_svr_gemm(int n, const double* __restrict__ feats, const uint64_t* __restrict__ records,
                                                   const double* __restrict__ model_t, const double* __restrict__ sv_norm,
                                                   const double* __restrict__ sv_coef, const double* __restrict__ center, int n_sv_pad,
                                                   double gamma_l2e, double rho, double* __restrict__ scores)
 {
+    __shared__ double sB[2][SG_KC * SG_BP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * SG_CANDS + wave * 16;                 // first candidate of this wavefront
     // this lane's operands: A[i][k] with i = lane & 15, k = lane >> 4; B[k][j] with j = lane & 15
@@ -78,26 +83,55 @@ __global__ __launch_bounds__(256) void k_svr_gemm(int n, const double* __restric
 #pragma unroll
     for (int r = 0; r < 4; r++) xr[r] = __shfl(q, lk + 4 * r, 64);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};             // score partial sums of the lane's four candidates over its support-vector columns
-    for (int s0 = 0; s0 < n_sv_pad; s0 += SG_SVT) {
-        double4_t d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, d2 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
-        const double* bp = model_t + (int64_t)lk * n_sv_pad + s0 + li;
+
+    // staging: chunk g = (SV tile g / 4, feature chunk g % 4) is SG_KC rows of 64 doubles; thread tid copies row (tid >> 6) + 4 j, column tid & 63
+    constexpr int NCH = MIPGEN_N_FEATURES / SG_KC;                    // chunks per SV tile
+    static_assert(NCH % 2 == 0, "the double buffer alternates with the chunk index");
+    constexpr int SR = SG_KC / 4;                                     // rows per thread
+    const int n_chunks = (n_sv_pad / SG_SVT) * NCH;
+    const int s_row = tid >> 6, s_col = tid & 63;
+    double stage[SR];
+    auto fetch = [&](int g) {
+        const int s0 = (g / NCH) * SG_SVT, k0 = (g % NCH) * SG_KC;
+        const double* src = model_t + (int64_t)(k0 + s_row) * n_sv_pad + s0 + s_col;
 #pragma unroll
-        for (int t = 0; t < MIPGEN_N_FEATURES / 4; t++) {
-            const double* b = bp + (int64_t)(4 * t) * n_sv_pad;
-            const double b0 = b[0], b1 = b[16], b2 = b[32], b3 = b[48];
-            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b0, d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b1, d1, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b2, d2, 0, 0, 0);
-            d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], b3, d3, 0, 0, 0);
+        for (int j = 0; j < SR; j++) stage[j] = src[(int64_t)(4 * j) * n_sv_pad];
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < SR; j++) sB[buf][(s_row + 4 * j) * SG_BP + s_col] = stage[j];
+    };
+    fetch(0);
+    store(0);
+    __syncthreads();
+    for (int tile = 0; tile < n_sv_pad / SG_SVT; tile++) {
+        double4_t d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, d2 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {                               // unrolled: the A operands are addressed statically
+            const int g = tile * NCH + c, buf = c & 1;                // NCH is even: chunk g sits in buffer g & 1 = c & 1
+            if (g + 1 < n_chunks) fetch(g + 1);                       // in flight under the matrix instructions below
+            const double* bb = &sB[buf][lk * SG_BP + li];
+#pragma unroll
+            for (int t = 0; t < SG_KC / 4; t++) {
+                const double* b = bb + (4 * t) * SG_BP;
+                const double b0 = b[0], b1 = b[16], b2 = b[32], b3 = b[48];
+                d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c * (SG_KC / 4) + t], b0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c * (SG_KC / 4) + t], b1, d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c * (SG_KC / 4) + t], b2, d2, 0, 0, 0);
+                d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c * (SG_KC / 4) + t], b3, d3, 0, 0, 0);
+            }
+            if (g + 1 < n_chunks) store(buf ^ 1);                     // the buffer the previous chunk read: every wavefront passed the barrier since
+            __syncthreads();
         }
-        // epilogue: K = 2^(-gamma log2(e) (|x|^2 + |s|^2 - 2 x.s)); column j = s0 + 16 t + li
+        // epilogue of the SV tile: K = 2^(-gamma log2(e) (|x|^2 + |s|^2 - 2 x.s)); column j = s0 + 16 t + li
+        const int s0 = tile * SG_SVT;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const double sn = sv_norm[s0 + 16 * t + li], cf = sv_coef[s0 + 16 * t + li];
             const double4_t d = t == 0 ? d0 : (t == 1 ? d1 : (t == 2 ? d2 : d3));
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const double d2v = fmax(xr[r] + sn - 2.0 * d[r], 0.0);               // a squared distance: rounding may leave -1e-17
+                const double d2v = fmax(xr[r] + sn - 2.0 * d[r], 0.0);                   // a squared distance: rounding may leave -1e-17
                 acc[r] = fma(cf, exp2_poly(-gamma_l2e * d2v), acc[r]);
             }
         }
