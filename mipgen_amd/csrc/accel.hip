@@ -642,21 +642,24 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
             }
             // tiles of the table-based dense logistic kernel: capture sizes in runs of <= 9, as many positions as its LDS tables allow
             if (ld_ok) {
+                // a tile = a run of positions with ALL their capture sizes (the kernel works them off in nkc runs of <= 9, staging the bases and
+                // their prefix words once): sized for the widest run's tables and the first run's reach
                 const int nkc = (d.n_sizes + 8) / 9;
-                for (int c = 0; c < nkc && ld_ok; c++) {
-                    const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc), kc = ki1 - ki0;
-                    const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
-                    const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum, ssr = ssmax - ssmin + 1;
-                    int np = (int)std::min<int64_t>({ld_np_cap, (int64_t)d.n_pos, 64});
-                    size_t b = 0;
-                    for (; np >= 1; np--) {
-                        b = std::max(mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
-                                     mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
-                        if (b <= 80 * 1024) break;                         // two 512-thread workgroups per compute unit: one builds tables while the other scores
-                    }
-                    if (np < 1 || ssmin < 1) { ld_ok = false; break; }
+                int kc_max = 0;
+                for (int c = 0; c < nkc; c++) kc_max = std::max(kc_max, (int)((int64_t)d.n_sizes * (c + 1) / nkc) - (int)((int64_t)d.n_sizes * c / nkc));
+                const int ssr = (kc_max - 1) * D.inc + D.max_sum - D.min_sum + 1, ssmax = Cmax - D.min_sum;
+                const int ssmin_all = Cmax - (d.n_sizes - 1) * D.inc - D.max_sum;
+                int np = (int)std::min<int64_t>({ld_np_cap, (int64_t)d.n_pos, 64});
+                size_t b = 0;
+                for (; np >= 1; np--) {
+                    b = std::max(mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
+                                 mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
+                    if (b <= 80 * 1024) break;                             // two 512-thread workgroups per compute unit: one builds tables while the other scores
+                }
+                if (np < 1 || ssmin_all < 1) ld_ok = false;
+                else {
                     ld_lds = std::max(ld_lds, b);
-                    for (int p0 = 0; p0 < d.n_pos; p0 += np) { SvrTile t = {i, 0, p0, std::min(np, d.n_pos - p0), ki0, kc}; ldt.push_back(t); }   // both strands
+                    for (int p0 = 0; p0 < d.n_pos; p0 += np) { SvrTile t = {i, 0, p0, std::min(np, d.n_pos - p0), 0, d.n_sizes}; ldt.push_back(t); }   // both strands, all sizes
                 }
             }
             if (!svr_possible) continue;

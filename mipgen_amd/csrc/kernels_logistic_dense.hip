@@ -27,18 +27,19 @@
 // shared with the host (tile sizing)
 extern "C" size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn)
 {
+    // ssr: scan sizes of the widest run of the tile; ssmax: the largest scan size of the whole tile (its first run)
     const int nq = np + ssr - 1;
     const int span = np + ssmax + 2 * Lmax + 2;
     size_t b = 0;
     b += (size_t)3 * (span + 1) * 8 + 48 * 8;                   // W0..W2 prefix words + scan scratch
     b += 102 * 8;                                                // log10 of the copy numbers 0..100 (101 = "more than 100")
+    b += 256 * 8;                                                // 2^(j/256) table of the exponential
+    b += (size_t)span + 16 + 16;                                 // bases (+ alignment of what follows)
     const int n_max = n_up > n_dn ? n_up : n_dn;                 // both strands reuse the tables: sized for either role assignment
     b += (size_t)np * n_max * LD_ARM_STRIDE * 8;                 // upstream arm windows
     b += (size_t)nq * n_max * LD_ARM_STRIDE * 8;                 // downstream arm windows
     b += (size_t)np * ssr * LD_INS_STRIDE * 8;                   // insert windows
-    b += (size_t)np * n_max * 2 + 16;                            // mappability masks of the upstream windows (bit per capture size of the tile)
-    b += (size_t)span + 16;                                      // bases
-    b += 256 * 8;                                                // 2^(j/256) table of the exponential
+    b += (size_t)np * n_max * 2 + 16;                            // mappability masks of the upstream windows (bit per capture size of the run)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -85,25 +86,23 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     const int wid = __builtin_amdgcn_readfirstlane(tid / WAVE);       // a scalar: the row arithmetic of the candidate loop stays on the scalar unit
     const int A = P->n_pairs, nK = R.n_sizes, inc = P->inc;
     const int Lmax = max(P->e_max, P->l_max);
-    const int Cmax_t = P->max_capture - (R.k0 + tile.ki0) * inc, Cmin_t = Cmax_t - (tile.kc - 1) * inc;
-    const int ssmax = Cmax_t - P->min_sum, ssmin = Cmin_t - P->max_sum, ssr = ssmax - ssmin + 1;
-    const int np = tile.np, nq = np + ssr - 1;
+    // The tile holds ALL capture sizes of its positions; they are worked off in runs of <= 9 (the tables of a run must fit the LDS budget),
+    // largest sizes first.  The bases and their prefix words are staged once for the whole tile - the first run reaches furthest.
+    const int n_runs = (tile.kc + 8) / 9;
+    const int np = tile.np;
     const int n_e = P->e_max - P->e_min + 1, n_l = P->l_max - P->l_min + 1, n_max = max(n_e, n_l);
     const int p_first = R.first_pos + tile.p0;
     const int lo = p_first - Lmax;                                     // chromosome coordinate of local base 0
-    const int span = np + ssmax + 2 * Lmax + 2;
+    const int span = np + (P->max_capture - (R.k0 + tile.ki0) * inc - P->min_sum) + 2 * Lmax + 2;
 
     uint64_t* W0 = (uint64_t*)smem;
     uint64_t* W1 = W0 + (span + 1);
     uint64_t* W2 = W1 + (span + 1);
     uint64_t* scratch = W2 + (span + 1);                               // 48
     double* LG = (double*)(scratch + 48);                              // log10(copy), as log_copy_dev gives it
-    double* TU = LG + 102;
-    double* TD = TU + (size_t)np * n_max * LD_ARM_STRIDE;
-    double* TT = TD + (size_t)nq * n_max * LD_ARM_STRIDE;
-    uint16_t* UM = (uint16_t*)(TT + (size_t)np * ssr * LD_INS_STRIDE);
-    uint8_t* sb = (uint8_t*)(UM + (size_t)np * n_max + 8);
-    double* XT = (double*)(smem + ((((size_t)(sb - smem) + span + 15) & ~(size_t)15)));   // 2^(j/256)
+    double* XT = LG + 102;                                             // 2^(j/256)
+    uint8_t* sb = (uint8_t*)(XT + 256);
+    double* const tables = (double*)(smem + ((((size_t)(sb - smem) + span + 16 + 15) & ~(size_t)15)));   // the run's tables, carved per run
     for (int i = tid; i < 256; i += LD_THREADS) XT[i] = EXP2_TAB[i];
 
     // ---- stage bases and the packed prefix words (as k_records_logistic) ---------------------------------------------------------
@@ -128,6 +127,17 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     __syncthreads();
     block_exclusive_scan3_u64(W0, W1, W2, span, scratch);
     LD_STAMP(0)
+
+    for (int run = 0; run < n_runs; run++) {
+    const int rk0 = tile.ki0 + (int)((int64_t)tile.kc * run / n_runs), rkc = tile.ki0 + (int)((int64_t)tile.kc * (run + 1) / n_runs) - rk0;
+    const int Cmax_t = P->max_capture - (R.k0 + rk0) * inc, Cmin_t = Cmax_t - (rkc - 1) * inc;
+    const int ssmax = Cmax_t - P->min_sum, ssmin = Cmin_t - P->max_sum, ssr = ssmax - ssmin + 1;
+    const int nq = np + ssr - 1;
+    double* TU = tables;
+    double* TD = TU + (size_t)np * n_max * LD_ARM_STRIDE;
+    double* TT = TD + (size_t)nq * n_max * LD_ARM_STRIDE;
+    uint16_t* UM = (uint16_t*)(TT + (size_t)np * ssr * LD_INS_STRIDE);
+    if (run) __syncthreads();                                         // every wavefront is done with the previous run's tables
 
     // Both strands of the tile, one after the other: the '+' and '-' rows of a (position, capture size) are neighbours in the result
     // arrays (912 bytes together), so writing them from the same compute unit a few microseconds apart lets L2 merge them into full lines
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
             if (R.unmap_off >= 0 && P->check_copy_number) {
                 const int ms = start_chr - R.seq_start;
                 if (ms >= 0 && ms < R.seq_len)
-                    for (int k = 0; k < tile.kc; k++) mask |= (uint32_t)(unmap[R.unmap_off + (int64_t)(R.k0 + tile.ki0 + k) * R.seq_len + ms] != 0) << k;
+                    for (int k = 0; k < rkc; k++) mask |= (uint32_t)(unmap[R.unmap_off + (int64_t)(R.k0 + rk0 + k) * R.seq_len + ms] != 0) << k;
             }
             UM[wl * n_up + li] = (uint16_t)mask;
         }
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     constexpr double xc[4] = EXP2_TAB_POLY;
     const double EXP_MAGIC = 6755399441055744.0;                        // 1.5 * 2^52: rounds to an integer, which lands in the low mantissa bits
     const double k256 = HC->ln_base * (1.4426950408889634074 * 256.0);   // exponent -> units of 1/256 of a binary order
-    const int n_rows = np * tile.kc;
+    const int n_rows = np * rkc;
     for (int a0 = 0; a0 < A; a0 += WAVE) {
         const int a = a0 + lane;
         const bool have = a < A;
@@ -243,9 +253,9 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
         typedef __attribute__((address_space(3))) const uint64_t lds_cq;
         const uint32_t tu_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TU, td_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TD, tt_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TT;
         for (int row = wid; row < n_rows; row += NW) {
-            const int pl = row / tile.kc, kci = row - pl * tile.kc;
+            const int pl = row / rkc, kci = row - pl * rkc;
             const int C = Cmax_t - kci * inc, p = p_first + pl, ss = C - S;
-            const int64_t out = R.out_off + ((((int64_t)(tile.p0 + pl) * nK + (tile.ki0 + kci)) * 2 + (minus ? 1 : 0)) * A) + a;
+            const int64_t out = R.out_off + ((((int64_t)(tile.p0 + pl) * nK + (rk0 + kci)) * 2 + (minus ? 1 : 0)) * A) + a;
             if (!have) continue;
             // bounds skips, mipgen.cpp:443-444
             const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) && ss > 0;
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     }
     LD_STAMP(4)
     }   // strand
+    }   // run
 #ifdef MIPGEN_DIAG
     if (prof && lane == 0 && blockIdx.x < 512) for (int k = 0; k < 5; k++) prof[(blockIdx.x * 8 + wid) * 5 + k] = pc[k];
 #endif
