@@ -149,6 +149,16 @@ DESIGNS2 = [
          sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-capture_increment", "10"]),
     dict(name="double_tile_both", method="logistic", ivs=[("1", 72000, 72600, "a")], minC=152, maxC=162, sums=[42, 44], flank=0, tags="5,0", snps=False,
          trf=False, bwa="hashed", model=None, extra=["-double_tile_strand_unaware", "on", "-double_tile_strands_separately", "on"]),
+    # the score limits, copy-number limits and minimum arm lengths as options (they change the arm-pair set, the replay's early exits, the
+    # condense / collapse filters and the pick stage's thresholds)
+    dict(name="limits_logistic", method="logistic", ivs=[("1", 74000, 74600, "a"), ("1", 75300, 75500, "b")], minC=150, maxC=160, sums=[40, 42, 44], flank=0,
+         tags="5,0", snps=False, trf=False, bwa="hashed", model=None,
+         extra=["-ext_min_length", "18", "-lig_min_length", "20", "-logistic_priority_score", "0.8", "-logistic_optimal_score", "0.93",
+                "-max_arm_copy_product", "20", "-target_arm_copy", "5"]),
+    # the same kind of limits for the SVR, given through -file_of_parameters (mipgen.cpp:1445-1481)
+    dict(name="limits_svr_parameter_file", method="svr", ivs=[("1", 77000, 77350, "s")], minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0", snps=False,
+         trf=False, bwa="hashed", model="svr_syn_64.model", extra=[],
+         params_file="# limits of the SVR design\n-svr_optimal_score 1.9\n-svr_priority_score 1.2\n-target_arm_copy 8\nnot an option line\n"),
 ]
 
 
@@ -167,6 +177,11 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
     extra = ["-feature_flank", str(d["flank"]), "-tag_sizes", d["tags"]]
     extra += ["-arm_lengths", d["arm_lengths"]] if d.get("arm_lengths") else ["-arm_length_sums", ",".join(map(str, d["sums"]))]
     extra += list(d.get("extra", []))
+    if d.get("params_file"):
+        with open(w + "/params.txt", "w") as fh:
+            fh.write(d["params_file"])
+        shutil.copy(w + "/params.txt", out + "/params.txt")
+        extra += ["-file_of_parameters", w + "/params.txt"]
     snp_path = None
     if d["snps"]:
         lo = min(iv.bed_start for iv in ivs) - 1000
@@ -187,6 +202,7 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
         meta["extra"] = list(d.get("extra", []))
         meta["chrom"] = d.get("chrom", "1")
         meta["arm_lengths"] = d.get("arm_lengths")
+        meta["params_file"] = bool(d.get("params_file"))
     meta["sha256"] = {}
     meta["lines"] = {}
     for key in ("all_mips", "collapsed_mips", "picked_mips", "snp_mips"):

@@ -146,6 +146,9 @@ def prepare_cli_workdir(meta: dict, work: str, fai: bool = False) -> List[str]:
     if meta["trf"]:
         argv += ["-trf", os.path.join(ORACLE_DIR, "faketrf.sh")]
     argv += list(meta.get("extra", []))
+    if meta.get("params_file"):
+        shutil.copy(os.path.join(meta["dir"], "params.txt"), os.path.join(work, "params.txt"))
+        argv += ["-file_of_parameters", os.path.join(work, "params.txt")]
     return argv
 
 

@@ -19,7 +19,7 @@ from tests import host_select_common as HS
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DESIGNS = sorted(d[len("design_"):] for d in os.listdir(H.GOLDEN) if d.startswith("design_"))
 # the CPU oracle needs ~10 minutes of one core for the 1.55e7-candidate SVR grid of BASELINE configs[1]: that design is checked on the GPU only
-# (tests/test_gpu_cli.py), the CPU suite keeps the other seventeen
+# (tests/test_gpu_cli.py), the CPU suite keeps all the others
 HEAVY = {"practice62_config2_svr"}
 DESIGNS = [d for d in DESIGNS if d not in HEAVY]
 
