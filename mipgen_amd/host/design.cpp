@@ -12,6 +12,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <stdexcept>
 #include <thread>
 
@@ -437,9 +438,13 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
         t_prev = std::chrono::steady_clock::now();                 // (time blocked on the consumer is not the worker's)
     }
     mipgen_accel_destroy(h);
-    if (timing) std::cerr << "[mipgen timing] device " << device << " worker: create + model " << t_stage[0] << " s, long-range content " << t_stage[1] << " s, upload "
-                          << t_stage[2] << " s, score + replay + collapse + downloads " << t_stage[3] << " s, record text " << t_stage[4] << " s, mixed re-scores "
-                          << t_stage[5] << " s\n";
+    if (timing) {
+        std::ostringstream line;                                     // one write: the selection thread prints to stderr too
+        line << "[mipgen timing] device " << device << " worker: create + model " << t_stage[0] << " s, long-range content " << t_stage[1] << " s, upload "
+             << t_stage[2] << " s, score + replay + collapse + downloads " << t_stage[3] << " s, record text " << t_stage[4] << " s, mixed re-scores "
+             << t_stage[5] << " s\n";
+        std::cerr << line.str();
+    }
 }
 
 }  // namespace
