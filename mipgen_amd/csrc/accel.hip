@@ -103,6 +103,26 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// two pinned host chunks + their "copy finished" events: large tables cross PCIe as they are packed / unpacked, chunk by chunk
+template <typename T>
+struct PinnedPair {
+    T* buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    hipError_t alloc(size_t n)
+    {
+        for (int b = 0; b < 2; b++) {
+            hipError_t e = hipHostMalloc((void**)&buf[b], std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    hipError_t wait(int b) { hipError_t e = busy[b] ? hipEventSynchronize(done[b]) : hipSuccess; busy[b] = false; return e; }
+    ~PinnedPair() { for (int b = 0; b < 2; b++) { if (done[b]) { if (busy[b]) (void)hipEventSynchronize(done[b]); (void)hipEventDestroy(done[b]); } if (buf[b]) (void)hipHostFree(buf[b]); } }
+};
+
 struct mipgen_accel {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -538,7 +558,6 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     // encode + pack on the host
     std::vector<uint8_t> hb((size_t)std::max<int64_t>(seq_total, 1));
     std::vector<char> hl((size_t)std::max<int64_t>(seq_total, 1));
-    std::vector<int32_t> hc((size_t)std::max<int64_t>(copy_total, 1));
     std::vector<uint8_t> hu((size_t)std::max<int64_t>(unmap_total, 1));
     for (int i = 0; i < n; i++) {
         const mipgen_region& R = regions[i];
@@ -552,22 +571,13 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
             if (R.snp_class) v |= (uint8_t)((R.snp_class[k] & 3) << BASE_SNP_SHIFT);
             b[k] = v;
         }
-        if (R.copy) {
-            for (int len = 0; len <= MIPGEN_MAX_OLIGO; len++) {
-                int s = D.len_slot[len];
-                if (s < 0) continue;
-                int32_t* dst = &hc[(size_t)d.copy_off + (size_t)s * R.seq_len];
-                if (R.copy[len]) memcpy(dst, R.copy[len], (size_t)R.seq_len * sizeof(int32_t));
-                else memset(dst, 0, (size_t)R.seq_len * sizeof(int32_t));
-            }
-        }
         if (R.unmappable) memcpy(&hu[(size_t)d.unmap_off], R.unmappable, (size_t)D.n_sizes_all * R.seq_len);
     }
     // inputs -> HBM (everything the kernels read stays resident for the whole batch)
     if (h->letters.reserve(hl.size())) return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpyAsync(h->letters.p, hl.data(), hl.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve(hc.size()) || h->unmap.reserve(hu.size()) ||
+    if (h->regions.reserve((size_t)std::max(n, 1)) || h->bases.reserve(hb.size()) || h->copy.reserve((size_t)std::max<int64_t>(copy_total, 1)) || h->unmap.reserve(hu.size()) ||
         h->survivors.reserve((size_t)std::max<int64_t>(2 * pos_total, 1)) || h->emitted_per_region.reserve((size_t)std::max(n, 1)) ||
         h->pos_region.reserve((size_t)std::max<int64_t>(pos_total, 1)) || h->pos_local.reserve((size_t)std::max<int64_t>(pos_total, 1)))
         return MIPGEN_E_NOMEM;
@@ -761,7 +771,42 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     }
     if (n > 0) HIP_TRY(hipMemcpyAsync(h->regions.p, h->hregions.data(), (size_t)n * sizeof(DevRegion), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->bases.p, hb.data(), hb.size(), hipMemcpyHostToDevice, h->stream));
-    if (copy_total) HIP_TRY(hipMemcpyAsync(h->copy.p, hc.data(), hc.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (copy_total) {
+        // copy tables: packed region by region into two pinned chunks and sent as they fill - no host image of the whole table (6.7 GB for the exome)
+        int64_t max_block = 0;
+        for (int i = 0; i < n; i++) if (regions[i].copy) max_block = std::max(max_block, (int64_t)D.n_len_slots * regions[i].seq_len);
+        const int64_t chunk = std::min(copy_total, std::max<int64_t>((int64_t)1 << 20, max_block));          // int32 elements: 4 MiB, or the largest region's block
+        PinnedPair<int32_t> pin;
+        HIP_TRY(pin.alloc((size_t)chunk));
+        int cur = 0;
+        int64_t fill = 0, base = 0;
+        auto flush = [&]() -> hipError_t {
+            if (fill == 0) return hipSuccess;
+            hipError_t e = hipMemcpyAsync(h->copy.p + base, pin.buf[cur], (size_t)fill * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipEventRecord(pin.done[cur], h->stream);
+            if (e != hipSuccess) return e;
+            pin.busy[cur] = true;
+            base += fill; fill = 0; cur ^= 1;
+            return pin.wait(cur);
+        };
+        for (int i = 0; i < n; i++) {
+            const mipgen_region& R = regions[i];
+            if (!R.copy) continue;
+            const int64_t block = (int64_t)D.n_len_slots * R.seq_len;
+            if (fill + block > chunk) HIP_TRY(flush());
+            if (h->hregions[i].copy_off != base + fill) return fail(MIPGEN_E_INVALID, "internal: copy table offsets out of order");
+            for (int len = 0; len <= MIPGEN_MAX_OLIGO; len++) {
+                const int s = D.len_slot[len];
+                if (s < 0) continue;
+                int32_t* dst = pin.buf[cur] + fill + (int64_t)s * R.seq_len;
+                if (R.copy[len]) memcpy(dst, R.copy[len], (size_t)R.seq_len * sizeof(int32_t));
+                else memset(dst, 0, (size_t)R.seq_len * sizeof(int32_t));
+            }
+            fill += block;
+        }
+        HIP_TRY(flush());
+        HIP_TRY(pin.wait(0)); HIP_TRY(pin.wait(1));
+    }
     if (unmap_total) HIP_TRY(hipMemcpyAsync(h->unmap.p, hu.data(), hu.size(), hipMemcpyHostToDevice, h->stream));
     if (!lt.empty()) HIP_TRY(hipMemcpyAsync(h->log_tiles.p, lt.data(), lt.size() * sizeof(LogTile), hipMemcpyHostToDevice, h->stream));
     if (!st.empty()) HIP_TRY(hipMemcpyAsync(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
@@ -1277,21 +1322,34 @@ int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char
         ms_total += ms; gbytes += chrom_lens[c];
     }
     KTRY(mipgen_launch_kmer_lookup(h->stream, dq.p, total, &KP, dkeys.p, dcounts.p, dout.p));
-    std::vector<int32_t> out((size_t)total * (size_t)n_lengths);
-    KTRY(hipMemcpyAsync(out.data(), dout.p, out.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    KTRY(hipStreamSynchronize(h->stream));
+    // back to the host one oligo length at a time through two pinned buffers: the copy of length s + 1 runs under the scatter of length s
+    {
+        PinnedPair<int32_t> pin;
+        KTRY(pin.alloc((size_t)total));
+        KTRY(hipMemcpyAsync(pin.buf[0], dout.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        KTRY(hipEventRecord(pin.done[0], h->stream));
+        pin.busy[0] = true;
+        for (int s = 0; s < n_lengths; s++) {
+            const int b = s & 1;
+            if (s + 1 < n_lengths) {
+                KTRY(hipMemcpyAsync(pin.buf[b ^ 1], dout.p + (size_t)(s + 1) * (size_t)total, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                KTRY(hipEventRecord(pin.done[b ^ 1], h->stream));
+                pin.busy[b ^ 1] = true;
+            }
+            KTRY(pin.wait(b));
+            for (int r = 0; r < n_regions; r++) {
+                const int len = region_lens[r];
+                if (!copy_out[r]) continue;
+                int32_t* dst = copy_out[r] + (size_t)s * (size_t)len;
+                memcpy(dst, pin.buf[b] + roff[(size_t)r], (size_t)len * sizeof(int32_t));
+                for (int i = std::max(0, len - lengths[s]); i < len; i++) dst[i] = 0;      // oligos the reference never writes (mipgen.cpp:829): absent key -> 0
+            }
+        }
+        KTRY(hipStreamSynchronize(h->stream));
+    }
 #undef KTRY
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     cleanup();
-    for (int r = 0; r < n_regions; r++) {
-        const int len = region_lens[r];
-        if (!copy_out[r]) continue;
-        for (int s = 0; s < n_lengths; s++) {
-            int32_t* dst = copy_out[r] + (size_t)s * (size_t)len;
-            memcpy(dst, &out[(size_t)s * (size_t)total + (size_t)roff[(size_t)r]], (size_t)len * sizeof(int32_t));
-            for (int i = std::max(0, len - lengths[s]); i < len; i++) dst[i] = 0;      // oligos the reference never writes (mipgen.cpp:829): absent key -> 0
-        }
-    }
     h->kmer_count_ms = ms_total; h->kmer_genome_bytes = gbytes;
     return MIPGEN_OK;
 }

@@ -329,7 +329,7 @@ static char comp(char c)
 void attach_tables(const Options& o, const Tables& t, Region& r)
 {
     const int n = (int)r.seq.size();
-    if (!r.copy_ready) r.copy_store.clear();
+    r.copy_store.clear();
     r.copy_ptr.assign(MIPGEN_MAX_OLIGO + 1, nullptr);
     auto cit = t.copies.find(r.chr);
     for (int len : o.oligo_sizes) {
@@ -347,7 +347,11 @@ void attach_tables(const Options& o, const Tables& t, Region& r)
     }
     {
         size_t k = 0;
-        for (int len : o.oligo_sizes) { if (len < 0 || len > MIPGEN_MAX_OLIGO) continue; r.copy_ptr[(size_t)len] = r.copy_store[k++].data(); }
+        for (int len : o.oligo_sizes) {
+            if (len < 0 || len > MIPGEN_MAX_OLIGO) continue;
+            r.copy_ptr[(size_t)len] = r.copy_ready ? r.copy_flat.data() + k * (size_t)n : r.copy_store[k].data();
+            k++;
+        }
     }
     r.unmappable.clear();
     if (!t.unmappable.empty()) {
@@ -383,15 +387,29 @@ void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
 {
     // the genome the reference's bwa index was built from: every chr*.fa of -genome_dir, or every record of the indexed fasta
     std::vector<std::string> chroms;
-    auto read_fasta = [&](const std::string& path) {
-        std::ifstream fh(path);
-        if (!fh.is_open()) return false;
-        std::string line;
-        while (std::getline(fh, line)) {
-            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-            if (!line.empty() && line[0] == '>') { chroms.emplace_back(); continue; }
-            if (chroms.empty()) chroms.emplace_back();
-            chroms.back() += line;
+    auto read_fasta = [&](const std::string& path) {                  // whole file at once, lines joined by memchr / append
+        FILE* fh = fopen(path.c_str(), "rb");
+        if (!fh) return false;
+        std::string buf;
+        if (fseek(fh, 0, SEEK_END) == 0) { const long sz = ftell(fh); if (sz > 0) buf.resize((size_t)sz); rewind(fh); }
+        size_t got = buf.empty() ? 0 : fread(&buf[0], 1, buf.size(), fh);
+        if (buf.empty()) { char tmp[1 << 16]; size_t k; while ((k = fread(tmp, 1, sizeof tmp, fh)) > 0) buf.append(tmp, k); got = buf.size(); }
+        fclose(fh);
+        buf.resize(got);
+        const char* p = buf.data(); const char* end = p + buf.size();
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* stop = nl ? nl : end;
+            const char* next = nl ? nl + 1 : end;
+            while (stop > p && stop[-1] == '\r') stop--;
+            if (stop > p) {
+                if (*p == '>') chroms.emplace_back();
+                else {
+                    if (chroms.empty()) chroms.emplace_back();
+                    chroms.back().append(p, (size_t)(stop - p));
+                }
+            }
+            p = next;
         }
         return true;
     };
@@ -407,11 +425,11 @@ void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
     std::vector<const char*> cs; std::vector<int64_t> cl;
     for (const std::string& c : chroms) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
     std::vector<int32_t> lengths(o.oligo_sizes.begin(), o.oligo_sizes.end());
-    std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<std::vector<int32_t>> flat(regs.size()); std::vector<int32_t*> outp;
+    std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<int32_t*> outp;
     for (size_t i = 0; i < regs.size(); i++) {
         rs.push_back(regs[i].seq.data()); rl.push_back((int32_t)regs[i].seq.size());
-        flat[i].assign(lengths.size() * regs[i].seq.size(), 0);
-        outp.push_back(flat[i].data());
+        regs[i].copy_flat.assign(lengths.size() * regs[i].seq.size(), 0);
+        outp.push_back(regs[i].copy_flat.data());
     }
     mipgen_params ap = o.accel_params();
     mipgen_accel* h = nullptr;
@@ -420,13 +438,7 @@ void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
                                                    (int32_t)lengths.size(), lengths.data(), outp.data());
     if (rc) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; mipgen_accel_destroy(h); throw 11; }
     mipgen_accel_destroy(h);
-    for (size_t i = 0; i < regs.size(); i++) {
-        Region& r = regs[i];
-        const size_t n = r.seq.size();
-        r.copy_store.clear();
-        for (size_t s = 0; s < lengths.size(); s++) r.copy_store.emplace_back(flat[i].begin() + (long)(s * n), flat[i].begin() + (long)((s + 1) * n));
-        r.copy_ready = true;
-    }
+    for (Region& r : regs) r.copy_ready = true;
 }
 
 void fill_accel_region(const Region& r, mipgen_region& out)

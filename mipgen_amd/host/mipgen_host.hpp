@@ -61,10 +61,11 @@ struct Region {                                   // Featurev5
     double lrc[MIPGEN_N_LRC] = {0};
     // per-region slices of the global lookup tables, laid out as mipgen_region expects
     std::vector<std::vector<int32_t>> copy_store;
+    std::vector<int32_t> copy_flat;               // -gpu_copy_counter on: [oligo size slot][position], filled by the accelerator in one piece
     std::vector<const int32_t*> copy_ptr;
     std::vector<uint8_t> unmappable, snp_class;
     std::string long_range_seq;                   // region +/- 1000 bases (svr / mixed only)
-    bool copy_ready = false;                      // copy_store already holds the oligo copy numbers (-gpu_copy_counter on)
+    bool copy_ready = false;                      // copy_flat already holds the oligo copy numbers (-gpu_copy_counter on)
 };
 
 struct Tables {                                   // global lookup tables the input stage fills (mipgen.cpp:81-83)
