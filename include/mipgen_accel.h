@@ -114,7 +114,8 @@ typedef struct mipgen_region {
     /* copy_chr_start_stop[chr][start][start+len-1] for oligo length len (mipgen.cpp:612-613):
      * copy[len] points to int32[seq_len] indexed by (start - seq_start); absent keys are 0, as
      * std::map::operator[] yields.  copy[len] may be NULL for lengths no arm pair uses, and the whole
-     * pointer table may be NULL = "every oligo has copy 1". */
+     * pointer table may be NULL = "every oligo has copy 1".  MIPGEN_COPY_RESIDENT = the counts the handle itself
+     * produced with mipgen_accel_count_oligo_copies_resident() for exactly this batch (they never left the device). */
     const int32_t* const* copy;      /* table of MIPGEN_MAX_OLIGO+1 pointers, indexed by oligo length */
     /* unmappable_positions[capture_size][chr] (mipgen.cpp:615-618): byte [k * seq_len + (pos - seq_start)] != 0
      * iff a MIP of capture size (max_capture_size - k*capture_increment) starting at pos is ambiguous.
@@ -224,7 +225,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
 /* total dense-grid candidates of the resident batch */
 int64_t mipgen_accel_batch_candidates(const mipgen_accel* h);
 /* upper bound on the candidates of one result window for the following uploads (0 = automatic: what fits in free device memory, at most
- * 2^31 candidates unless a single region is larger) */
+ * 2^30 candidates unless a single region is larger) */
 int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates);
 int32_t mipgen_accel_window_count(const mipgen_accel* h);
 /* regions [first_region, +n_regions), candidates [first_candidate, +n_candidates) and scan positions of window w; any output may be NULL */
@@ -319,6 +320,18 @@ int mipgen_accel_download_text(mipgen_accel* h, char* dst, int64_t capacity);
 int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens,
                                     int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens,
                                     int32_t n_lengths, const int32_t* lengths, int32_t* const* copy_out);
+
+/* The same counts, kept in the handle's device memory in the layout the scoring kernels read (288 GB of HBM: the tables of a whole exome
+ * are 6.7 GB and would otherwise cross PCIe twice).  The oligo lengths are the ones the handle's arm pairs use.  The next
+ * mipgen_accel_upload_regions must pass the SAME regions (count, order, seq_len) with copy = MIPGEN_COPY_RESIDENT in every one of them;
+ * any other upload discards the resident tables.  Counts of 65535 and more - which the 16-bit record fields cannot carry and the host looks
+ * up instead (MIPGEN_REC_EXT_COPY) - are returned as a list owned by the handle, valid until the next call on it
+ * (start = 0-based offset of the oligo in the region string). */
+#define MIPGEN_COPY_RESIDENT ((const int32_t* const*)(uintptr_t)1)
+typedef struct mipgen_big_copy { int32_t region, length, start, copies; } mipgen_big_copy;
+int mipgen_accel_count_oligo_copies_resident(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens,
+                                             int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens,
+                                             int64_t* n_big, const mipgen_big_copy** big);
 
 /* ---- tuning ---------------------------------------------------------------------------------------- */
 /* A dense SVR launch with few tiles is split along the support-vector list so that it still fills the chip (partial sums are added

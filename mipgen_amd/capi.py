@@ -109,11 +109,18 @@ def arm_pairs_of(p: Params) -> List[Tuple[int, int]]:
     return [(p.arm_ext[i], p.arm_lig[i]) for i in range(p.n_arm_pairs)]
 
 
+COPY_RESIDENT = "resident"
+
+
+class BigCopy(C.Structure):
+    _fields_ = [("region", C.c_int32), ("length", C.c_int32), ("start", C.c_int32), ("copies", C.c_int32)]
+
+
 class RegionData:
     """Owns the host arrays a mipgen_region points into (keeps them alive for ctypes)."""
 
     def __init__(self, start_flanked: int, stop_flanked: int, seq_start: int, seq: bytes,
-                 masked: Optional[bytes] = None, copy: Optional[Dict[int, np.ndarray]] = None,
+                 masked: Optional[bytes] = None, copy=None,
                  unmappable: Optional[np.ndarray] = None, snp_class: Optional[np.ndarray] = None,
                  lrc: Optional[Sequence[float]] = None, chrom: str = "1", label: str = "x",
                  start: Optional[int] = None, stop: Optional[int] = None):
@@ -122,7 +129,9 @@ class RegionData:
         self.stop = stop if stop is not None else stop_flanked
         self.seq = bytes(seq)
         self.masked = bytes(masked) if masked is not None else None
-        self.copy = {k: np.ascontiguousarray(v, dtype=np.int32) for k, v in (copy or {}).items()}
+        resident = isinstance(copy, str)                                  # COPY_RESIDENT: the tables the handle counted itself
+        assert not resident or copy == COPY_RESIDENT
+        self.copy = {} if resident else {k: np.ascontiguousarray(v, dtype=np.int32) for k, v in (copy or {}).items()}
         self.unmappable = np.ascontiguousarray(unmappable, dtype=np.uint8) if unmappable is not None else None
         self.snp_class = np.ascontiguousarray(snp_class, dtype=np.uint8) if snp_class is not None else None
         self.alleles: Optional[bytes] = None                              # oracle-only allele table
@@ -134,7 +143,9 @@ class RegionData:
         r.seq_stop = seq_start + len(self.seq) - 1
         r.seq = self.seq
         r.masked_seq = self.masked if self.masked is not None else None
-        if copy is not None:
+        if resident:
+            r.copy = C.cast(C.c_void_p(1), C.POINTER(C.POINTER(C.c_int32)))  # MIPGEN_COPY_RESIDENT
+        elif copy is not None:
             self._copy_tab = (C.POINTER(C.c_int32) * (MAX_OLIGO + 1))()
             for k, v in self.copy.items():
                 assert v.shape == (r.seq_len,)
@@ -293,6 +304,8 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_download_collapsed.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     lib.mipgen_accel_count_oligo_copies.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, C.c_int32, i32p,
                                                     C.POINTER(C.POINTER(C.c_int32))]
+    lib.mipgen_accel_count_oligo_copies_resident.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, i64p,
+                                                             C.POINTER(C.POINTER(BigCopy))]
     lib.mipgen_accel_format_all_mips.argtypes = [vp, C.POINTER(RecordNames), C.c_char_p, C.c_int64, i64p, i64p]
     lib.mipgen_accel_download_text.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
@@ -300,7 +313,7 @@ def load_library(path: Optional[str] = None):
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "format_all_mips", "download_text"):
+                 "set_sv_split", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "format_all_mips", "download_text"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -318,6 +331,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
+    "mipgen_accel_count_oligo_copies_resident",
 ]
 
 
@@ -423,6 +437,20 @@ class Accel:
         self._check(self.lib.mipgen_accel_count_oligo_copies(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
                                                              rl.ctypes.data_as(C.POINTER(C.c_int32)), nl, la.ctypes.data_as(C.POINTER(C.c_int32)), op))
         return [{int(k): o[i] for i, k in enumerate(lengths)} for o in outs]
+
+    def count_oligo_copies_resident(self, chroms: Sequence[bytes], region_seqs: Sequence[bytes]) -> List[Tuple[int, int, int, int]]:
+        """The same counts for the handle's own oligo lengths, left on the device for an upload of the same regions with copy=COPY_RESIDENT;
+        returns the (region, length, start, copies) entries with 65535 copies or more."""
+        nc, nr = len(chroms), len(region_seqs)
+        ca = (C.c_char_p * max(nc, 1))(*chroms)
+        cl = np.array([len(c) for c in chroms], dtype=np.int64)
+        ra = (C.c_char_p * max(nr, 1))(*region_seqs)
+        rl = np.array([len(r) for r in region_seqs], dtype=np.int32)
+        nb = C.c_int64(0)
+        big = C.POINTER(BigCopy)()
+        self._check(self.lib.mipgen_accel_count_oligo_copies_resident(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
+                                                                      rl.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nb), C.byref(big)))
+        return [(big[i].region, big[i].length, big[i].start, big[i].copies) for i in range(nb.value)]
 
     def format_all_mips(self, names: Sequence[Tuple[str, str, int, int]], middle: bytes, first_index: int = 0) -> Tuple[bytes, int]:
         """all_mips records of the window replayed last, formatted on the device: (text, number of records)."""

@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -55,7 +57,10 @@ hipError_t mipgen_launch_kmer_insert(hipStream_t, const char* seq, int64_t len, 
 hipError_t mipgen_launch_kmer_fold(hipStream_t, const uint32_t* filter, int filter_bits, uint32_t* folded);
 hipError_t mipgen_launch_kmer_count(hipStream_t, const char* genome, int64_t len, const KmerParams*, const uint64_t* keys, const uint32_t* filter,
                                     const uint32_t* folded, unsigned int* counts, int n_cu);
+hipError_t mipgen_launch_fill_pos_map(hipStream_t, const int64_t* region_pos0, int n_regions, int64_t total, int32_t* pos_region, int32_t* pos_local);
 hipError_t mipgen_launch_kmer_lookup(hipStream_t, const char* seq, int64_t len, const KmerParams*, const uint64_t* keys, const unsigned int* counts, int32_t* out);
+hipError_t mipgen_launch_kmer_place(hipStream_t, const int32_t* src, int64_t len, const KmerParams*, const int64_t* roff, int n_regions, int32_t* dst, void* big,
+                                    unsigned int* n_big, unsigned int big_cap);
 hipError_t mipgen_launch_collapse(hipStream_t, int n_tiles, const CollapseTile* tiles, const DevParams*, const DevRegion*, const int64_t* region_pos0,
                                   const int64_t* region_base0, const mipgen_survivor* survivors, const int32_t* copy, int64_t cand_base, int32_t* collapsed);
 }
@@ -85,22 +90,57 @@ struct Window {
     int64_t base0 = 0, n_base_entries = 0;   // collapsed entries (2 per base) of the window inside the batch-wide array
 };
 
+// Device buffers a handle has let go of, kept for its next allocations.  hipFree of tens of GB returns at once but the release is paid by
+// a later hipMalloc (~60 ms per GB, tools/microbench/alloc_cost.hip: seconds for the k-mer tables of an exome); handing the blocks on -
+// the counter's tables become the result arrays of the scoring calls - costs nothing.  Whole blocks only, best fit, at most 4x the request.
+struct DevPool {
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> blocks;
+    size_t held() const { size_t n = 0; for (const Block& b : blocks) n += b.bytes; return n; }
+    void* take(size_t bytes, size_t* got)
+    {
+        int best = -1;
+        for (int i = 0; i < (int)blocks.size(); i++)
+            if (blocks[(size_t)i].bytes >= bytes && blocks[(size_t)i].bytes / 4 <= bytes && (best < 0 || blocks[(size_t)i].bytes < blocks[(size_t)best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        void* p = blocks[(size_t)best].p;
+        *got = blocks[(size_t)best].bytes;
+        blocks.erase(blocks.begin() + best);
+        return p;
+    }
+    void give(void* p, size_t bytes) { if (bytes >= ((size_t)1 << 20)) blocks.push_back({p, bytes}); else (void)hipFree(p); }   // small ones are not worth keeping
+    void clear() { for (const Block& b : blocks) (void)hipFree(b.p); blocks.clear(); }
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    DevPool* pool = nullptr;                 // where the buffer comes from / goes to (nullptr: hipMalloc / hipFree)
     int reserve(size_t n)
     {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        release();
         size_t want = n + std::min<size_t>(n / 8, (size_t)1 << 20) + 64;
+        if (pool) {
+            size_t got = 0;
+            if (void* q = pool->take(want * sizeof(T), &got)) { p = (T*)q; cap = got / sizeof(T); return 0; }
+        }
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
-        if (e != hipSuccess) return fail(MIPGEN_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        if (e != hipSuccess && pool && !pool->blocks.empty()) {        // out of memory with blocks in hand: give them back and try again
+            (void)hipGetLastError();
+            pool->clear();
+            e = hipMalloc((void**)&p, want * sizeof(T));
+        }
+        if (e != hipSuccess) { p = nullptr; return fail(MIPGEN_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e)); }
         cap = want;
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) { if (pool) pool->give(p, cap * sizeof(T)); else (void)hipFree(p); }
+        p = nullptr; cap = 0;
+    }
 };
 
 // two pinned host chunks + their "copy finished" events: large tables cross PCIe as they are packed / unpacked, chunk by chunk
@@ -139,6 +179,7 @@ struct mipgen_accel {
     DevBuf<double> model;
     std::string svr_geometry_error;  // why the dense SVR kernel cannot run this parameter set ("" = it can); reported when SVR is requested
     std::string svr_batch_error;     // same, for the resident batch (tile does not fit LDS)
+    bool record_tiles_ready = false, logistic_tiles_ready = false, svr_tiles_ready = false;   // tile lists of the resident batch, laid out on first use
     int sv_split = 0;                // 0 = chosen per launch from the tile count; > 0 forced
     int n_cu = 256;
     // batch
@@ -155,7 +196,10 @@ struct mipgen_accel {
     DevBuf<char> fmt_pool, fmt_text, fmt_temp;
     DevBuf<int64_t> fmt_a, fmt_b, fmt_c, fmt_d;
     int64_t fmt_bytes = -1;
+    DevPool pool;                             // large buffers the handle let go of (see DevPool)
     DevBuf<int32_t> copy;
+    std::vector<int32_t> resident_lens;      // seq_len of the regions whose copy tables mipgen_accel_count_oligo_copies_resident left in `copy`
+    std::vector<mipgen_big_copy> big_copies; // ... and their counts >= 65535
     DevBuf<LogTile> log_tiles;
     DevBuf<SvrTile> svr_tiles, ld_tiles;      // dense SVR tiles; tiles of the table-based dense logistic kernel (same shape, own sizes)
     size_t ld_lds = 0;                        // 0: some region does not fit that kernel's LDS -> the per-candidate kernel scores the batch
@@ -262,6 +306,9 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     HIP_TRY(hipSetDevice(device));
 
     mipgen_accel* h = new mipgen_accel();
+    // the buffers that reach gigabytes share the handle's pool
+    h->copy.pool = h->scores.pool = h->partials.pool = h->records.pool = h->emitted.pool = h->survivors.pool = h->collapsed.pool = h->pos_region.pool =
+        h->pos_local.pool = h->bases.pool = h->letters.pool = h->unmap.pool = h->fmt_pool.pool = h->fmt_text.pool = h->fmt_temp.pool = &h->pool;
     h->device = device;
     h->params = *params;
     DevParams& D = h->hp;
@@ -357,6 +404,7 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
     h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();
+    h->pool.clear();
     if (h->dp) (void)hipFree(h->dp);
     if (h->dconsts) (void)hipFree(h->dconsts);
     for (hipEvent_t e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -521,9 +569,23 @@ int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split)
     return MIPGEN_OK;
 }
 
+#ifdef MIPGEN_DIAG
+struct DiagClock {                           // host seconds per stage of a call, on stderr (diagnostic builds only)
+    const char* what; std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit DiagClock(const char* w) : what(w) {}
+    void lap(const char* stage) { const auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "[mipgen_accel] %s: %s %.3f s\n", what, stage, std::chrono::duration<double>(n_ - t).count()); t = n_; }
+};
+#define DIAG_CLOCK(name) DiagClock diag_clock(name)
+#define DIAG_LAP(stage) diag_clock.lap(stage)
+#else
+#define DIAG_CLOCK(name) do { } while (0)
+#define DIAG_LAP(stage) do { } while (0)
+#endif
+
 int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, mipgen_grid* grids_out)
 {
     if (!h || n < 0 || (n > 0 && !regions)) return fail(MIPGEN_E_INVALID, "bad arguments");
+    DIAG_CLOCK("upload");
     HIP_TRY(hipSetDevice(h->device));
     const mipgen_params& P = h->params;
     const DevParams& D = h->hp;
@@ -532,6 +594,16 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     h->hregions.assign((size_t)n, DevRegion());
     h->grids.assign((size_t)n, mipgen_grid());
     int64_t seq_total = 0, copy_total = 0, unmap_total = 0, cand_total = 0, pos_total = 0, cand_max = 0;
+    // copy tables the handle counted itself (mipgen_accel_count_oligo_copies_resident): the batch must be the one they were counted for
+    int n_resident = 0;
+    for (int i = 0; i < n; i++) n_resident += regions[i].copy == MIPGEN_COPY_RESIDENT;
+    if (n_resident) {
+        bool same = n_resident == n && h->resident_lens.size() == (size_t)n;
+        for (int i = 0; same && i < n; i++) same = h->resident_lens[(size_t)i] == regions[i].seq_len;
+        if (!same) return fail(MIPGEN_E_INVALID, "MIPGEN_COPY_RESIDENT: the batch is not the one mipgen_accel_count_oligo_copies_resident counted (regions, order, seq_len)");
+    } else {
+        h->resident_lens.clear();                                      // `copy` is about to be overwritten (or unused)
+    }
     for (int i = 0; i < n; i++) {
         const mipgen_region& R = regions[i];
         if (!R.seq || R.seq_len <= 0) return fail(MIPGEN_E_INVALID, "region %d has no sequence", i);
@@ -555,7 +627,10 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         cand_max = std::max(cand_max, g.count);
     }
     if (pos_total > INT32_MAX) return fail(MIPGEN_E_INVALID, "batch has %lld scan positions (max %d): split the design", (long long)pos_total, INT32_MAX);
+    DIAG_LAP("layout");
     // encode + pack on the host
+    uint8_t code_lut[256];
+    for (int c = 0; c < 256; c++) code_lut[c] = base_code((char)c);
     std::vector<uint8_t> hb((size_t)std::max<int64_t>(seq_total, 1));
     std::vector<char> hl((size_t)std::max<int64_t>(seq_total, 1));
     std::vector<uint8_t> hu((size_t)std::max<int64_t>(unmap_total, 1));
@@ -564,15 +639,12 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         const DevRegion& d = h->hregions[i];
         uint8_t* b = &hb[(size_t)d.seq_off];
         memcpy(&hl[(size_t)d.seq_off], R.seq, (size_t)R.seq_len);
-        for (int k = 0; k < R.seq_len; k++) {
-            uint8_t v = base_code(R.seq[k]);
-            const char m = R.masked_seq ? R.masked_seq[k] : R.seq[k];
-            if (m == 'N') v |= BASE_MASKED_BIT;
-            if (R.snp_class) v |= (uint8_t)((R.snp_class[k] & 3) << BASE_SNP_SHIFT);
-            b[k] = v;
-        }
+        const char* ms = R.masked_seq ? R.masked_seq : R.seq;
+        if (R.snp_class) for (int k = 0; k < R.seq_len; k++) b[k] = (uint8_t)(code_lut[(uint8_t)R.seq[k]] | (ms[k] == 'N' ? BASE_MASKED_BIT : 0) | ((R.snp_class[k] & 3) << BASE_SNP_SHIFT));
+        else for (int k = 0; k < R.seq_len; k++) b[k] = (uint8_t)(code_lut[(uint8_t)R.seq[k]] | (ms[k] == 'N' ? BASE_MASKED_BIT : 0));
         if (R.unmappable) memcpy(&hu[(size_t)d.unmap_off], R.unmappable, (size_t)D.n_sizes_all * R.seq_len);
     }
+    DIAG_LAP("pack");
     // inputs -> HBM (everything the kernels read stays resident for the whole batch)
     if (h->letters.reserve(hl.size())) return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpyAsync(h->letters.p, hl.data(), hl.size(), hipMemcpyHostToDevice, h->stream));
@@ -582,16 +654,18 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         h->pos_region.reserve((size_t)std::max<int64_t>(pos_total, 1)) || h->pos_local.reserve((size_t)std::max<int64_t>(pos_total, 1)))
         return MIPGEN_E_NOMEM;
 
+    DIAG_LAP("input buffers");
     // ---- result windows: consecutive regions, at most `cap` candidates each (17 B per candidate: score, record, emitted flag) ----
     int64_t cap = h->window_cap;
     if (cap <= 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const int64_t have = (int64_t)(h->scores.cap * 8 + h->records.cap * 8 + h->emitted.cap) + (int64_t)free_b;   // what the result arrays may grow into
+        const int64_t have = (int64_t)(h->scores.cap * 8 + h->records.cap * 8 + h->emitted.cap) + (int64_t)free_b + (int64_t)h->pool.held();   // what the result arrays may grow into
         cap = std::max<int64_t>(1, (int64_t)((double)have * 0.85) / 17);
-        // 2^31 candidates keep every kernel of a window busy for tens of milliseconds; result arrays beyond that only cost allocation time
+        // 2^30 candidates keep every kernel of a window busy for milliseconds to tenths of a second; result arrays beyond that only cost
+        // allocation time (18 GB: 0.4-1 s on a cold device; 36 GB: 2 s) and delay the first window a pipelined caller can work on
         // (hipMalloc of 250 GB takes seconds) - unless one region alone is larger
-        cap = std::min<int64_t>(cap, std::max<int64_t>((int64_t)1 << 31, cand_max));
+        cap = std::min<int64_t>(cap, std::max<int64_t>((int64_t)1 << 30, cand_max));
     }
     if (cand_max > cap && h->window_cap > 0) cap = cand_max;       // a region is never split: one oversized region is its own window
     if (cand_max > cap) return fail(MIPGEN_E_NOMEM, "a single region has %lld dense candidates; device memory holds %lld", (long long)cand_max, (long long)cap);
@@ -622,136 +696,24 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         rpos0[(size_t)i + 1] = rpos0[(size_t)i] + d.n_pos;
         h->h_region_base0[(size_t)i + 1] = h->h_region_base0[(size_t)i] + 2 * nb;
     }
+    // collapse tiles: 128 bases each.  The scoring kernels' tile lists depend on the method and are laid out on first use (ensure_tiles)
     std::vector<CollapseTile> ct;
-    std::vector<SvrTile> ldt;
-    size_t ld_lds = 0;
-    bool ld_ok = true;
-    const int64_t ld_np_cap = pos_total * 2 < 8192 ? 8 : (pos_total * 2 < 65536 ? 16 : 64);      // small batches: more, smaller tiles (fill 256 CUs)
-    // ---- tiles, window by window ----
-    std::vector<LogTile> lt;
-    std::vector<SvrTile> st;
-    std::vector<double> st_cost;
-    const int Lmax = std::max(D.e_max, D.l_max);
-    int span_max = 0;
-    size_t svr_lds = 0;
-    const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
-    const bool svr_possible = h->svr_geometry_error.empty();
     for (Window& w : h->windows) {
-        w.log_tile0 = (int)lt.size(); w.svr_tile0 = (int)st.size(); w.col_tile0 = (int)ct.size(); w.ld_tile0 = (int)ldt.size();
+        w.col_tile0 = (int)ct.size();
         w.base0 = h->h_region_base0[(size_t)w.r0]; w.n_base_entries = h->h_region_base0[(size_t)w.r1] - w.base0;
+        w.log_tile0 = w.n_log_tiles = w.svr_tile0 = w.n_svr_tiles = w.ld_tile0 = w.n_ld_tiles = 0;
         for (int i = w.r0; i < w.r1; i++) {
             const DevRegion& d = h->hregions[i];
             if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
             for (int64_t j0 = 0; 2 * j0 < h->h_region_base0[(size_t)i + 1] - h->h_region_base0[(size_t)i]; j0 += 128) { CollapseTile t = {i, (int32_t)j0}; ct.push_back(t); }
-            const int Cmax = D.max_capture - d.k0 * D.inc;
-            const int NPL = 8;  // 8 positions per records tile: ~10 resident blocks per CU hide the per-candidate gathers (32: 2.6 waves/SIMD, 45 % slower)
-            for (int p0 = 0; p0 < d.n_pos; p0 += NPL) {
-                LogTile t = {i, p0, std::min(NPL, d.n_pos - p0), 0};
-                lt.push_back(t);
-                span_max = std::max(span_max, t.np + Cmax + Lmax);
-            }
-            // tiles of the table-based dense logistic kernel: capture sizes in runs of <= 9, as many positions as its LDS tables allow
-            if (ld_ok) {
-                // a tile = a run of positions with ALL their capture sizes (the kernel works them off in nkc runs of <= 9, staging the bases and
-                // their prefix words once): sized for the widest run's tables and the first run's reach
-                const int nkc = (d.n_sizes + 8) / 9;
-                int kc_max = 0;
-                for (int c = 0; c < nkc; c++) kc_max = std::max(kc_max, (int)((int64_t)d.n_sizes * (c + 1) / nkc) - (int)((int64_t)d.n_sizes * c / nkc));
-                const int ssr = (kc_max - 1) * D.inc + D.max_sum - D.min_sum + 1, ssmax = Cmax - D.min_sum;
-                const int ssmin_all = Cmax - (d.n_sizes - 1) * D.inc - D.max_sum;
-                int np = (int)std::min<int64_t>({ld_np_cap, (int64_t)d.n_pos, 64});
-                size_t b = 0;
-                for (; np >= 1; np--) {
-                    b = std::max(mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
-                                 mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
-                    if (b <= 80 * 1024) break;                             // two 512-thread workgroups per compute unit: one builds tables while the other scores
-                }
-                if (np < 1 || ssmin_all < 1) ld_ok = false;
-                else {
-                    ld_lds = std::max(ld_lds, b);
-                    for (int p0 = 0; p0 < d.n_pos; p0 += np) { SvrTile t = {i, 0, p0, std::min(np, d.n_pos - p0), 0, d.n_sizes}; ldt.push_back(t); }   // both strands, all sizes
-                }
-            }
-            if (!svr_possible) continue;
-            // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs as long as the tile's LDS allows (more positions
-            // per tile = fewer factor-table entries per candidate and fewer idle candidate lanes).  Every split of the sizes is priced
-            // with the kernel's instruction budget - ~47 VALU per (table entry, SV) against ~2.7 per (candidate, SV) at full lanes -
-            // and the cheapest one is laid out.
-            const int lanes = 64 * h->geom.wpc;
-            struct Run { int ki0, kc, np; };
-            std::vector<Run> best_runs;
-            double best_cost = 0;
-            size_t best_lds = 0;
-            for (int kc_cap = std::min(9, d.n_sizes); kc_cap >= 1; kc_cap--) {
-                const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
-                if (kc_cap < std::min(9, d.n_sizes) && nkc == (d.n_sizes + kc_cap) / (kc_cap + 1)) continue;   // same split as the previous cap
-                std::vector<Run> runs;
-                double ent = 0, slots = 0;
-                size_t lds_r = 0;
-                bool ok = true;
-                for (int c = 0; c < nkc && ok; c++) {
-                    const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
-                    const int kc = ki1 - ki0;
-                    const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
-                    const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum, ssr = ssmax - ssmin + 1;
-                    int np = std::max(1, std::min(lanes / kc, d.n_pos));       // every lane of a pair chunk owns one (position, capture size)
-                    size_t lds_t = 0;
-                    for (; np >= 1; np--) {
-                        lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
-                        if (lds_t <= 160 * 1024) break;
-                    }
-                    if (np < 1) { ok = false; break; }
-                    // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping):
-                    // taken when it costs few positions
-                    { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 10 >= np * 9) { np = np_cf; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
-                    // the same number of tiles, evenly filled (the last tile of a region is not a stub that costs a full table stage)
-                    { const int nt = (d.n_pos + np - 1) / np, np_even = (d.n_pos + nt - 1) / nt;
-                      if (np_even < np) { np = np_even; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
-                    runs.push_back({ki0, kc, np});
-                    lds_r = std::max(lds_r, lds_t);
-                    const double tiles = std::ceil((double)d.n_pos / np);
-                    ent += tiles * (np * (h->geom.n_e + h->geom.n_l) / 2.0 + (np + ssr - 1) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)np * ssr);
-                    slots += tiles * lanes;
-                }
-                if (!ok) continue;
-                const double cost = 47.0 * ent + 2.7 * slots * D.n_pairs / 1.0;
-                if (best_runs.empty() || cost < best_cost) { best_runs = runs; best_cost = cost; best_lds = lds_r; }
-            }
-            if (best_runs.empty()) { svr_lds = (size_t)1 << 30; continue; }
-            svr_lds = std::max(svr_lds, best_lds);
-            for (const Run& r : best_runs)
-                for (int p0 = 0; p0 < d.n_pos; p0 += r.np) {
-                    const int npt = std::min(r.np, d.n_pos - p0);
-                    // run time of the tile in wavefront-cycles per SV group (measured shares of the three stages): table entries, scan span,
-                    // candidate steps (all lanes of the block step, whatever the tile holds)
-                    const int Cmax_t = Cmax - r.ki0 * D.inc, ssmax = Cmax_t - D.min_sum, ssr = (r.kc - 1) * D.inc + D.max_sum - D.min_sum + 1;
-                    const double ent = (npt + (npt + ssr - 1)) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)npt * ssr;
-                    const double cost = 19.0 * ent + 100.0 * (npt + ssmax + 2 * Lmax) + 75000.0;
-                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); st_cost.push_back(cost); }
-                }
         }
-        // longest tiles first: workgroups are dispatched in index order as compute units free up, so the short tiles fill the end of the
-        // launch (k_svr_dense takes tile blockIdx / n_split: consecutive tiles already land on different XCDs)
-        {
-            const size_t t0 = (size_t)w.svr_tile0, n = st.size() - t0;
-            std::vector<size_t> order(n);
-            for (size_t k = 0; k < n; k++) order[k] = k;
-            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st_cost[t0 + a] > st_cost[t0 + b]; });
-            std::vector<SvrTile> sorted(n);
-            for (size_t k = 0; k < n; k++) sorted[k] = st[t0 + order[k]];
-            std::copy(sorted.begin(), sorted.end(), st.begin() + (ptrdiff_t)t0);
-        }
-        w.n_log_tiles = (int)lt.size() - w.log_tile0; w.n_svr_tiles = (int)st.size() - w.svr_tile0; w.n_col_tiles = (int)ct.size() - w.col_tile0;
-        w.n_ld_tiles = (int)ldt.size() - w.ld_tile0;
+        w.n_col_tiles = (int)ct.size() - w.col_tile0;
     }
+    h->record_tiles_ready = h->logistic_tiles_ready = h->svr_tiles_ready = false;
     h->svr_batch_error.clear();
-    if (svr_lds > 160 * 1024) { h->svr_batch_error = "an SVR tile needs more than 160 KiB of LDS: capture range / arm lists too wide"; st.clear(); for (Window& w : h->windows) { w.svr_tile0 = 0; w.n_svr_tiles = 0; } svr_lds = 0; }
-    if (!ld_ok) { ldt.clear(); ld_lds = 0; }
-    h->ld_lds = ld_lds;
-    if (h->ld_tiles.reserve(std::max<size_t>(ldt.size(), 1))) return MIPGEN_E_NOMEM;
-    if (!ldt.empty()) HIP_TRY(hipMemcpyAsync(h->ld_tiles.p, ldt.data(), ldt.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
-    if (h->log_tiles.reserve(std::max<size_t>(lt.size(), 1)) || h->svr_tiles.reserve(std::max<size_t>(st.size(), 1)) ||
-        h->scores.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) || h->records.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) ||
+    h->ld_lds = 0; h->log_span_max = 0; h->svr_lds = 0;
+    DIAG_LAP("tiles");
+    if (h->scores.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) || h->records.reserve((size_t)std::max<int64_t>(win_cand_max, 1)) ||
         h->emitted.reserve((size_t)std::max<int64_t>(win_cand_max, 1)))
         return MIPGEN_E_NOMEM;
     if (h->region_pos0.reserve((size_t)n + 1) || h->region_base0.reserve((size_t)n + 1) || h->col_tiles.reserve(std::max<size_t>(ct.size(), 1)) ||
@@ -760,18 +722,10 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     HIP_TRY(hipMemcpyAsync(h->region_pos0.p, rpos0.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->region_base0.p, h->h_region_base0.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     if (!ct.empty()) HIP_TRY(hipMemcpyAsync(h->col_tiles.p, ct.data(), ct.size() * sizeof(CollapseTile), hipMemcpyHostToDevice, h->stream));
-    std::vector<int32_t> pr((size_t)pos_total), pl((size_t)pos_total);
-    {
-        int64_t k = 0;
-        for (int i = 0; i < n; i++) for (int p = 0; p < h->hregions[i].n_pos; p++, k++) { pr[(size_t)k] = i; pl[(size_t)k] = p; }
-    }
-    if (pos_total) {
-        HIP_TRY(hipMemcpyAsync(h->pos_region.p, pr.data(), (size_t)pos_total * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->pos_local.p, pl.data(), (size_t)pos_total * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    }
+    HIP_TRY(mipgen_launch_fill_pos_map(h->stream, h->region_pos0.p, n, pos_total, h->pos_region.p, h->pos_local.p));       // position -> (region, position in it)
     if (n > 0) HIP_TRY(hipMemcpyAsync(h->regions.p, h->hregions.data(), (size_t)n * sizeof(DevRegion), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->bases.p, hb.data(), hb.size(), hipMemcpyHostToDevice, h->stream));
-    if (copy_total) {
+    if (copy_total && !n_resident) {
         // copy tables: packed region by region into two pinned chunks and sent as they fill - no host image of the whole table (6.7 GB for the exome)
         int64_t max_block = 0;
         for (int i = 0; i < n; i++) if (regions[i].copy) max_block = std::max(max_block, (int64_t)D.n_len_slots * regions[i].seq_len);
@@ -808,16 +762,13 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         HIP_TRY(pin.wait(0)); HIP_TRY(pin.wait(1));
     }
     if (unmap_total) HIP_TRY(hipMemcpyAsync(h->unmap.p, hu.data(), hu.size(), hipMemcpyHostToDevice, h->stream));
-    if (!lt.empty()) HIP_TRY(hipMemcpyAsync(h->log_tiles.p, lt.data(), lt.size() * sizeof(LogTile), hipMemcpyHostToDevice, h->stream));
-    if (!st.empty()) HIP_TRY(hipMemcpyAsync(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
+    DIAG_LAP("buffers + copies");
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
-    h->log_span_max = span_max; h->svr_lds = svr_lds;
     h->scored = false; h->replayed = false; h->collapsed_valid = false; h->fmt_bytes = -1;
     h->ev_used.assign(h->windows.size(), 0);
 #ifdef MIPGEN_DIAG
-    fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates in %zu window(s), %zu record tiles (LDS %zu B), %zu SVR tiles x %d threads (LDS %zu B)\n", n,
-            (long long)cand_total, h->windows.size(), lt.size(), mipgen_logistic_lds_bytes(span_max), st.size(), h->geom.nchunk * h->geom.wpc * 64, svr_lds);
+    fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates in %zu window(s)\n", n, (long long)cand_total, h->windows.size());
 #endif
     if (grids_out) memcpy(grids_out, h->grids.data(), (size_t)n * sizeof(mipgen_grid));
     return MIPGEN_OK;
@@ -869,10 +820,205 @@ static int ensure_events(mipgen_accel* h)
     return 0;
 }
 
+// ---- tile lists of the scoring kernels: laid out when a method is first used on the resident batch (a 200,000-region logistic design
+// never prices an SVR tile) ----
+static int build_record_tiles(mipgen_accel* h)          // k_records / k_records_logistic: 8 positions per tile
+{
+    if (h->record_tiles_ready) return MIPGEN_OK;
+    const DevParams& D = h->hp;
+    const int Lmax = std::max(D.e_max, D.l_max);
+    std::vector<LogTile> lt;
+    int span_max = 0;
+    for (Window& w : h->windows) {
+        w.log_tile0 = (int)lt.size();
+        for (int i = w.r0; i < w.r1; i++) {
+            const DevRegion& d = h->hregions[i];
+            if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
+            const int Cmax = D.max_capture - d.k0 * D.inc;
+            const int NPL = 8;  // 8 positions per records tile: ~10 resident blocks per CU hide the per-candidate gathers (32: 2.6 waves/SIMD, 45 % slower)
+            for (int p0 = 0; p0 < d.n_pos; p0 += NPL) {
+                LogTile t = {i, p0, std::min(NPL, d.n_pos - p0), 0};
+                lt.push_back(t);
+                span_max = std::max(span_max, t.np + Cmax + Lmax);
+            }
+        }
+        w.n_log_tiles = (int)lt.size() - w.log_tile0;
+    }
+    if (h->log_tiles.reserve(std::max<size_t>(lt.size(), 1))) return MIPGEN_E_NOMEM;
+    if (!lt.empty()) HIP_TRY(hipMemcpy(h->log_tiles.p, lt.data(), lt.size() * sizeof(LogTile), hipMemcpyHostToDevice));
+    h->log_span_max = span_max;
+    h->record_tiles_ready = true;
+    return MIPGEN_OK;
+}
+
+static int build_logistic_tiles(mipgen_accel* h)        // k_logistic_dense: a run of positions with all their capture sizes
+{
+    if (h->logistic_tiles_ready) return MIPGEN_OK;
+    const DevParams& D = h->hp;
+    const int Lmax = std::max(D.e_max, D.l_max);
+    std::vector<SvrTile> ldt;
+    size_t ld_lds = 0;
+    bool ld_ok = true;
+    const int64_t ld_np_cap = h->total_pos * 2 < 8192 ? 8 : (h->total_pos * 2 < 65536 ? 16 : 64);      // small batches: more, smaller tiles (fill 256 CUs)
+    for (Window& w : h->windows) {
+        w.ld_tile0 = (int)ldt.size();
+        for (int i = w.r0; i < w.r1 && ld_ok; i++) {
+            const DevRegion& d = h->hregions[i];
+            if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
+            const int Cmax = D.max_capture - d.k0 * D.inc;
+            // a tile = a run of positions with ALL their capture sizes (the kernel works them off in nkc runs of <= 9, staging the bases and
+            // their prefix words once): sized for the widest run's tables and the first run's reach
+            const int nkc = (d.n_sizes + 8) / 9;
+            int kc_max = 0;
+            for (int c = 0; c < nkc; c++) kc_max = std::max(kc_max, (int)((int64_t)d.n_sizes * (c + 1) / nkc) - (int)((int64_t)d.n_sizes * c / nkc));
+            const int ssr = (kc_max - 1) * D.inc + D.max_sum - D.min_sum + 1, ssmax = Cmax - D.min_sum;
+            const int ssmin_all = Cmax - (d.n_sizes - 1) * D.inc - D.max_sum;
+            int np = (int)std::min<int64_t>({ld_np_cap, (int64_t)d.n_pos, 64});
+            size_t b = 0;
+            for (; np >= 1; np--) {
+                b = std::max(mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
+                             mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
+                if (b <= 80 * 1024) break;                             // two 512-thread workgroups per compute unit: one builds tables while the other scores
+            }
+            if (np < 1 || ssmin_all < 1) { ld_ok = false; break; }
+            ld_lds = std::max(ld_lds, b);
+            for (int p0 = 0; p0 < d.n_pos; p0 += np) { SvrTile t = {i, 0, p0, std::min(np, d.n_pos - p0), 0, d.n_sizes}; ldt.push_back(t); }   // both strands, all sizes
+        }
+        w.n_ld_tiles = (int)ldt.size() - w.ld_tile0;
+    }
+    if (!ld_ok) {                                        // some region does not fit that kernel's LDS: the per-candidate kernel scores the batch
+        for (Window& w : h->windows) { w.ld_tile0 = 0; w.n_ld_tiles = 0; }
+        h->ld_lds = 0;
+        h->logistic_tiles_ready = true;
+        return build_record_tiles(h);
+    }
+    if (h->ld_tiles.reserve(std::max<size_t>(ldt.size(), 1))) return MIPGEN_E_NOMEM;
+    if (!ldt.empty()) HIP_TRY(hipMemcpy(h->ld_tiles.p, ldt.data(), ldt.size() * sizeof(SvrTile), hipMemcpyHostToDevice));
+    h->ld_lds = ld_lds;
+    h->logistic_tiles_ready = true;
+    return MIPGEN_OK;
+}
+
+static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the record tiles of k_records, which runs before it)
+{
+    if (h->svr_tiles_ready) return MIPGEN_OK;
+    if (int rc = build_record_tiles(h)) return rc;
+    const DevParams& D = h->hp;
+    const int Lmax = std::max(D.e_max, D.l_max);
+    const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
+    const int lanes = 64 * h->geom.wpc;
+    std::vector<SvrTile> st;
+    std::vector<double> st_cost;
+    size_t svr_lds = 0;
+    // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs as long as the tile's LDS allows (more positions per tile =
+    // fewer factor-table entries per candidate and fewer idle candidate lanes).  Every split of the sizes is priced with the kernel's
+    // instruction budget - ~47 VALU per (table entry, SV) against ~2.7 per (candidate, SV) at full lanes - and the cheapest one is laid
+    // out.  The choice depends on (first size, number of sizes, positions) only: exome-shaped batches repeat the same few thousand shapes.
+    struct Run { int ki0, kc, np; };
+    struct Shape { std::vector<Run> runs; size_t lds = 0; };
+    std::unordered_map<uint64_t, Shape> shapes;
+    auto shape_of = [&](const DevRegion& d) -> const Shape& {
+        const uint64_t key = ((uint64_t)(uint32_t)d.n_pos << 32) | ((uint64_t)(uint16_t)d.k0 << 16) | (uint64_t)(uint16_t)d.n_sizes;
+        auto it = shapes.find(key);
+        if (it != shapes.end()) return it->second;
+        Shape best;
+        double best_cost = 0;
+        const int Cmax = D.max_capture - d.k0 * D.inc;
+        for (int kc_cap = std::min(9, d.n_sizes); kc_cap >= 1; kc_cap--) {
+            const int nkc = (d.n_sizes + kc_cap - 1) / kc_cap;
+            if (kc_cap < std::min(9, d.n_sizes) && nkc == (d.n_sizes + kc_cap) / (kc_cap + 1)) continue;   // same split as the previous cap
+            std::vector<Run> runs;
+            double ent = 0, slots = 0;
+            size_t lds_r = 0;
+            bool ok = true;
+            for (int c = 0; c < nkc && ok; c++) {
+                const int ki0 = (int)((int64_t)d.n_sizes * c / nkc), ki1 = (int)((int64_t)d.n_sizes * (c + 1) / nkc);
+                const int kc = ki1 - ki0;
+                const int Cmax_t = Cmax - ki0 * D.inc, Cmin_t = Cmax_t - (kc - 1) * D.inc;
+                const int ssmax = Cmax_t - D.min_sum, ssmin = Cmin_t - D.max_sum, ssr = ssmax - ssmin + 1;
+                int np = std::max(1, std::min(lanes / kc, d.n_pos));       // every lane of a pair chunk owns one (position, capture size)
+                size_t lds_t = 0;
+                for (; np >= 1; np--) {
+                    lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l);
+                    if (lds_t <= 160 * 1024) break;
+                }
+                if (np < 1) { ok = false; break; }
+                // np = -inc (mod 32) makes the candidate steps' downstream-factor loads conflict free (see the kernel's lane mapping):
+                // taken when it costs few positions
+                { const int np_cf = np - ((np + D.inc) % 32); if (np_cf >= 1 && np_cf * 10 >= np * 9) { np = np_cf; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
+                // the same number of tiles, evenly filled (the last tile of a region is not a stub that costs a full table stage)
+                { const int nt = (d.n_pos + np - 1) / np, np_even = (d.n_pos + nt - 1) / nt;
+                  if (np_even < np) { np = np_even; lds_t = mipgen_svr_lds_bytes_tile(np, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l); } }
+                runs.push_back({ki0, kc, np});
+                lds_r = std::max(lds_r, lds_t);
+                const double tiles = std::ceil((double)d.n_pos / np);
+                ent += tiles * (np * (h->geom.n_e + h->geom.n_l) / 2.0 + (np + ssr - 1) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)np * ssr);
+                slots += tiles * lanes;
+            }
+            if (!ok) continue;
+            const double cost = 47.0 * ent + 2.7 * slots * D.n_pairs / 1.0;
+            if (best.runs.empty() || cost < best_cost) { best.runs = runs; best_cost = cost; best.lds = lds_r; }
+        }
+        return shapes.emplace(key, std::move(best)).first->second;
+    };
+    for (Window& w : h->windows) {
+        w.svr_tile0 = (int)st.size();
+        for (int i = w.r0; i < w.r1; i++) {
+            const DevRegion& d = h->hregions[i];
+            if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
+            const Shape& shape = shape_of(d);
+            if (shape.runs.empty()) { svr_lds = (size_t)1 << 30; continue; }
+            svr_lds = std::max(svr_lds, shape.lds);
+            const int Cmax = D.max_capture - d.k0 * D.inc;
+            for (const Run& r : shape.runs)
+                for (int p0 = 0; p0 < d.n_pos; p0 += r.np) {
+                    const int npt = std::min(r.np, d.n_pos - p0);
+                    // run time of the tile in wavefront-cycles per SV group (measured shares of the three stages): table entries, scan span,
+                    // candidate steps (all lanes of the block step, whatever the tile holds)
+                    const int Cmax_t = Cmax - r.ki0 * D.inc, ssmax = Cmax_t - D.min_sum, ssr = (r.kc - 1) * D.inc + D.max_sum - D.min_sum + 1;
+                    const double ent = (npt + (npt + ssr - 1)) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)npt * ssr;
+                    const double cost = 19.0 * ent + 100.0 * (npt + ssmax + 2 * Lmax) + 75000.0;
+                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); st_cost.push_back(cost); }
+                }
+        }
+        // longest tiles first: workgroups are dispatched in index order as compute units free up, so the short tiles fill the end of the
+        // launch (k_svr_dense takes tile blockIdx / n_split: consecutive tiles already land on different XCDs)
+        {
+            const size_t t0 = (size_t)w.svr_tile0, n = st.size() - t0;
+            std::vector<size_t> order(n);
+            for (size_t k = 0; k < n; k++) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st_cost[t0 + a] > st_cost[t0 + b]; });
+            std::vector<SvrTile> sorted(n);
+            for (size_t k = 0; k < n; k++) sorted[k] = st[t0 + order[k]];
+            std::copy(sorted.begin(), sorted.end(), st.begin() + (ptrdiff_t)t0);
+        }
+        w.n_svr_tiles = (int)st.size() - w.svr_tile0;
+    }
+    h->svr_batch_error.clear();
+    if (svr_lds > 160 * 1024) {
+        h->svr_batch_error = "an SVR tile needs more than 160 KiB of LDS: capture range / arm lists too wide";
+        st.clear();
+        for (Window& w : h->windows) { w.svr_tile0 = 0; w.n_svr_tiles = 0; }
+        svr_lds = 0;
+    }
+    if (h->svr_tiles.reserve(std::max<size_t>(st.size(), 1))) return MIPGEN_E_NOMEM;
+    if (!st.empty()) HIP_TRY(hipMemcpy(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice));
+    h->svr_lds = svr_lds;
+    h->svr_tiles_ready = true;
+    return MIPGEN_OK;
+}
+
+static int ensure_tiles(mipgen_accel* h, int32_t method)
+{
+    if (method == MIPGEN_SCORE_SVR) return h->svr_geometry_error.empty() ? build_svr_tiles(h) : MIPGEN_OK;       // the caller reports the geometry error
+    return build_logistic_tiles(h);
+}
+
 static int score_window_impl(mipgen_accel* h, int w, int32_t method)
 {
-    const Window& W = h->windows[(size_t)w];
     if (method == MIPGEN_SCORE_SVR && !h->svr_geometry_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_geometry_error.c_str());
+    if (int rc = ensure_tiles(h, method)) return rc;
+    const Window& W = h->windows[(size_t)w];
     if (method == MIPGEN_SCORE_SVR && !h->svr_batch_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_batch_error.c_str());
     hipEvent_t* ev = nullptr;
     if (h->timing) { if (ensure_events(h)) return MIPGEN_E_HIP; ev = &h->ev[4 * (size_t)w]; }
@@ -1258,14 +1404,34 @@ int mipgen_accel_survivors_device_ptr(const mipgen_accel* h, void** survivors_de
 }
 
 // ---- section 8f-3: arm-oligo copy numbers by exact k-mer counting (opt-in replacement of the bwa round trip) ----------------
-int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
-                                    const char* const* region_seqs, const int32_t* region_lens, int32_t n_lengths, const int32_t* lengths,
-                                    int32_t* const* copy_out)
-{
-    if (!h || n_chrom < 0 || n_regions < 0 || n_lengths < 1 || n_lengths > MIPGEN_MAX_OLIGO || !lengths || (n_chrom && (!chrom_seqs || !chrom_lens)) ||
-        (n_regions && (!region_seqs || !region_lens || !copy_out)))
-        return fail(MIPGEN_E_INVALID, "bad arguments");
+namespace {
+
+// device state of one counting run; `out` = int32 [n_k][total] over the concatenated region strings (kernels_kmer.hip: k_kmer_lookup)
+struct KmerRun {
     KmerParams KP;
+    int64_t total = 0;
+    std::vector<int64_t> roff;                // start of every region in the concatenation (one separator after each), then `total`
+    DevBuf<char> dq, dg;
+    DevBuf<uint64_t> dkeys;
+    DevBuf<unsigned int> dcounts;
+    DevBuf<uint32_t> dfilter, dfolded;
+    DevBuf<int32_t> out;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit KmerRun(DevPool* pool) { dq.pool = dg.pool = dkeys.pool = dcounts.pool = dfilter.pool = dfolded.pool = out.pool = pool; }
+    ~KmerRun()
+    {
+        dq.release(); dg.release(); dkeys.release(); dcounts.release(); dfilter.release(); dfolded.release(); out.release();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+// insert the regions' k-mers, stream the genome past them, look every region position up again: K.out is filled (on the stream) on return
+int kmer_count_run(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                   const char* const* region_seqs, const int32_t* region_lens, int32_t n_lengths, const int32_t* lengths, KmerRun& K)
+{
+    DIAG_CLOCK("oligo copies");
+    KmerParams& KP = K.KP;
     memset(&KP, 0, sizeof KP);
     KP.n_k = n_lengths;
     for (int i = 0; i < n_lengths; i++) {
@@ -1273,14 +1439,17 @@ int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char
         KP.k[i] = lengths[i];
     }
     KP.kmax = lengths[n_lengths - 1];
-    if (n_regions == 0) return MIPGEN_OK;
-    HIP_TRY(hipSetDevice(h->device));
     // region sequences, separated by one 'N' (no k-mer crosses it)
     int64_t total = 0;
-    std::vector<int64_t> roff((size_t)n_regions);
-    for (int r = 0; r < n_regions; r++) { roff[(size_t)r] = total; total += (int64_t)region_lens[r] + 1; }
+    K.roff.resize((size_t)n_regions + 1);
+    for (int r = 0; r < n_regions; r++) {
+        if (region_lens[r] < 0 || !region_seqs[r]) return fail(MIPGEN_E_INVALID, "region %d: no sequence", r);
+        K.roff[(size_t)r] = total; total += (int64_t)region_lens[r] + 1;
+    }
+    K.roff[(size_t)n_regions] = total;
+    K.total = total;
     std::vector<char> q((size_t)total, 'N');
-    for (int r = 0; r < n_regions; r++) memcpy(&q[(size_t)roff[(size_t)r]], region_seqs[r], (size_t)region_lens[r]);
+    for (int r = 0; r < n_regions; r++) memcpy(&q[(size_t)K.roff[(size_t)r]], region_seqs[r], (size_t)region_lens[r]);
     uint64_t cap = 1024;
     while (cap < 2 * (uint64_t)total) cap <<= 1;
     KP.cap_mask = cap - 1;
@@ -1289,68 +1458,117 @@ int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char
     while (KP.filter_bits < 30 && (1ull << KP.filter_bits) < 32ull * (uint64_t)total) KP.filter_bits++;
     int64_t gmax = 0;
     for (int c = 0; c < n_chrom; c++) gmax = std::max(gmax, chrom_lens[c]);
-    DevBuf<char> dq, dg;
-    DevBuf<uint64_t> dkeys;
-    DevBuf<unsigned int> dcounts;
-    DevBuf<uint32_t> dfilter, dfolded;
-    DevBuf<int32_t> dout;
     const size_t tab = (size_t)cap * (size_t)n_lengths;
-    int rc = 0;
-    if (dq.reserve((size_t)total) || dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || dkeys.reserve(tab) || dcounts.reserve(tab) || dfilter.reserve((size_t)1 << (KP.filter_bits - 5)) || dfolded.reserve((size_t)1 << 13) || dout.reserve((size_t)total * (size_t)n_lengths)) rc = MIPGEN_E_NOMEM;
-    auto cleanup = [&]() { dq.release(); dg.release(); dkeys.release(); dcounts.release(); dfilter.release(); dfolded.release(); dout.release(); };
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-#define KTRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return fail(MIPGEN_E_HIP, "%s: %s", #expr, hipGetErrorString(e__)); } } while (0)
-    if (rc) { cleanup(); return rc; }
-    KTRY(hipEventCreate(&e0)); KTRY(hipEventCreate(&e1));
-    KTRY(hipMemcpyAsync(dq.p, q.data(), (size_t)total, hipMemcpyHostToDevice, h->stream));
-    KTRY(hipMemsetAsync(dkeys.p, 0xFF, tab * sizeof(uint64_t), h->stream));
-    KTRY(hipMemsetAsync(dcounts.p, 0, tab * sizeof(unsigned int), h->stream));
-    KTRY(hipMemsetAsync(dfilter.p, 0, ((size_t)1 << (KP.filter_bits - 5)) * sizeof(uint32_t), h->stream));
-    KTRY(mipgen_launch_kmer_insert(h->stream, dq.p, total, &KP, dkeys.p, dfilter.p));
-    KTRY(mipgen_launch_kmer_fold(h->stream, dfilter.p, KP.filter_bits, dfolded.p));
+    if (K.dq.reserve((size_t)total) || K.dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || K.dkeys.reserve(tab) || K.dcounts.reserve(tab) ||
+        K.dfilter.reserve((size_t)1 << (KP.filter_bits - 5)) || K.dfolded.reserve((size_t)1 << 13) || K.out.reserve((size_t)total * (size_t)n_lengths))
+        return MIPGEN_E_NOMEM;
+    DIAG_LAP("concatenate + device buffers");
+    HIP_TRY(hipEventCreate(&K.e0)); HIP_TRY(hipEventCreate(&K.e1));
+    HIP_TRY(hipMemcpyAsync(K.dq.p, q.data(), (size_t)total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(K.dkeys.p, 0xFF, tab * sizeof(uint64_t), h->stream));
+    HIP_TRY(hipMemsetAsync(K.dcounts.p, 0, tab * sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemsetAsync(K.dfilter.p, 0, ((size_t)1 << (KP.filter_bits - 5)) * sizeof(uint32_t), h->stream));
+    HIP_TRY(mipgen_launch_kmer_insert(h->stream, K.dq.p, total, &KP, K.dkeys.p, K.dfilter.p));
+    HIP_TRY(mipgen_launch_kmer_fold(h->stream, K.dfilter.p, KP.filter_bits, K.dfolded.p));
+    HIP_TRY(hipStreamSynchronize(h->stream));                          // q dies with this scope
+    DIAG_LAP("insert");
     double ms_total = 0.0;
     int64_t gbytes = 0;
     for (int c = 0; c < n_chrom; c++) {                                // one streaming pass per chromosome: 1 byte per genome base
         if (chrom_lens[c] <= 0) continue;
-        KTRY(hipMemcpyAsync(dg.p, chrom_seqs[c], (size_t)chrom_lens[c], hipMemcpyHostToDevice, h->stream));
-        KTRY(hipEventRecord(e0, h->stream));
-        KTRY(mipgen_launch_kmer_count(h->stream, dg.p, chrom_lens[c], &KP, dkeys.p, dfilter.p, dfolded.p, dcounts.p, h->n_cu));
-        KTRY(hipEventRecord(e1, h->stream));
-        KTRY(hipEventSynchronize(e1));
+        HIP_TRY(hipMemcpyAsync(K.dg.p, chrom_seqs[c], (size_t)chrom_lens[c], hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipEventRecord(K.e0, h->stream));
+        HIP_TRY(mipgen_launch_kmer_count(h->stream, K.dg.p, chrom_lens[c], &KP, K.dkeys.p, K.dfilter.p, K.dfolded.p, K.dcounts.p, h->n_cu));
+        HIP_TRY(hipEventRecord(K.e1, h->stream));
+        HIP_TRY(hipEventSynchronize(K.e1));
         float ms = 0.f;
-        KTRY(hipEventElapsedTime(&ms, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&ms, K.e0, K.e1));
         ms_total += ms; gbytes += chrom_lens[c];
     }
-    KTRY(mipgen_launch_kmer_lookup(h->stream, dq.p, total, &KP, dkeys.p, dcounts.p, dout.p));
-    // back to the host one oligo length at a time through two pinned buffers: the copy of length s + 1 runs under the scatter of length s
-    {
-        PinnedPair<int32_t> pin;
-        KTRY(pin.alloc((size_t)total));
-        KTRY(hipMemcpyAsync(pin.buf[0], dout.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        KTRY(hipEventRecord(pin.done[0], h->stream));
-        pin.busy[0] = true;
-        for (int s = 0; s < n_lengths; s++) {
-            const int b = s & 1;
-            if (s + 1 < n_lengths) {
-                KTRY(hipMemcpyAsync(pin.buf[b ^ 1], dout.p + (size_t)(s + 1) * (size_t)total, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                KTRY(hipEventRecord(pin.done[b ^ 1], h->stream));
-                pin.busy[b ^ 1] = true;
-            }
-            KTRY(pin.wait(b));
-            for (int r = 0; r < n_regions; r++) {
-                const int len = region_lens[r];
-                if (!copy_out[r]) continue;
-                int32_t* dst = copy_out[r] + (size_t)s * (size_t)len;
-                memcpy(dst, pin.buf[b] + roff[(size_t)r], (size_t)len * sizeof(int32_t));
-                for (int i = std::max(0, len - lengths[s]); i < len; i++) dst[i] = 0;      // oligos the reference never writes (mipgen.cpp:829): absent key -> 0
-            }
-        }
-        KTRY(hipStreamSynchronize(h->stream));
-    }
-#undef KTRY
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    cleanup();
+    DIAG_LAP("genome passes");
+    HIP_TRY(mipgen_launch_kmer_lookup(h->stream, K.dq.p, total, &KP, K.dkeys.p, K.dcounts.p, K.out.p));
     h->kmer_count_ms = ms_total; h->kmer_genome_bytes = gbytes;
+    return MIPGEN_OK;
+}
+
+}  // namespace
+
+int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                    const char* const* region_seqs, const int32_t* region_lens, int32_t n_lengths, const int32_t* lengths,
+                                    int32_t* const* copy_out)
+{
+    if (!h || n_chrom < 0 || n_regions < 0 || n_lengths < 1 || n_lengths > MIPGEN_MAX_OLIGO || !lengths || (n_chrom && (!chrom_seqs || !chrom_lens)) ||
+        (n_regions && (!region_seqs || !region_lens || !copy_out)))
+        return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (n_regions == 0) return MIPGEN_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    KmerRun K(&h->pool);
+    if (int rc = kmer_count_run(h, n_chrom, chrom_seqs, chrom_lens, n_regions, region_seqs, region_lens, n_lengths, lengths, K)) return rc;
+    // back to the host one oligo length at a time through two pinned buffers: the copy of length s + 1 runs under the scatter of length s
+    const int64_t total = K.total;
+    PinnedPair<int32_t> pin;
+    HIP_TRY(pin.alloc((size_t)total));
+    HIP_TRY(hipMemcpyAsync(pin.buf[0], K.out.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(pin.done[0], h->stream));
+    pin.busy[0] = true;
+    for (int s = 0; s < n_lengths; s++) {
+        const int b = s & 1;
+        if (s + 1 < n_lengths) {
+            HIP_TRY(hipMemcpyAsync(pin.buf[b ^ 1], K.out.p + (size_t)(s + 1) * (size_t)total, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipEventRecord(pin.done[b ^ 1], h->stream));
+            pin.busy[b ^ 1] = true;
+        }
+        HIP_TRY(pin.wait(b));
+        for (int r = 0; r < n_regions; r++) {
+            const int len = region_lens[r];
+            if (!copy_out[r]) continue;
+            int32_t* dst = copy_out[r] + (size_t)s * (size_t)len;
+            memcpy(dst, pin.buf[b] + K.roff[(size_t)r], (size_t)len * sizeof(int32_t));
+            for (int i = std::max(0, len - lengths[s]); i < len; i++) dst[i] = 0;      // oligos the reference never writes (mipgen.cpp:829): absent key -> 0
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_count_oligo_copies_resident(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                             const char* const* region_seqs, const int32_t* region_lens, int64_t* n_big, const mipgen_big_copy** big)
+{
+    if (!h || n_chrom < 0 || n_regions < 0 || (n_chrom && (!chrom_seqs || !chrom_lens)) || (n_regions && (!region_seqs || !region_lens)))
+        return fail(MIPGEN_E_INVALID, "bad arguments");
+    h->resident_lens.clear();
+    h->big_copies.clear();
+    if (n_big) *n_big = 0;
+    if (big) *big = nullptr;
+    if (n_regions == 0) return MIPGEN_OK;
+    const DevParams& D = h->hp;
+    std::vector<int32_t> lengths;                                      // slot order = ascending oligo length (create_handle)
+    for (int len = 0; len <= MIPGEN_MAX_OLIGO; len++) if (D.len_slot[len] >= 0) lengths.push_back(len);
+    if ((int)lengths.size() != D.n_len_slots || lengths.empty()) return fail(MIPGEN_E_INVALID, "internal: oligo length slots");
+    HIP_TRY(hipSetDevice(h->device));
+    KmerRun K(&h->pool);
+    if (int rc = kmer_count_run(h, n_chrom, chrom_seqs, chrom_lens, n_regions, region_seqs, region_lens, (int32_t)lengths.size(), lengths.data(), K)) return rc;
+    const int64_t copy_total = (K.total - n_regions) * (int64_t)D.n_len_slots;
+    const unsigned int big_cap = (unsigned int)std::min<int64_t>(std::max<int64_t>(K.total / 4, (int64_t)1 << 16), (int64_t)1 << 28);
+    DevBuf<int64_t> droff;
+    DevBuf<mipgen_big_copy> dbig;
+    DevBuf<unsigned int> dn;
+    struct Free { DevBuf<int64_t>& a; DevBuf<mipgen_big_copy>& b; DevBuf<unsigned int>& c; ~Free() { a.release(); b.release(); c.release(); } } free_all{droff, dbig, dn};
+    if (h->copy.reserve((size_t)std::max<int64_t>(copy_total, 1)) || droff.reserve(K.roff.size()) || dbig.reserve(big_cap) || dn.reserve(1)) return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemcpyAsync(droff.p, K.roff.data(), K.roff.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(dn.p, 0, sizeof(unsigned int), h->stream));
+    HIP_TRY(mipgen_launch_kmer_place(h->stream, K.out.p, K.total, &K.KP, droff.p, n_regions, h->copy.p, dbig.p, dn.p, big_cap));
+    unsigned int nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, dn.p, sizeof nb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (nb > big_cap) return fail(MIPGEN_E_NOMEM, "%u oligos with 65535 or more copies (list capacity %u): use mipgen_accel_count_oligo_copies", nb, big_cap);
+    h->big_copies.resize(nb);
+    if (nb) HIP_TRY(hipMemcpy(h->big_copies.data(), dbig.p, (size_t)nb * sizeof(mipgen_big_copy), hipMemcpyDeviceToHost));
+    std::sort(h->big_copies.begin(), h->big_copies.end(), [](const mipgen_big_copy& x, const mipgen_big_copy& y) {
+        return x.region != y.region ? x.region < y.region : (x.length != y.length ? x.length < y.length : x.start < y.start); });
+    h->resident_lens.assign(region_lens, region_lens + n_regions);
+    if (n_big) *n_big = (int64_t)nb;
+    if (big) *big = h->big_copies.data();
     return MIPGEN_OK;
 }
 

@@ -248,6 +248,36 @@ __global__ __launch_bounds__(256) void k_kmer_lookup(const char* __restrict__ se
     for (int slot = got; slot < P.n_k; slot++) out[(int64_t)slot * len + i] = 100;     // a non-ACGT byte inside the window (the host zeroes region tails)
 }
 
+// The resident layout of the copy tables (common.h: per region int32 [n_len_slots][seq_len], regions back to back) from the [n_k][len] image
+// of k_kmer_lookup, so that the counts never leave the device between the counter and the scoring kernels.  roff[r] = start of region r in
+// the concatenated sequence (one separator after every region; roff[n_regions] = len).  Oligos that would run past their region string are
+// 0 (mipgen.cpp:829); counts the 16-bit record fields cannot carry (>= 65535) are listed for the host as well.
+struct KmerBig { int32_t region, length, start, copies; };
+
+__global__ __launch_bounds__(256) void k_kmer_place(const int32_t* __restrict__ src, int64_t len, KmerParams P, const int64_t* __restrict__ roff, int n_regions,
+                                                    int32_t* __restrict__ dst, KmerBig* __restrict__ big, unsigned int* __restrict__ n_big, unsigned int big_cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    int lo = 0, hi = n_regions - 1;
+    while (lo < hi) {                                                  // the last region that starts at or before i
+        const int mid = (lo + hi + 1) >> 1;
+        if (roff[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    const int64_t r0 = roff[lo];
+    const int rl = (int)(roff[lo + 1] - r0 - 1), rel = (int)(i - r0);
+    if (rel >= rl) return;                                             // the separator
+    int32_t* block = dst + (r0 - lo) * P.n_k;                          // sum of the earlier regions' lengths x slots
+    for (int s = 0; s < P.n_k; s++) {
+        const int32_t v = rel < rl - P.k[s] ? src[(int64_t)s * len + i] : 0;
+        block[(int64_t)s * rl + rel] = v;
+        if (v >= 65535) {
+            const unsigned int at = atomicAdd(n_big, 1u);
+            if (at < big_cap) big[at] = KmerBig{lo, P.k[s], rel, v};
+        }
+    }
+}
+
 extern "C" hipError_t mipgen_launch_kmer_insert(hipStream_t s, const char* seq, int64_t len, const KmerParams* P, uint64_t* keys, uint32_t* filter)
 {
     if (len <= 0) return hipSuccess;
@@ -275,5 +305,12 @@ extern "C" hipError_t mipgen_launch_kmer_lookup(hipStream_t s, const char* seq, 
 {
     if (len <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_kmer_lookup, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, seq, len, *P, keys, counts, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_kmer_place(hipStream_t s, const int32_t* src, int64_t len, const KmerParams* P, const int64_t* roff, int n_regions,
+                                               int32_t* dst, void* big, unsigned int* n_big, unsigned int big_cap)
+{
+    if (len <= 0 || n_regions <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_kmer_place, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, src, len, *P, roff, n_regions, dst, (KmerBig*)big, n_big, big_cap);
     return hipGetLastError();
 }

@@ -487,3 +487,26 @@ extern "C" hipError_t mipgen_launch_collapse(hipStream_t stream, int n_tiles, co
     hipLaunchKernelGGL(k_collapse, dim3(n_tiles), dim3(256), 0, stream, n_tiles, tiles, P, regions, region_pos0, region_base0, survivors, copy, cand_base, collapsed);
     return hipGetLastError();
 }
+
+// the scan-position map of a batch (position -> region, position inside the region) from the regions' first-position offsets:
+// region_pos0[r] = positions before region r, region_pos0[n_regions] = total
+__global__ __launch_bounds__(256) void k_fill_pos_map(const int64_t* __restrict__ region_pos0, int n_regions, int64_t total, int32_t* __restrict__ pos_region,
+                                                      int32_t* __restrict__ pos_local)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = n_regions - 1;
+    while (lo < hi) {                                                  // the last region that starts at or before i (empty regions share a start: the last wins)
+        const int mid = (lo + hi + 1) >> 1;
+        if (region_pos0[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    pos_region[i] = lo;
+    pos_local[i] = (int32_t)(i - region_pos0[lo]);
+}
+
+extern "C" hipError_t mipgen_launch_fill_pos_map(hipStream_t stream, const int64_t* region_pos0, int n_regions, int64_t total, int32_t* pos_region, int32_t* pos_local)
+{
+    if (total <= 0 || n_regions <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_pos_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, region_pos0, n_regions, total, pos_region, pos_local);
+    return hipGetLastError();
+}

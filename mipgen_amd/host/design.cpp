@@ -55,6 +55,11 @@ struct mipgen_design {
     std::string model_path;
     int next_region = 0;
     bool closed = false;
+    // -gpu_copy_counter on: the genome the arm oligos are counted against.  The device workers of mipgen_design_tile_regions count their own
+    // shard and keep the tables in HBM; host tables are only built for a caller that asks for the regions (mipgen_design_region).
+    std::vector<std::string> genome;
+    bool copies_deferred = false;
+    std::mutex copies_mu;
 };
 
 extern "C" {
@@ -114,7 +119,9 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         out.progress << "all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         std::cerr << "[mipgen] all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         if (gpu_copies) {
-            gpu_copy_numbers(o, d->regions);
+            load_genome(o, d->regions, d->genome);
+            d->copies_deferred = true;
+            for (Region& r : d->regions) r.copy_deferred = true;
             out.progress << "0 ambiguously mapping start positions must be avoided\nexact oligo copy numbers counted on the accelerator\n";
             std::cerr << "[mipgen] oligo copy numbers counted on the accelerator (no bwa)\n";
         } else {
@@ -174,6 +181,14 @@ int32_t mipgen_design_region_count(const mipgen_design* d) { return d ? (int32_t
 int mipgen_design_region(const mipgen_design* d, int32_t i, mipgen_region* out)
 {
     if (!d || !out || i < 0 || i >= (int32_t)d->regions.size()) return fail(MIPGEN_HOST_E_USAGE, 0, "region index out of range");
+    if (d->copies_deferred) {                                          // the caller scores through its own handle: it needs the tables on the host
+        mipgen_design* md = const_cast<mipgen_design*>(d);
+        std::lock_guard<std::mutex> lock(md->copies_mu);
+        if (!md->regions[(size_t)i].copy_ready) {
+            try { gpu_copy_numbers(md->o, md->genome, md->regions); } catch (int e) { return fail(MIPGEN_HOST_E_ACCEL, e, std::string("accelerator: ") + mipgen_accel_last_error()); }
+            for (Region& r : md->regions) { r.copy_deferred = false; attach_copy_tables(md->o, r); }
+        }
+    }
     fill_accel_region(d->regions[(size_t)i], *out);
     return 0;
 }
@@ -214,8 +229,12 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
     const Region& r = d->regions[(size_t)i];
     Outputs& out = d->out;
     try {
-        out.progress << "designing all mips for feature #" << i + 1 << std::endl;
-        std::cerr << "[mipgen] feature #" << i + 1 << std::endl;
+        out.progress << "designing all mips for feature #" << i + 1 << '\n';        // flushed when the design closes (200,000 regions: no write per line)
+        {
+            char line[48];
+            const int n = snprintf(line, sizeof line, "[mipgen] feature #%d\n", i + 1);
+            std::cerr.write(line, n);                                                // unbuffered stream: one write, not three
+        }
         if (!o.silent && scores && records && emitted_mask) {
             // the reference's generation order: position, size, pair, plus then minus (mipgen.cpp:421-491)
             const int64_t An = (int64_t)o.arm_pairs.size();
@@ -232,7 +251,7 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
                     }
             out.all << buf;
         } else out.all_counter += (int)emitted;
-        out.progress << "condensing feature #" << i + 1 << "\ncollapsing feature #" << i + 1 << std::endl;
+        out.progress << "condensing feature #" << i + 1 << "\ncollapsing feature #" << i + 1 << '\n';
         std::vector<mipgen_survivor> rs(survivors, survivors + 2 * (size_t)grid->n_pos);
         for (auto& s : rs) if (s.cand_index >= 0) s.cand_index -= grid->offset;       // region-local for make_cand
         const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;   // mixed scans with logistic (:467)
@@ -337,7 +356,7 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
     const Options& o = d->o;
     // $MIPGEN_TIMING: seconds per stage of this worker
     const bool timing = std::getenv("MIPGEN_TIMING") != nullptr;
-    double t_stage[6] = {0, 0, 0, 0, 0, 0};      // create + model, long-range content, upload, score + replay + collapse (+ downloads), text, mixed re-scores
+    double t_stage[7] = {0, 0, 0, 0, 0, 0, 0};   // create + model, long-range content, upload, score + replay + collapse (+ downloads), text, mixed re-scores, copy numbers
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](int k) { const auto n_ = std::chrono::steady_clock::now(); t_stage[k] += std::chrono::duration<double>(n_ - t_prev).count(); t_prev = n_; };
     mipgen_accel* h = nullptr;
@@ -361,8 +380,24 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
         for (int i = 0; i < n; i++) memcpy(d->regions[(size_t)(r0 + i)].lrc, &lrc[(size_t)i * MIPGEN_N_LRC], sizeof(double) * MIPGEN_N_LRC);
     }
     lap(1);
+    // -gpu_copy_counter on: this handle counts the arm oligos of its own shard against the genome; the tables never leave its HBM
+    // (host tables exist already if a caller asked for the regions before)
+    const bool resident = d->copies_deferred && n > 0 && !d->regions[(size_t)r0].copy_ready;
+    if (resident) {
+        std::vector<const char*> cs, rs;
+        std::vector<int64_t> cl;
+        std::vector<int32_t> rl;
+        for (const std::string& c : d->genome) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
+        for (int i = 0; i < n; i++) { const Region& r = d->regions[(size_t)(r0 + i)]; rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size()); }
+        int64_t n_big = 0;
+        const mipgen_big_copy* big = nullptr;
+        if (mipgen_accel_count_oligo_copies_resident(h, (int32_t)cs.size(), cs.data(), cl.data(), n, rs.data(), rl.data(), &n_big, &big)) { bail(11); return; }
+        for (int i = 0; i < n; i++) { Region& r = d->regions[(size_t)(r0 + i)]; r.copy_resident = true; r.big_copy.clear(); }
+        for (int64_t k = 0; k < n_big; k++) d->regions[(size_t)(r0 + big[k].region)].big_copy[{big[k].length, big[k].start}] = big[k].copies;
+    }
+    lap(6);
     std::vector<mipgen_region> batch((size_t)n);
-    for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)(r0 + i)], batch[(size_t)i]);
+    for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)(r0 + i)], batch[(size_t)i], resident);
     std::vector<mipgen_grid> grids((size_t)n);
     // silent designs keep only survivors, so a window may fill the HBM; otherwise its dense results come to the host (17 B per candidate)
     mipgen_accel_set_window_candidates(h, o.silent ? 0 : (int64_t)64 << 20);
@@ -440,7 +475,8 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
     mipgen_accel_destroy(h);
     if (timing) {
         std::ostringstream line;                                     // one write: the selection thread prints to stderr too
-        line << "[mipgen timing] device " << device << " worker: create + model " << t_stage[0] << " s, long-range content " << t_stage[1] << " s, upload "
+        line << "[mipgen timing] device " << device << " worker: create + model " << t_stage[0] << " s, long-range content " << t_stage[1]
+             << " s, arm copy numbers (resident) " << t_stage[6] << " s, upload "
              << t_stage[2] << " s, score + replay + collapse + downloads " << t_stage[3] << " s, record text " << t_stage[4] << " s, mixed re-scores "
              << t_stage[5] << " s\n";
         std::cerr << line.str();

@@ -325,15 +325,27 @@ static char comp(char c)
     switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; default: return 0; }
 }
 
+void attach_copy_tables(const Options& o, Region& r)
+{
+    const size_t n = r.seq.size();
+    r.copy_ptr.assign(MIPGEN_MAX_OLIGO + 1, nullptr);
+    size_t k = 0;
+    for (int len : o.oligo_sizes) {
+        if (len < 0 || len > MIPGEN_MAX_OLIGO) continue;
+        r.copy_ptr[(size_t)len] = r.copy_ready ? r.copy_flat.data() + k * n : r.copy_store[k].data();
+        k++;
+    }
+}
+
 // slices of the global tables in the layout of mipgen_region (include/mipgen_accel.h)
 void attach_tables(const Options& o, const Tables& t, Region& r)
 {
     const int n = (int)r.seq.size();
     r.copy_store.clear();
-    r.copy_ptr.assign(MIPGEN_MAX_OLIGO + 1, nullptr);
+    r.copy_ptr.clear();
     auto cit = t.copies.find(r.chr);
     for (int len : o.oligo_sizes) {
-        if (r.copy_ready) break;
+        if (r.copy_ready || r.copy_deferred) break;
         if (len < 0 || len > MIPGEN_MAX_OLIGO) continue;
         r.copy_store.emplace_back((size_t)n, 0);                                 // absent key -> 0 (std::map::operator[], mipgen.cpp:612-613)
         std::vector<int32_t>& v = r.copy_store.back();
@@ -345,14 +357,7 @@ void attach_tables(const Options& o, const Tables& t, Region& r)
             }
         }
     }
-    {
-        size_t k = 0;
-        for (int len : o.oligo_sizes) {
-            if (len < 0 || len > MIPGEN_MAX_OLIGO) continue;
-            r.copy_ptr[(size_t)len] = r.copy_ready ? r.copy_flat.data() + k * (size_t)n : r.copy_store[k].data();
-            k++;
-        }
-    }
+    if (!r.copy_deferred) attach_copy_tables(o, r);            // deferred: counted by the scoring handle (design.cpp: worker), or on the first mipgen_design_region
     r.unmappable.clear();
     if (!t.unmappable.empty()) {
         const int K = (o.max_capture - o.min_capture) / o.capture_increment + 1;
@@ -383,10 +388,10 @@ void attach_tables(const Options& o, const Tables& t, Region& r)
 
 // the arm-oligo copy numbers (mipgen.cpp:558-596, 825-835) as exact occurrence counts against the whole genome,
 // counted by the accelerator in one streaming pass per chromosome - no FASTQ files, no bwa.
-void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
+// the genome the reference's bwa index was built from: every chr*.fa of -genome_dir, or every record of the indexed fasta
+void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<std::string>& chroms)
 {
-    // the genome the reference's bwa index was built from: every chr*.fa of -genome_dir, or every record of the indexed fasta
-    std::vector<std::string> chroms;
+    chroms.clear();
     auto read_fasta = [&](const std::string& path) {                  // whole file at once, lines joined by memchr / append
         FILE* fh = fopen(path.c_str(), "rb");
         if (!fh) return false;
@@ -422,6 +427,11 @@ void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
         std::string name;
         while (lst >> name) if (seen.insert(name).second) read_fasta(dir + "/chr" + name + ".fa");
     } else if (!read_fasta(o.bwa_genome_index)) { std::cerr << "genome fasta could not be opened; check file path and permissions?" << std::endl; throw 9; }
+}
+
+// the counts as host tables (Region::copy_flat): for callers that score through their own accelerator handle
+void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs)
+{
     std::vector<const char*> cs; std::vector<int64_t> cl;
     for (const std::string& c : chroms) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
     std::vector<int32_t> lengths(o.oligo_sizes.begin(), o.oligo_sizes.end());
@@ -441,14 +451,14 @@ void gpu_copy_numbers(const Options& o, std::vector<Region>& regs)
     for (Region& r : regs) r.copy_ready = true;
 }
 
-void fill_accel_region(const Region& r, mipgen_region& out)
+void fill_accel_region(const Region& r, mipgen_region& out, bool resident_copies)
 {
     memset(&out, 0, sizeof out);
     out.start_flanked = r.start_fl; out.stop_flanked = r.stop_fl;
     out.seq_start = r.seq_start; out.seq_stop = r.seq_stop; out.seq_len = (int)r.seq.size();
     out.seq = r.seq.c_str();
     out.masked_seq = r.masked.size() == r.seq.size() ? r.masked.c_str() : nullptr;
-    out.copy = r.copy_ptr.empty() ? nullptr : r.copy_ptr.data();
+    out.copy = resident_copies ? MIPGEN_COPY_RESIDENT : (r.copy_ptr.empty() ? nullptr : r.copy_ptr.data());
     out.unmappable = r.unmappable.empty() ? nullptr : r.unmappable.data();
     out.snp_class = r.snp_class.empty() ? nullptr : r.snp_class.data();
     memcpy(out.long_range_content, r.lrc, sizeof out.long_range_content);

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <fstream>
+#include <array>
 #include <map>
 #include <memory>
 #include <set>
@@ -65,6 +66,11 @@ struct Region {                                   // Featurev5
     std::vector<const int32_t*> copy_ptr;
     std::vector<uint8_t> unmappable, snp_class;
     std::string long_range_seq;                   // region +/- 1000 bases (svr / mixed only)
+    // -gpu_copy_counter on, counted by the scoring handle itself: the tables stay in HBM (MIPGEN_COPY_RESIDENT) and the host only holds
+    // the counts the 16-bit record fields cannot carry: (oligo length, offset in seq) -> copies >= 65535
+    bool copy_resident = false;
+    bool copy_deferred = false;                   // -gpu_copy_counter on: no tables yet (design.cpp counts them where they are needed)
+    std::map<std::pair<int, int>, int> big_copy;
     bool copy_ready = false;                      // copy_flat already holds the oligo copy numbers (-gpu_copy_counter on)
 };
 
@@ -85,8 +91,10 @@ std::string check_copy_numbers(const Options& o, const std::vector<Region>& regs
 void find_copy(const Options& o, Tables& t);
 void attach_tables(const Options& o, const Tables& t, Region& r);                          // fill copy/unmappable/snp slices
 // -gpu_copy_counter on: exact oligo copy numbers from the accelerator's k-mer counter instead of the bwa round trip; throws int on failure
-void gpu_copy_numbers(const Options& o, std::vector<Region>& regs);
-void fill_accel_region(const Region& r, mipgen_region& out);
+void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<std::string>& chroms);   // the genome behind the bwa index
+void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs); // host tables (copy_flat)
+void attach_copy_tables(const Options& o, Region& r);                                                  // copy_ptr from copy_store / copy_flat
+void fill_accel_region(const Region& r, mipgen_region& out, bool resident_copies = false);
 
 // one candidate as the selection stage sees it (the fields of SVMipv4 it reads)
 struct Cand {
@@ -150,6 +158,49 @@ private:
     std::vector<uint64_t> bits_;
 };
 
+// positions_to_scan (and its three siblings) of pick_mips (mipgen.cpp:1508-1516): the reference fills a std::set<int> with the flanked
+// region, base by base, and only ever erases from it.  Same membership and ascending order as a bitmap over that run; front() / back()
+// are *begin() / *rbegin().
+class PosSet {
+public:
+    void fill(int first, int last)                  // every position of [first, last]
+    {
+        first_ = first;
+        const int n = std::max(last - first + 1, 0);
+        bits_.assign(((size_t)n + 63) / 64, ~0ull);
+        if (n & 63) bits_.back() = ~0ull >> (64 - (n & 63));
+        count_ = n; lo_ = 0; hi_ = bits_.empty() ? 0 : bits_.size() - 1;
+    }
+    bool empty() const { return count_ == 0; }
+    int front() const                               // undefined on an empty set, as *begin() is
+    {
+        while (lo_ < bits_.size() && !bits_[lo_]) lo_++;
+        return lo_ < bits_.size() ? first_ + (int)(lo_ * 64) + __builtin_ctzll(bits_[lo_]) : first_;
+    }
+    int back() const
+    {
+        while (hi_ > 0 && !bits_[hi_]) hi_--;
+        return !bits_.empty() && bits_[hi_] ? first_ + (int)(hi_ * 64) + 63 - __builtin_clzll(bits_[hi_]) : first_;
+    }
+    void erase(int p)
+    {
+        const long rel = (long)p - first_;
+        if (rel < 0 || (size_t)rel >= bits_.size() * 64) return;
+        uint64_t& w = bits_[(size_t)rel >> 6];
+        const uint64_t bit = 1ull << (rel & 63);
+        if (w & bit) { w &= ~bit; count_--; }
+    }
+    template <class F> void for_each(F f) const     // ascending
+    {
+        for (size_t w = lo_; w < bits_.size(); w++)
+            for (uint64_t b = bits_[w]; b; b &= b - 1) f(first_ + (int)(w * 64) + __builtin_ctzll(b));
+    }
+private:
+    int first_ = 0, count_ = 0;
+    mutable size_t lo_ = 0, hi_ = 0;                // words below lo_ / above hi_ are empty (the set only shrinks)
+    std::vector<uint64_t> bits_;
+};
+
 // scan_strand_best_mip / pos_strand_best_mip of the region in hand (mipgen.cpp:1616-1746, 1748-1908): [position][strand] -> candidate.
 // The reference nests two std::map; the positions of a region are one dense run, so this is a flat table from the first position with
 // an "exists" flag per position - operator[] on the reference's map CREATES the position (:1869) and later find() calls see it, which
@@ -194,18 +245,19 @@ private:
     using CandPtr = Cand*;                                                 // into arena_: valid until the next region
     std::vector<Cand> arena_;                                              // the survivors of the region in hand (<= 2 per scan position)
     const Options& o_; const Tables& t_; Outputs& out_;
-    std::map<std::string, std::map<int, UsedBases>> used_;                 // chr_strand_pos_used_arm_bases (persists across regions)
+    std::map<std::string, std::array<UsedBases, 2>> used_;                 // chr_strand_pos_used_arm_bases (persists across regions)
+    std::array<UsedBases, 2>* used_cur_ = nullptr;                         // ... of the chromosome of the region in hand
     PosTable scan_best_, pos_best_;                                        // [position][strand 0/1]
     const Region* r_ = nullptr; Rescorer* rs_ = nullptr; double lower_ = 0, upper_ = 0;
     GlibcRand rand_;
     void collapse();
     void output_collapsed();
     void pick();
-    CandPtr optimize_worst(std::set<int>& positions, int strand_to_use);
-    CandPtr translocate(std::set<int>& positions, int strand_to_use);
-    void manage_picked(CandPtr m, std::set<int>& positions);
-    void print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions);
-    void create_gap(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions);
+    CandPtr optimize_worst(PosSet& positions, int strand_to_use);
+    CandPtr translocate(PosSet& positions, int strand_to_use);
+    void manage_picked(CandPtr m, PosSet& positions);
+    void print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, PosSet& positions);
+    void create_gap(std::ofstream& f, const std::string& ext, const std::string& note, PosSet& positions);
     bool arm_used(const Cand& c, int strand) const;
 };
 

@@ -42,6 +42,10 @@ Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t 
     // the record's 16-bit copy fields saturate; bwa's X0 count does not (mipgen.cpp:586-587): a saturated field is read from the
     // region's own copy table, so printed and compared copies are the reference's
     auto true_copy = [&](int start, int len) -> int {
+        if (r.copy_resident) {                                                     // the tables stayed in HBM: the host holds exactly the counts >= 65535
+            auto it = r.big_copy.find({len, (int)((long)start - r.seq_start)});
+            return it != r.big_copy.end() ? it->second : 0;
+        }
         if ((size_t)len >= r.copy_ptr.size() || !r.copy_ptr[(size_t)len]) return 65535;
         const long rel = (long)start - r.seq_start;
         return rel >= 0 && rel < (long)r.seq.size() ? r.copy_ptr[(size_t)len][rel] : 0;
@@ -179,17 +183,15 @@ int GlibcRand::next()
 
 bool Selector::arm_used(const Cand& c, int strand) const
 {
-    auto ci = used_.find(r_->chr);
-    if (ci == used_.end()) return false;
-    auto si = ci->second.find(strand);
-    if (si == ci->second.end()) return false;
-    return si->second.any(c.ext_start, c.ext_stop) || si->second.any(c.lig_start, c.lig_stop);
+    const UsedBases& u = (*used_cur_)[(size_t)strand];
+    return u.any(c.ext_start, c.ext_stop) || u.any(c.lig_start, c.lig_stop);
 }
 
 void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& surv, Rescorer* rs,
                           double lower, double upper, const int32_t* collapsed, int32_t n_bases)
 {
     r_ = &r; rs_ = rs; lower_ = lower; upper_ = upper;
+    used_cur_ = &used_[r.chr];
     const auto t0 = std::chrono::steady_clock::now();
     scan_best_.reset(g.first_pos, g.n_pos); pos_best_.reset(g.first_pos, collapsed ? n_bases : g.n_pos);
     arena_.clear(); arena_.reserve((size_t)2 * (size_t)std::max(g.n_pos, 0));                 // never reallocates below: the pointers stay valid
@@ -260,12 +262,12 @@ void Selector::output_collapsed()
 }
 
 // optimize_worst_in_region, mipgen.cpp:1748-1820
-Selector::CandPtr Selector::optimize_worst(std::set<int>& positions, int strand_to_use)
+Selector::CandPtr Selector::optimize_worst(PosSet& positions, int strand_to_use)
 {
     CandPtr worst = nullptr;
-    for (int pos : positions) {
+    positions.for_each([&](int pos) {
         PosTable::Slot* pit = pos_best_.find(pos);
-        if (!pit) continue;
+        if (!pit) return;
         CandPtr cur = nullptr, plus = nullptr, minus = nullptr;
         bool plus_set = false, minus_set = false;
         if (pit->m[0] && strand_to_use != 1) {
@@ -279,15 +281,15 @@ Selector::CandPtr Selector::optimize_worst(std::set<int>& positions, int strand_
             if (minus_set) cur = plus_set ? (plus->score > minus->score ? plus : minus) : minus;
         }
         if ((plus_set || minus_set) && (!worst || cur->score < worst->score)) worst = cur;
-    }
+    });
     return worst;
 }
 
 // translocate_down_region, mipgen.cpp:1822-1908
-Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_use)
+Selector::CandPtr Selector::translocate(PosSet& positions, int strand_to_use)
 {
     if (positions.empty()) return nullptr;                       // the reference dereferences begin() of an empty set here (UB); see DESIGN.md
-    const int latest = *positions.begin();
+    const int latest = positions.front();
     const int to_end = r_->stop_fl - latest;
     const int min_scan = o_.min_capture - o_.max_arm_sum;
     int earliest, prelim, dir;
@@ -304,7 +306,7 @@ Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_
     for (int chosen = prelim;
          (!next && prev_extent > latest && chosen < r_->stop_fl && chosen > r_->start_fl - o_.min_capture) ||
          (next && ((next->score < upper_ || next->snp_count > 0) && chosen >= earliest && chosen <= latest - o_.starting_mip_overlap &&
-                   (dir == -1 || chosen + next->scan_size() > *positions.rbegin())));
+                   (dir == -1 || chosen + next->scan_size() > positions.back())));
          chosen += dir) {
         int strand_index, iterations;
         if (strand_to_use != -1) { strand_index = 1 - strand_to_use; iterations = 1; }
@@ -333,14 +335,14 @@ Selector::CandPtr Selector::translocate(std::set<int>& positions, int strand_to_
 }
 
 // manage_picked_mip, mipgen.cpp:1910-1939
-void Selector::manage_picked(CandPtr m, std::set<int>& positions)
+void Selector::manage_picked(CandPtr m, PosSet& positions)
 {
     out_.picked_counter++;
     out_.picked << format_record(o_, *r_, t_, *m, out_.picked_counter, false);
     if (m->snp_count == 1 && m->snp_failed == '0') out_.snp << format_record(o_, *r_, t_, *m, out_.picked_counter, true);
     else if (m->snp_failed == '1') out_.snp << ">Alternate MIP(s) could not be generated for SNP in arms of MIP #" << out_.picked_counter << std::endl;
     const int other = 1 - m->strand;
-    auto& used = used_[r_->chr];
+    auto& used = *used_cur_;
     if (o_.seal_both) {
         for (int p = m->ext_start; p <= m->ext_stop; p++) used[other].insert(p);
         for (int p = m->lig_start; p <= m->lig_stop; p++) used[other].insert(p);
@@ -354,31 +356,31 @@ void Selector::manage_picked(CandPtr m, std::set<int>& positions)
 }
 
 // print_gaps, mipgen.cpp:1231-1259
-void Selector::print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions)
+void Selector::print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, PosSet& positions)
 {
     if (positions.empty()) return;
     if (!f.is_open()) f.open(o_.arg("-project_name") + ext);
     out_.progress << note << r_->chr << ":\n";
-    int start = *positions.begin(), stop = start - 1;
-    for (int p : positions) {
+    int start = positions.front(), stop = start - 1;
+    positions.for_each([&](int p) {
         if (p == stop + 1) stop++;
         else {
             out_.bad_design_count++;
             f << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
             start = p; stop = p;
         }
-    }
+    });
     out_.bad_design_count++;
     f << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
 }
 
 // create_gap, mipgen.cpp:1261-1278
-void Selector::create_gap(std::ofstream& f, const std::string& ext, const std::string& note, std::set<int>& positions)
+void Selector::create_gap(std::ofstream& f, const std::string& ext, const std::string& note, PosSet& positions)
 {
     out_.bad_design_count++;
     if (!f.is_open()) f.open(o_.arg("-project_name") + ext);
     out_.progress << note << r_->chr << ":\n";
-    const int start = *positions.begin(), stop = start + o_.max_capture / 2;
+    const int start = positions.front(), stop = start + o_.max_capture / 2;
     out_.progress << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
     for (int i = start; i <= stop; i++) positions.erase(i);
     f << r_->chr << "\t" << start - 1 << "\t" << stop << std::endl;
@@ -387,14 +389,12 @@ void Selector::create_gap(std::ofstream& f, const std::string& ext, const std::s
 // pick_mips, mipgen.cpp:1506-1614
 void Selector::pick()
 {
-    std::set<int> pos, again, minus, minus_again;
+    PosSet pos, again, minus, minus_again;
     const int strand_to_use = o_.double_tile_strands_separately ? 0 : -1;
-    for (int p = r_->start_fl; p <= r_->stop_fl; p++) {
-        pos.insert(p);
-        if (o_.double_tile) again.insert(p);
-        if (o_.double_tile_strands_separately) minus.insert(p);
-        if (o_.double_tile && o_.double_tile_strands_separately) minus_again.insert(p);
-    }
+    pos.fill(r_->start_fl, r_->stop_fl);
+    if (o_.double_tile) again.fill(r_->start_fl, r_->stop_fl);
+    if (o_.double_tile_strands_separately) minus.fill(r_->start_fl, r_->stop_fl);
+    if (o_.double_tile && o_.double_tile_strands_separately) minus_again.fill(r_->start_fl, r_->stop_fl);
     const bool mixed = o_.score_method == MIPGEN_SCORE_MIXED && rs_;
     CandPtr picked = optimize_worst(pos, strand_to_use);
     if (mixed && picked) picked->score = rs_->svr(*picked);
@@ -415,7 +415,7 @@ void Selector::pick()
     if (!pos.empty()) {
         do {
             picked = translocate(pos, strand_to_use);
-            extended = *pos.rbegin() - *pos.begin() > o_.max_capture;
+            extended = pos.back() - pos.front() > o_.max_capture;
             if (!picked && extended) create_gap(out_.gaps, ".coverage_failed.bed", "GAP INTRODUCED ON CHROMOSOME ", pos);
             if (picked) manage_picked(picked, pos);
         } while (!pos.empty() && (picked || extended));
@@ -423,7 +423,7 @@ void Selector::pick()
     if (!minus.empty()) {
         do {
             picked = translocate(minus, 1);
-            extended = *minus.rbegin() - *minus.begin() > o_.max_capture;
+            extended = minus.back() - minus.front() > o_.max_capture;
             if (!picked && extended) create_gap(out_.minus_gaps, ".minus_strand_failed.bed", "GAP INTRODUCED ON MINUS STRAND OF CHROMOSOME ", minus);
             if (picked) manage_picked(picked, minus);
         } while (!minus.empty() && (picked || extended));
@@ -431,7 +431,7 @@ void Selector::pick()
     if (o_.double_tile) {
         do {
             picked = translocate(again, strand_to_use);
-            extended = !again.empty() && *again.rbegin() - *again.begin() > o_.max_capture;
+            extended = !again.empty() && again.back() - again.front() > o_.max_capture;
             if (!picked && extended) create_gap(out_.double_gaps, ".double_tile_failed.bed", "GAP INTRODUCED ON DOUBLE TILING OF CHROMOSOME ", again);
             if (picked) manage_picked(picked, again);
         } while (!again.empty() && (picked || extended));
@@ -439,7 +439,7 @@ void Selector::pick()
             // the reference walks positions_to_scan_again here but manages / terminates on positions_to_scan_minus_again (:1597-1607)
             do {
                 picked = translocate(again, 1);
-                extended = !again.empty() && *again.rbegin() - *again.begin() > o_.max_capture;
+                extended = !again.empty() && again.back() - again.front() > o_.max_capture;
                 if (!picked && extended && !minus_again.empty())
                     create_gap(out_.double_gaps, ".minus_strand_double_tile_failed.bed", "GAP INTRODUCED ON MINUS STRAND OF DOUBLE TILING OF CHROMOSOME ", minus_again);
                 if (picked) manage_picked(picked, minus_again);

@@ -1,7 +1,7 @@
 """GPU: BASELINE.json configs[2] at its FULL size - all 1,000 regions of 5,000 bp, capture 120-250 (27 sizes x 57 arm pairs x 2 strands at
 5.2 M scan starts = 1.6e10 dense candidates), the logistic scan of the mixed design - through the silent fused path
 (mipgen_accel_score_condense_all: score -> replay of the early exits -> condense, window by window).  At this size the dense results
-(272 GB) are produced window by window (automatic windows hold at most 2^31 candidates), so the result windows are exercised for real.  Checked through size-independent properties:
+(272 GB) are produced window by window (automatic windows hold at most 2^30 candidates), so the result windows are exercised for real.  Checked through size-independent properties:
 
   * the survivors do not depend on how the batch is cut into result windows, nor on how the regions are sharded over handles (= ranks);
   * structural invariants of every survivor (its candidate lies in the row block of its own scan position and strand, it is valid,
@@ -49,7 +49,7 @@ def test_full_config3_size_and_invariants(full5k):
     P, grids, surv, emitted, pos0 = (full5k[k] for k in ("P", "grids", "surv", "emitted", "pos0"))
     total = sum(g.count for g in grids)
     assert len(grids) == N_REGIONS and total > 1.5e10 and all(g.n_sizes == 27 for g in grids)
-    assert full5k["n_win_auto"] >= 2                       # automatic windows hold at most 2^31 candidates: 1.6e10 need eight
+    assert full5k["n_win_auto"] >= 2                       # automatic windows hold at most 2^30 candidates: 1.6e10 need fifteen
     assert surv.shape[0] == 2 * pos0[-1]
     A = P.n_arm_pairs
     rel = _relative(surv, grids, pos0)

@@ -7,7 +7,7 @@ chromosome FASTA files (300 Mb) and a BED with the first N of the 200,000 exon-l
 
 (no bwa: the arm copy numbers come from the GPU k-mer counter; a 1,024-SV synthetic model beside the executable).
 
-    python3 tools/cli_exome.py [N] [workdir]
+    python3 tools/cli_exome.py [N] [workdir] [exome|regions5k] [svr|logistic|mixed]
 """
 import os
 import shutil
@@ -40,6 +40,8 @@ def main() -> None:
         for c in chroms:
             synth.write_fasta(os.path.join(work, "genome", f"chr{c}.fa"), "chr" + c, workloads.exome_chromosome(c, chrom_len[c]))
         capture, method = ("150", "170"), "svr"
+    if len(sys.argv) > 4:
+        method = sys.argv[4]
     synth.write_bed(os.path.join(work, "exome.bed"), ivs)
     exe = os.path.join(work, "mipgen")
     os.symlink(os.path.join(ROOT, "mipgen_amd", "mipgen"), exe)
@@ -53,7 +55,7 @@ def main() -> None:
     p = subprocess.run(argv, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MIPGEN_TIMING="1"))
     dt = time.time() - t1
     print("rc", p.returncode, f"wall {dt:.1f} s")
-    print("".join(l + "\n" for l in p.stderr.decode().split("\n") if "timing" in l))
+    print("".join(l + "\n" for l in p.stderr.decode().split("\n") if "timing" in l or "[mipgen_accel]" in l))
     if p.returncode != 0:
         print(p.stderr.decode()[-2000:])
         raise SystemExit(1)
