@@ -338,6 +338,10 @@ int mipgen_accel_count_oligo_copies_resident(mipgen_accel* h, int32_t n_chrom, c
  * in a fixed order: results are deterministic for a given split).  0 = chosen per launch from the tile count (default), n >= 1 forces
  * n parts - e.g. to compare two differently sized batches bit for bit. */
 int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
+/* The dense logistic kernel gives a workgroup `n` consecutive runs of scan positions (it stages the bases once and slides its downstream-arm
+ * table from run to run).  0 = chosen from the batch size (1 for small batches, which need every workgroup they can get; 2 or 3 for large ones),
+ * 1..8 forced.  Results do not depend on it. */
+int mipgen_accel_set_logistic_subruns(mipgen_accel* h, int32_t n);
 
 /* ---- instrumentation ------------------------------------------------------------------------------ */
 /* HIP-event time (ms) of the kernels of the last scoring call (summed over its windows), measured on the handle's stream;

@@ -38,7 +38,7 @@ hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_p
                                          const int32_t* pos_region, const int32_t* pos_local, const double* scores,
                                          const uint64_t* records, const int32_t* copy, int64_t cand_base, uint8_t* emitted,
                                          mipgen_survivor* survivors, unsigned long long* emitted_per_region);
-size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn);
+size_t mipgen_logistic_dense_lds_bytes(int np_all, int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn);
 hipError_t mipgen_launch_logistic_dense(hipStream_t, int n_tiles, size_t lds_bytes, const DevParams*, const DevRegion*, const SvrTile*, const uint8_t*,
                                         const int32_t*, const uint8_t*, const HostConsts*, double*, uint64_t*);
 struct FmtRegion { int32_t chr_off, chr_len, label_off, label_len, feature_start, feature_stop; int64_t rb0; };
@@ -181,6 +181,7 @@ struct mipgen_accel {
     std::string svr_batch_error;     // same, for the resident batch (tile does not fit LDS)
     bool record_tiles_ready = false, logistic_tiles_ready = false, svr_tiles_ready = false;   // tile lists of the resident batch, laid out on first use
     int sv_split = 0;                // 0 = chosen per launch from the tile count; > 0 forced
+    int ld_subruns = 0;              // position sub-runs per tile of the dense logistic kernel: 0 = from the batch size; 1..8 forced
     int n_cu = 256;
     // batch
     int n_regions = 0;
@@ -562,6 +563,14 @@ int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates)
     return MIPGEN_OK;
 }
 
+int mipgen_accel_set_logistic_subruns(mipgen_accel* h, int32_t n)
+{
+    if (!h || n < 0 || n > 8) return fail(MIPGEN_E_INVALID, "bad arguments");
+    h->ld_subruns = n;
+    h->logistic_tiles_ready = false;                                   // laid out again on the next logistic call
+    return MIPGEN_OK;
+}
+
 int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split)
 {
     if (!h || n_split < 0 || n_split > 64) return fail(MIPGEN_E_INVALID, "n_split must be in [0, 64] (0 = automatic)");
@@ -873,16 +882,22 @@ static int build_logistic_tiles(mipgen_accel* h)        // k_logistic_dense: a r
             for (int c = 0; c < nkc; c++) kc_max = std::max(kc_max, (int)((int64_t)d.n_sizes * (c + 1) / nkc) - (int)((int64_t)d.n_sizes * c / nkc));
             const int ssr = (kc_max - 1) * D.inc + D.max_sum - D.min_sum + 1, ssmax = Cmax - D.min_sum;
             const int ssmin_all = Cmax - (d.n_sizes - 1) * D.inc - D.max_sum;
+            // the positions of a tile are worked off in `subs` sub-runs of np, the downstream-arm table sliding along (only np of its
+            // np + ssr - 1 window starts are new per sub-run) and the bases / prefix words staged once; small batches keep one sub-run per tile
+            // (they need every workgroup they can get)
+            const int subs = h->ld_subruns > 0 ? h->ld_subruns : (h->total_pos >= 1000000 ? 3 : (h->total_pos >= 25000 ? 2 : 1));   // measured: 24 x 5 kb best at 2, 8,192 exons at 3
             int np = (int)std::min<int64_t>({ld_np_cap, (int64_t)d.n_pos, 64});
             size_t b = 0;
             for (; np >= 1; np--) {
-                b = std::max(mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
-                             mipgen_logistic_dense_lds_bytes(np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
+                const int np_all = std::min(subs * np, d.n_pos);
+                b = std::max(mipgen_logistic_dense_lds_bytes(np_all, np, ssr, ssmax, Lmax, D.e_max - D.e_min + 1, D.l_max - D.l_min + 1),
+                             mipgen_logistic_dense_lds_bytes(np_all, np, ssr, ssmax, Lmax, D.l_max - D.l_min + 1, D.e_max - D.e_min + 1));
                 if (b <= 80 * 1024) break;                             // two 512-thread workgroups per compute unit: one builds tables while the other scores
             }
             if (np < 1 || ssmin_all < 1) { ld_ok = false; break; }
             ld_lds = std::max(ld_lds, b);
-            for (int p0 = 0; p0 < d.n_pos; p0 += np) { SvrTile t = {i, 0, p0, std::min(np, d.n_pos - p0), 0, d.n_sizes}; ldt.push_back(t); }   // both strands, all sizes
+            // the sub-run length travels in the tile's strand field (these tiles hold both strands)
+            for (int p0 = 0; p0 < d.n_pos; p0 += subs * np) { SvrTile t = {i, np, p0, std::min(subs * np, d.n_pos - p0), 0, d.n_sizes}; ldt.push_back(t); }
         }
         w.n_ld_tiles = (int)ldt.size() - w.ld_tile0;
     }

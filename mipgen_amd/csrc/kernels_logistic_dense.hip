@@ -23,13 +23,15 @@
 #define LD_THREADS 512
 #define LD_ARM_STRIDE 9              // doubles per arm-window entry: 8 values + one packed 64-bit word
 #define LD_INS_STRIDE 4              // fT, BPS, TGC, TA
+#define LD_MOVE 10                   // words per thread and piece when the downstream-arm table slides (45 starts x 12 lengths x 9 words = 4,860)
 
 // shared with the host (tile sizing)
-extern "C" size_t mipgen_logistic_dense_lds_bytes(int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn)
+extern "C" size_t mipgen_logistic_dense_lds_bytes(int np_all, int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn)
 {
-    // ssr: scan sizes of the widest run of the tile; ssmax: the largest scan size of the whole tile (its first run)
+    // np_all: positions of the tile (bases and prefix words are staged for all of them); np: positions of one sub-run (its tables);
+    // ssr: scan sizes of the widest size run of the tile; ssmax: the largest scan size of the whole tile (its first size run)
     const int nq = np + ssr - 1;
-    const int span = np + ssmax + 2 * Lmax + 2;
+    const int span = np_all + ssmax + 2 * Lmax + 2;
     size_t b = 0;
     b += (size_t)3 * (span + 1) * 8 + 48 * 8;                   // W0..W2 prefix words + scan scratch
     b += 102 * 8;                                                // log10 of the copy numbers 0..100 (101 = "more than 100")
@@ -89,11 +91,13 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     // The tile holds ALL capture sizes of its positions; they are worked off in runs of <= 9 (the tables of a run must fit the LDS budget),
     // largest sizes first.  The bases and their prefix words are staged once for the whole tile - the first run reaches furthest.
     const int n_runs = (tile.kc + 8) / 9;
-    const int np = tile.np;
+    // ... and the positions in sub-runs of np_sub (tile.strand carries it: these tiles hold both strands), which slide the downstream-arm table
+    // along the region: consecutive sub-runs share all but np_sub of its np_sub + ssr - 1 window starts
+    const int np_all = tile.np, np_sub = tile.strand;
     const int n_e = P->e_max - P->e_min + 1, n_l = P->l_max - P->l_min + 1, n_max = max(n_e, n_l);
     const int p_first = R.first_pos + tile.p0;
     const int lo = p_first - Lmax;                                     // chromosome coordinate of local base 0
-    const int span = np + (P->max_capture - (R.k0 + tile.ki0) * inc - P->min_sum) + 2 * Lmax + 2;
+    const int span = np_all + (P->max_capture - (R.k0 + tile.ki0) * inc - P->min_sum) + 2 * Lmax + 2;
 
     uint64_t* W0 = (uint64_t*)smem;
     uint64_t* W1 = W0 + (span + 1);
@@ -132,12 +136,11 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     const int rk0 = tile.ki0 + (int)((int64_t)tile.kc * run / n_runs), rkc = tile.ki0 + (int)((int64_t)tile.kc * (run + 1) / n_runs) - rk0;
     const int Cmax_t = P->max_capture - (R.k0 + rk0) * inc, Cmin_t = Cmax_t - (rkc - 1) * inc;
     const int ssmax = Cmax_t - P->min_sum, ssmin = Cmin_t - P->max_sum, ssr = ssmax - ssmin + 1;
-    const int nq = np + ssr - 1;
+    const int nq_cap = np_sub + ssr - 1;
     double* TU = tables;
-    double* TD = TU + (size_t)np * n_max * LD_ARM_STRIDE;
-    double* TT = TD + (size_t)nq * n_max * LD_ARM_STRIDE;
-    uint16_t* UM = (uint16_t*)(TT + (size_t)np * ssr * LD_INS_STRIDE);
-    if (run) __syncthreads();                                         // every wavefront is done with the previous run's tables
+    double* TD = TU + (size_t)np_sub * n_max * LD_ARM_STRIDE;
+    double* TT = TD + (size_t)nq_cap * n_max * LD_ARM_STRIDE;
+    uint16_t* UM = (uint16_t*)(TT + (size_t)np_sub * ssr * LD_INS_STRIDE);
 
     // Both strands of the tile, one after the other: the '+' and '-' rows of a (position, capture size) are neighbours in the result
     // arrays (912 bytes together), so writing them from the same compute unit a few microseconds apart lets L2 merge them into full lines
@@ -147,15 +150,35 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     // roles: the upstream arm of p is the extension arm on '+', the ligation arm on '-'; the downstream arm the other one
     const int up_min = minus ? +P->l_min : +P->e_min, dn_min = minus ? +P->e_min : +P->l_min;
     const int n_up = minus ? n_l : n_e, n_dn = minus ? n_e : n_l;
-    if (strand) __syncthreads();                                      // every wavefront is done with the '+' tables
+    for (int pb = 0; pb < np_all; pb += np_sub) {                     // sub-runs of positions pb .. pb + np - 1
+    const int np = min(np_sub, np_all - pb), nq = np + ssr - 1;
+    __syncthreads();                                                  // every wavefront is done with the previous tables
+    // ---- the downstream-arm table slides: the window starts the previous sub-run shares with this one move to the front ----
+    int wl_new = 0;                                                   // first downstream window start that has to be built
+    if (pb) {
+        wl_new = ssr - 1;                                             // the previous sub-run was a full one: its starts np_sub .. np_sub + ssr - 2 are this one's 0 .. ssr - 2
+        const int n_words = (ssr - 1) * n_dn * LD_ARM_STRIDE;         // 8-byte words to move (an entry is 9 of them)
+        const uint64_t* src = (const uint64_t*)TD + (size_t)np_sub * n_dn * LD_ARM_STRIDE;
+        uint64_t* dst = (uint64_t*)TD;
+        // dst < src.  Pieces of LD_MOVE * LD_THREADS words in ascending order: every piece is read into registers by all threads, one barrier,
+        // then written - a piece's writes land below everything the later pieces still have to read
+        for (int i0 = 0; i0 < n_words; i0 += LD_MOVE * LD_THREADS) {
+            uint64_t v[LD_MOVE];
+#pragma unroll
+            for (int j = 0; j < LD_MOVE; j++) { const int i = i0 + j * LD_THREADS + tid; v[j] = i < n_words ? src[i] : 0; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LD_MOVE; j++) { const int i = i0 + j * LD_THREADS + tid; if (i < n_words) dst[i] = v[j]; }
+        }
+    }
     // ---- arm-window entries ----------------------------------------------------------------------------------------------------------
     // entry w < nU: upstream window ending at position pl (start = Lmax + pl - len); else downstream window starting at q (= Lmax + ssmin + q)
-    const int nU = np * n_up, nD = nq * n_dn;
+    const int nU = np * n_up, nD = (nq - wl_new) * n_dn;
     for (int w = tid; w < nU + nD; w += LD_THREADS) {
         const bool up = w < nU;
         int wl, li, len, s;
-        if (up) { wl = w / n_up; li = w - wl * n_up; len = up_min + li; s = Lmax + wl - len; }
-        else { const int w2 = w - nU; wl = w2 / n_dn; li = w2 - wl * n_dn; len = dn_min + li; s = Lmax + ssmin + wl; }
+        if (up) { wl = w / n_up; li = w - wl * n_up; len = up_min + li; s = Lmax + pb + wl - len; }
+        else { const int w2 = w - nU; wl = w2 / n_dn; li = w2 - wl * n_dn; wl += wl_new; len = dn_min + li; s = Lmax + ssmin + pb + wl; }
         const bool lig_role = up ? minus : !minus;
         const uint64_t d0 = W0[s + len] - W0[s], d1 = W1[s + len] - W1[s], d2 = W2[s + len] - W2[s];
         const uint32_t nA = f16(d0, 0), nC = f16(d0, 1), nG = f16(d0, 2), nBad = f16(d0, 3), nOther = f16(d2, 1);
@@ -205,7 +228,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     LD_STAMP(1)
     // ---- insert-window entries (position pl, scan size ssmin + ssi) ------------------------------------------------------------------------
     for (int w = tid; w < np * ssr; w += LD_THREADS) {
-        const int pl = w / ssr, ssi = w - pl * ssr, ss = ssmin + ssi, bi = Lmax + pl;
+        const int pl = w / ssr, ssi = w - pl * ssr, ss = ssmin + ssi, bi = Lmax + pb + pl;
         double* t = TT + (size_t)w * LD_INS_STRIDE;
         if (ss <= 0) { t[0] = 0.0; t[1] = 0.0; t[2] = 0.0; t[3] = 0.0; continue; }
         const uint64_t t0 = W0[bi + ss] - W0[bi], t2 = W2[bi + ss] - W2[bi];
@@ -254,8 +277,8 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
         const uint32_t tu_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TU, td_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TD, tt_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TT;
         for (int row = wid; row < n_rows; row += NW) {
             const int pl = row / rkc, kci = row - pl * rkc;
-            const int C = Cmax_t - kci * inc, p = p_first + pl, ss = C - S;
-            const int64_t out = R.out_off + ((((int64_t)(tile.p0 + pl) * nK + (rk0 + kci)) * 2 + (minus ? 1 : 0)) * A) + a;
+            const int C = Cmax_t - kci * inc, p = p_first + pb + pl, ss = C - S;
+            const int64_t out = R.out_off + ((((int64_t)(tile.p0 + pb + pl) * nK + (rk0 + kci)) * 2 + (minus ? 1 : 0)) * A) + a;
             if (!have) continue;
             // bounds skips, mipgen.cpp:443-444
             const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) && ss > 0;
@@ -325,6 +348,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
         }
     }
     LD_STAMP(4)
+    }   // sub-run of positions
     }   // strand
     }   // run
 #ifdef MIPGEN_DIAG

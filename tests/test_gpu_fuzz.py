@@ -48,6 +48,7 @@ def test_random_configuration(cfg):
         acc = capi.Accel(P)
         if method == capi.SCORE_SVR:
             acc.load_model_file(mp)
+        acc.set_logistic_subruns(i % 5)                  # 0 = automatic (1 at this size); 1..4 position sub-runs per tile: the sliding-table paths
         rd = capi.build_region(genome, "1", start, start + length, P, bwa_mode="hashed" if i % 2 else "unique", label=f"f{i}",
                                lrc=np.full(44, 0.01 * (i + 1)))
         grids, scores, records = acc.score_regions([rd], method)

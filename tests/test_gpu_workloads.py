@@ -51,9 +51,17 @@ def test_regions5k_logistic_full_grid(g5k):
     P = capi.make_params(120, 250, score_method=capi.SCORE_LOGISTIC)
     rd = workloads.build_regions5k(None, g5k, ivs, P, with_lrc=False)[0]
     acc = capi.Accel(P)
+    acc.set_logistic_subruns(4)                          # as the large batches of this shape run: four position sub-runs per workgroup, sliding tables
     grids, scores, records = acc.score_regions([rd], capi.SCORE_LOGISTIC)
     g = grids[0]
     assert g.n_sizes == 27 and g.count > 15_000_000
+    for subs in (1, 3):                                  # the layout does not change a bit of the results
+        acc.set_logistic_subruns(subs)
+        acc.score_window(0, capi.SCORE_LOGISTIC)
+        s2, r2 = acc.download()
+        assert np.array_equal(r2, records) and np.array_equal(s2, scores, equal_nan=True), subs
+    acc.set_logistic_subruns(4)
+    acc.score_window(0, capi.SCORE_LOGISTIC)
     og, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_LOGISTIC, None)
     assert og.count == g.count
     bad = np.nonzero(records != or_)[0]
