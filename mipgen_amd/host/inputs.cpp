@@ -95,6 +95,36 @@ std::vector<Region> load_regions(const Options& o)
 static void upper(std::string& s) { for (char& c : s) c = (char)std::toupper((unsigned char)c); }
 
 // get_chr_fasta_sequence_from_genome_dir, mipgen.cpp:1180-1229
+// A FASTA file at once: sequence lines joined (memchr / append), one string per '>' record (a file without a header line is one record)
+static bool slurp_fasta(const std::string& path, std::vector<std::string>& records)
+{
+    FILE* fh = fopen(path.c_str(), "rb");
+    if (!fh) return false;
+    std::string buf;
+    if (fseek(fh, 0, SEEK_END) == 0) { const long sz = ftell(fh); if (sz > 0) buf.resize((size_t)sz); rewind(fh); }
+    size_t got = buf.empty() ? 0 : fread(&buf[0], 1, buf.size(), fh);
+    if (buf.empty()) { char tmp[1 << 16]; size_t k; while ((k = fread(tmp, 1, sizeof tmp, fh)) > 0) buf.append(tmp, k); got = buf.size(); }
+    fclose(fh);
+    buf.resize(got);
+    const size_t first = records.size();
+    const char* p = buf.data(); const char* end = p + buf.size();
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* stop = nl ? nl : end;
+        const char* next = nl ? nl + 1 : end;
+        while (stop > p && stop[-1] == '\r') stop--;
+        if (stop > p) {
+            if (*p == '>') records.emplace_back();
+            else {
+                if (records.size() == first) records.emplace_back();
+                records.back().append(p, (size_t)(stop - p));
+            }
+        }
+        p = next;
+    }
+    return true;
+}
+
 bool load_sequences_from_genome_dir(const Options& o, std::vector<Region>& regs)
 {
     std::string chr = "0", chr_seq;
@@ -104,22 +134,16 @@ bool load_sequences_from_genome_dir(const Options& o, std::vector<Region>& regs)
         if (chr != r.chr) {
             chr_seq.clear();
             chr = r.chr;
-            std::ifstream fh(dir + "/chr" + chr + ".fa");
-            if (!fh.is_open()) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; return false; }
-            std::string line;
-            while (std::getline(fh, line)) {
-                if (!line.empty() && line[0] == '>') continue;
-                while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-                upper(line);
-                chr_seq += line;
-            }
+            std::vector<std::string> recs;
+            if (!slurp_fasta(dir + "/chr" + chr + ".fa", recs)) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; return false; }
+            for (std::string& rec : recs) { upper(rec); if (chr_seq.empty()) chr_seq.swap(rec); else chr_seq += rec; }      // every sequence line of the file, as the reference joins them
         }
         const int cs = r.start_fl - o.max_capture < 1 ? 1 : r.start_fl - o.max_capture;
         const int ce = r.stop_fl + o.max_capture + 15 > (int)chr_seq.size() ? (int)chr_seq.size() : r.stop_fl + o.max_capture + 15;
         const int len = ce - cs + 1;
         r.seq = chr_seq.substr((size_t)(cs - 1), (size_t)std::max(len, 0));
         r.seq_start = cs; r.seq_stop = ce;
-        fa << ">" << r.chr << ':' << cs << "-" << ce << std::endl << r.seq << std::endl;
+        fa << ">" << r.chr << ':' << cs << "-" << ce << '\n' << r.seq << '\n';        // flushed when the file closes (200,000 regions: no write per line)
         if (o.score_method != MIPGEN_SCORE_LOGISTIC) {
             long s0 = (long)r.start_fl - o.max_capture - 1 - 1000;               // :1225 (the reference throws if this is negative)
             if (s0 < 0) s0 = 0;
@@ -392,32 +416,7 @@ void attach_tables(const Options& o, const Tables& t, Region& r)
 void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<std::string>& chroms)
 {
     chroms.clear();
-    auto read_fasta = [&](const std::string& path) {                  // whole file at once, lines joined by memchr / append
-        FILE* fh = fopen(path.c_str(), "rb");
-        if (!fh) return false;
-        std::string buf;
-        if (fseek(fh, 0, SEEK_END) == 0) { const long sz = ftell(fh); if (sz > 0) buf.resize((size_t)sz); rewind(fh); }
-        size_t got = buf.empty() ? 0 : fread(&buf[0], 1, buf.size(), fh);
-        if (buf.empty()) { char tmp[1 << 16]; size_t k; while ((k = fread(tmp, 1, sizeof tmp, fh)) > 0) buf.append(tmp, k); got = buf.size(); }
-        fclose(fh);
-        buf.resize(got);
-        const char* p = buf.data(); const char* end = p + buf.size();
-        while (p < end) {
-            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-            const char* stop = nl ? nl : end;
-            const char* next = nl ? nl + 1 : end;
-            while (stop > p && stop[-1] == '\r') stop--;
-            if (stop > p) {
-                if (*p == '>') chroms.emplace_back();
-                else {
-                    if (chroms.empty()) chroms.emplace_back();
-                    chroms.back().append(p, (size_t)(stop - p));
-                }
-            }
-            p = next;
-        }
-        return true;
-    };
+    auto read_fasta = [&](const std::string& path) { return slurp_fasta(path, chroms); };
     if (o.has("-genome_dir")) {
         const std::string dir = o.arg("-genome_dir");
         std::set<std::string> seen;
