@@ -407,6 +407,175 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// The same fold for designs with at most CR capture sizes (CR <= 8: exome-style ranges such as 150-170 step 5).  A position's rows fit one
+// batch, so the replay keeps them in registers - both strands' scores AND records - and the condense fold reads nothing again: three
+// dependent round trips to memory per position (position map, region, rows) instead of five.  The kernel is latency bound (a position is
+// 2 CR short rows), which is why this matters: 8,192 exons 10.4 -> see DESIGN.md.  The emitted lanes of a row are wave-uniform masks and
+// stay in scalar registers (no LDS).
+// ---------------------------------------------------------------------------------------------------------
+template <int CR>
+__global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
+    int total_pos, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions,
+    const int32_t* __restrict__ pos_region, const int32_t* __restrict__ pos_local, const double* __restrict__ scores,
+    const uint64_t* __restrict__ records, const int32_t* __restrict__ copy, int64_t cand_base, uint8_t* __restrict__ emitted,
+    mipgen_survivor* __restrict__ survivors, unsigned long long* __restrict__ emitted_per_region)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gp = blockIdx.x * REPLAY_WAVES + wave;
+    if (gp >= total_pos) return;
+    const int ri = pos_region[gp], pi = pos_local[gp];
+    const DevRegion& R = regions[ri];
+    const int A = P->n_pairs, nK = R.n_sizes;                               // nK <= CR (the launcher checks the parameter set)
+    const int64_t per_pos = (int64_t)nK * A * 2;
+    const int64_t base = R.out_off + (int64_t)pi * per_pos;
+    const double upper = P->upper, lower = P->lower;
+    const bool heuristic = P->score_method == MIPGEN_SCORE_LOGISTIC && P->logistic_heuristic;
+    const uint64_t lane_bit = 1ull << lane, below_me = lane_bit - 1;
+
+    const bool in = lane < A;
+    const int e = in ? P->arm_ext[lane] : 1, l = in ? P->arm_lig[lane] : 1, gend = in ? P->group_end[lane] : 0;
+    const uint64_t list_ends = __ballot(in && lane + 1 == gend);
+    const uint64_t min_lists = __ballot(in && e + l == P->min_sum);
+    const uint64_t ends_below = list_ends & below_me;
+    const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
+    const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;
+    const uint64_t seg_below = seg & below_me, seg_above = seg & ~below_me & ~lane_bit;
+
+    // ---- the position's rows: scores and records of both strands, one round trip ----
+    double bp[CR], bm[CR];
+    uint64_t rp[CR], rm[CR], em[CR];
+#pragma unroll
+    for (int q = 0; q < CR; q++) {
+        const bool on = in && q < nK;
+        const int64_t idx = base + ((int64_t)q * 2) * A + lane;
+        bp[q] = on ? scores[idx] : 0.0; bm[q] = on ? scores[idx + A] : 0.0;
+        rp[q] = on ? records[idx] : 0; rm[q] = on ? records[idx + A] : 0;
+        em[q] = 0;
+    }
+    // ---- replay, mipgen.cpp:426-497 (as k_replay_condense_narrow) ----
+    unsigned long long n_emitted = 0;
+    double pbs = 0.0;
+#pragma unroll
+    for (int q = 0; q < CR; q++) {
+        if (q >= nK) break;
+        uint64_t emit_all = 0;
+        if (!(pbs > upper)) {                                                // :430
+            const double plus = bp[q], minus = bm[q];
+            const bool valid = (MIPGEN_REC_FLAGS(rp[q]) & MIPGEN_FLAG_VALID) != 0;               // :443-444
+            const uint64_t vmask = __ballot(valid);
+            bool mine = valid;
+            if (heuristic && vmask) {
+                const uint64_t below = vmask & seg_below;
+                const int src = below ? top_bit(below) : lane;
+                const double pp = __shfl(plus, src, 64), pm = __shfl(minus, src, 64);
+                const int ip = below ? to_int_x86(pp) : 0, im = below ? to_int_x86(pm) : 0;
+                const bool cond = valid && plus < (double)ip && minus < (double)im;               // :494
+                const uint64_t cmask = __ballot(cond);
+                mine = valid && !(cmask & seg_below);
+            }
+            emit_all = __ballot(mine);
+            if (emit_all) {
+                const double pb = (minus > plus) ? minus : plus;             // :495
+                const bool last_of_list = mine && !(emit_all & seg_above);
+                if (!__ballot(last_of_list && pb > upper)) {
+                    pbs = readlane_d(pb, top_bit(emit_all));
+                } else {
+                    uint64_t ends = list_ends;
+                    int a0 = 0;
+                    while (ends) {
+                        const int a1 = __builtin_ctzll(ends) + 1;
+                        ends &= ends - 1;
+                        const uint64_t sg = (a1 >= 64 ? ~0ull : (1ull << a1) - 1) & ~((1ull << a0) - 1);
+                        if (pbs > upper && !((min_lists >> a0) & 1)) emit_all &= ~sg;              // :434
+                        else if (emit_all & sg) pbs = readlane_d(pb, top_bit(emit_all & sg));
+                        a0 = a1;
+                    }
+                }
+                n_emitted += 2ull * (unsigned)__builtin_popcountll(emit_all);
+                if (emitted && (emit_all & lane_bit)) {
+                    const int64_t idx = base + ((int64_t)q * 2) * A + lane;
+                    emitted[idx] = 1; emitted[idx + A] = 1;
+                }
+            }
+        }
+        em[q] = emit_all;
+    }
+    if (n_emitted && lane == 0) atomicAdd(&emitted_per_region[ri], n_emitted);
+
+    // ---- condense, mipgen.cpp:1670-1746, from the registers ----
+    const int target_copy = P->target_arm_copy;
+    const int64_t max_product = P->max_arm_copy_product;
+    const double thr = P->masked_arm_threshold;
+    const double arm_sum = (double)(l + e);
+    int chosen_copy = 0;
+    double chosen_masked = 0.0;
+    for (int s = 0; s < 2; s++) {
+        int64_t best_idx = -1;
+        double best_score = 0.0;
+        uint64_t best_rec = 0;
+        int best_snp = 0;
+        bool stop = false;
+#pragma unroll
+        for (int q = CR - 1; q >= 0; q--) {                                  // newest first (push_front, :475,489)
+            if (stop || !em[q]) continue;
+            const int ki = q;
+            const bool mine = (em[q] & lane_bit) != 0;
+            const uint64_t r = s ? rm[q] : rp[q];
+            const double sc = s ? bm[q] : bp[q];
+            int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+            const bool saturated = mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0;
+            if (__ballot(saturated) && saturated) {
+                const int C = P->max_capture - (R.k0 + ki) * P->inc, p = R.first_pos + pi, ss = C - e - l;
+                const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
+                const int se = P->len_slot[e], sl = P->len_slot[l];
+                const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
+                ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
+                lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
+            }
+            const bool ok = mine && !((int64_t)ext_copy * lig_copy > max_product) && !(MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING);   // :1689-1690
+            const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
+            const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / arm_sum;
+            const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
+            uint64_t pending = __ballot(ok);
+            while (pending) {
+                const bool rA = best_idx < 0;                                                                     // :1695
+                const bool rB = (cur_masked > thr) & (cur_masked < chosen_masked);                                // :1701
+                const bool rC = (cur_copy > target_copy) & (cur_copy < chosen_copy);                              // :1709
+                const bool rD = cur_copy <= target_copy;
+                const bool above = sc > best_score;
+                const bool rE = (sc < lower) & above;                                                             // :1717
+                const bool hi_sc = sc > lower;
+                const bool rF = snp < best_snp;                                                                   // :1725
+                const bool rG = (snp == best_snp) & above;                                                        // :1731-1737
+                const bool early = rA | rB | rC;
+                const bool last_rule = !early & rD & !rE & hi_sc & !rF & rG;
+                const bool take = early | (rD & (rE | (hi_sc & (rF | rG))));
+                const bool update_chosen = !last_rule, stops = last_rule & (sc > upper);
+                const uint64_t tmask = __ballot(take) & pending;
+                if (!tmask) break;
+                const int f = top_bit(tmask);
+                best_idx = base + ((int64_t)ki * 2 + s) * A + f;
+                best_score = readlane_d(sc, f);
+                best_rec = readlane_u64(r, f);
+                best_snp = (int)MIPGEN_REC_SNP_COUNT(best_rec);
+                if (__builtin_amdgcn_readlane((int)update_chosen, f)) {
+                    chosen_masked = readlane_d(cur_masked, f);
+                    chosen_copy = __builtin_amdgcn_readlane(cur_copy, f);
+                }
+                if (__builtin_amdgcn_readlane((int)stops, f)) { stop = true; break; }
+                pending &= (1ull << f) - 1;
+            }
+        }
+        if (lane == 0) {
+            mipgen_survivor out;
+            out.cand_index = best_idx < 0 ? -1 : best_idx + cand_base; out.score = best_score; out.record = best_rec;
+            survivors[2 * (int64_t)gp + s] = out;
+        }
+    }
+}
+
 extern "C" hipError_t mipgen_launch_replay_condense(
     hipStream_t stream, int n_regions, int total_pos, const DevParams* P, int n_pairs, int n_sizes_max, const DevRegion* regions,
     const int32_t* pos_region, const int32_t* pos_local, const double* scores, const uint64_t* records, const int32_t* copy, int64_t cand_base,
@@ -418,7 +587,16 @@ extern "C" hipError_t mipgen_launch_replay_condense(
     const int pitch = n_sizes_max * n_chunks;
     const size_t lds = (size_t)REPLAY_WAVES * pitch * sizeof(uint64_t);
     const dim3 grid((total_pos + REPLAY_WAVES - 1) / REPLAY_WAVES), block(REPLAY_WAVES * 64);
-    if (n_chunks == 1)
+    if (n_chunks == 1 && n_sizes_max <= 3)
+        hipLaunchKernelGGL(k_replay_condense_carry<3>, grid, block, 0, stream, total_pos, P, regions, pos_region, pos_local, scores, records, copy, cand_base, emitted,
+                           survivors, emitted_per_region);
+    else if (n_chunks == 1 && n_sizes_max <= 5)
+        hipLaunchKernelGGL(k_replay_condense_carry<5>, grid, block, 0, stream, total_pos, P, regions, pos_region, pos_local, scores, records, copy, cand_base, emitted,
+                           survivors, emitted_per_region);
+    else if (n_chunks == 1 && n_sizes_max <= 8)
+        hipLaunchKernelGGL(k_replay_condense_carry<8>, grid, block, 0, stream, total_pos, P, regions, pos_region, pos_local, scores, records, copy, cand_base, emitted,
+                           survivors, emitted_per_region);
+    else if (n_chunks == 1)
         hipLaunchKernelGGL(k_replay_condense_narrow, grid, block, lds, stream, total_pos, pitch, P, regions, pos_region, pos_local, scores, records, copy,
                            cand_base, emitted, survivors, emitted_per_region);
     else
