@@ -321,6 +321,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
     const int target_copy = P->target_arm_copy;
     const int64_t max_product = P->max_arm_copy_product;
     const double thr = P->masked_arm_threshold;
+    const bool masked_any_counts = thr < 0.0;                                        // then even an arm without masked bases is "above the threshold" (:1701)
     const double arm_sum = (double)(l + e);
     int chosen_copy = 0;
     double chosen_masked = 0.0;                                                      // per position, not per strand (:1677-1680)
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
                 const uint64_t r = br[q];
                 const double sc = bs[q];
                 int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+                // Quick reject, exact: once a candidate is held (:1695 no longer applies) every other rule needs a higher score (:1717,1731),
+                // fewer SNPs (:1725), a copy number above the target (:1709) or masked bases (:1701) - most rows have none of these
+                if (best_idx >= 0 && !__ballot(mine && (sc > best_score || ext_copy > target_copy || lig_copy > target_copy || masked_any_counts ||
+                                                        MIPGEN_REC_MASKED_N(r) != 0 || (int)MIPGEN_REC_SNP_COUNT(r) < best_snp))) continue;
                 const bool saturated = mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0;
                 if (__ballot(saturated) && saturated) {                    // (the uniform test first: no exec-mask bookkeeping in the common case)
                     // the record's 16-bit fields saturate; the reference compares bwa's unbounded X0 counts (mipgen.cpp:586-587,1692,1709):
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
     const int target_copy = P->target_arm_copy;
     const int64_t max_product = P->max_arm_copy_product;
     const double thr = P->masked_arm_threshold;
+    const bool masked_any_counts = thr < 0.0;                                        // then even an arm without masked bases is "above the threshold" (:1701)
     const double arm_sum = (double)(l + e);
     int chosen_copy = 0;
     double chosen_masked = 0.0;
@@ -525,6 +531,9 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
             const uint64_t r = s ? rm[q] : rp[q];
             const double sc = s ? bm[q] : bp[q];
             int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
+            // quick reject, exact (see k_replay_condense_narrow)
+            if (best_idx >= 0 && !__ballot(mine && (sc > best_score || ext_copy > target_copy || lig_copy > target_copy || masked_any_counts ||
+                                                    MIPGEN_REC_MASKED_N(r) != 0 || (int)MIPGEN_REC_SNP_COUNT(r) < best_snp))) continue;
             const bool saturated = mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0;
             if (__ballot(saturated) && saturated) {
                 const int C = P->max_capture - (R.k0 + ki) * P->inc, p = R.first_pos + pi, ss = C - e - l;
