@@ -15,11 +15,18 @@ Workloads (mipgen_amd/workloads.py; no real genome / BED / trained model exists 
                         with the logistic score) or --method svr
   exome / exome_snp     configs[3] / [4] shape: --regions R of the 200,000 exon-like intervals, capture 150-170 / 120-250, SVR
 
+N = 1 (default): practice62 / SVR (configs[1], the config the 1-GPU metric is quoted on); `extra` carries a line for the metric's own
+multi-GPU config (exome200k, configs[3]) on this one GPU, a sustained (>= 2 s) run of the headline, the nSV sweep, the logistic scorer, the
+mixed-mode list re-scorer and the k-mer counter.  Before anything is timed an in-run PARITY GATE scores regions of the bench batch and
+compares records / scores / replay / condensed survivors with the oracle (the checker only: nothing the oracle computes is timed or reported
+as a rate) - SURVEY.md section 8d "correctness gate run with every measurement".
+
 N > 1: one process per GPU (`--gpus N` without a launcher starts `torch.distributed.run` itself, before anything touches a GPU).
 The BED is sharded over the ranks by dense-grid size (contiguous region ranges, no data-path collective while scoring); every step ends
 with ONE gather of the condensed survivors to rank 0 (RCCL over xGMI), where the sequential pick stage consumes them.
-  --scaling weak (default)   the BED grows with N: N practice62-sized instances (one per rank's worth of regions)
-  --scaling strong           one fixed BED (--regions) cut N ways
+  --scaling strong (default for N > 1)   ONE fixed BED cut N ways: by default --config exome (configs[3], the metric's multi-GPU config),
+                                         the first 65,536 of its 200,000 exons (--regions 200000 for all of them: ~20 s per pass per GPU-share)
+  --scaling weak (default for N = 1)     the BED grows with N: N practice62-sized instances / N x --regions
 
 Prints ONE JSON line on rank 0.
 """
@@ -57,10 +64,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="practice62")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: practice62 at N = 1, exome at N > 1")
     ap.add_argument("--regions", type=int, default=0, help="regions of the workload to use (0 = the config's default)")
     ap.add_argument("--method", choices=["svr", "logistic"], default=None)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak at N = 1, strong (one BED cut N ways) at N > 1")
     ap.add_argument("--nsv", type=int, default=1024)
     ap.add_argument("--min-capture", type=int, default=0)
     ap.add_argument("--max-capture", type=int, default=0)
@@ -68,8 +75,19 @@ def parse_args():
     ap.add_argument("--sv-split", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the nSV sweep and the logistic line")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the multi-core CPU baseline (0 = all host cores, at most 32)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the multi-core CPU baseline (0 = all physical host cores)")
+    ap.add_argument("--exome-regions", type=int, default=200000, help="exons of the exome200k line in `extra` (N = 1 default run; 0 = skip)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained run of the headline in `extra` (0 = skip)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the in-run oracle check (profiling runs)")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
+    if a.config is None:
+        a.config = "practice62" if world == 1 else "exome"
+    if a.scaling is None:
+        a.scaling = "weak" if world == 1 else "strong"
+    if not a.regions and a.config == "exome" and world > 1 and a.scaling == "strong":
+        a.regions = 65536
+    return a
 
 
 def self_launch(args) -> None:
@@ -166,15 +184,121 @@ def table_entries_min(P, grids) -> int:
     return total
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# in-run parity gate ("correctness gate run with every measurement"; reference semantics mipgen.cpp:426-497)
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def parity_gate(acc, P, regions, grids, method: str, model_path, device: int, stream: int, sample: int = 1500) -> dict:
+    """Checks the bench batch against the oracle BEFORE anything is timed (the oracle is the checker here, nothing it computes is timed):
+      (1) the smallest region of the batch scored alone: every integer record bit-exact, every score within 1e-5 (NaN / guard values exact),
+          the replayed emitted mask, the emitted count and the condensed survivors identical to the oracle's replay + fold fed with the
+          device's scores (mipgen.cpp:426-497, 1670-1746);
+      (2) the batch's own survivors of that region (scored inside the full batch by score_condense_all) equal the ones of (1);
+      (3) a random sample of candidates of the LARGEST region (all its capture sizes): records bit-exact, scores within 1e-5 of the
+          oracle's per-candidate arithmetic (SVMipv4.cpp:60-248, svm.cpp:2504-2593).
+    Raises AssertionError on any difference."""
+    import ctypes
+    import numpy as np
+    from mipgen_amd import capi
+    from oracle import pyoracle as po                     # checker only
+    t_start = time.perf_counter()
+    m = capi.SCORE_SVR if method == "svr" else capi.SCORE_LOGISTIC
+    om = po.Model(model_path) if model_path else None
+    nz = [i for i, g in enumerate(grids) if g.count > 0]
+    i_small, i_big = min(nz, key=lambda i: grids[i].count), max(nz, key=lambda i: grids[i].count)
+    acc.score_condense_all(m)
+    emitted_b, surv_b = acc.download_survivors()
+    chk = capi.Accel(P, device=device, stream=stream)
+    if model_path:
+        chk.load_model_file(model_path)
+
+    def close(a, b):
+        both_nan = np.isnan(a) & np.isnan(b)
+        return bool(np.all(both_nan | (np.abs(a - b) <= 1e-5)))
+
+    # (1) smallest region alone
+    rd, g = regions[i_small], grids[i_small]
+    _, s, r = chk.score_regions([rd], m)
+    chk.replay_condense()
+    em, sv, mask = chk.download_replay()
+    _, os_, or_ = po.score_region_dense(P, rd, m, om)
+    assert np.array_equal(r, or_), "parity gate: integer records differ from the oracle"
+    assert close(s, os_), f"parity gate: scores differ from the oracle (max {np.nanmax(np.abs(s - os_))})"
+    max_err = float(np.nanmax(np.abs(s - os_))) if s.size else 0.0
+    n_emit, omask = po.replay_region(P, rd, s, r)
+    assert int(em[0]) == n_emit and np.array_equal(mask, omask), "parity gate: replayed enumeration differs from the oracle"
+    osurv = po.condense_region(P, rd, s, r, omask)
+    assert np.array_equal(sv["cand_index"], osurv["cand_index"]) and np.array_equal(sv["record"], osurv["record"]) \
+        and np.array_equal(sv["score"], osurv["score"], equal_nan=True), "parity gate: condensed survivors differ from the oracle"
+    # (2) the same region inside the bench batch
+    pos0 = sum(gg.n_pos for gg in grids[:i_small])
+    got = surv_b[2 * pos0:2 * (pos0 + g.n_pos)]
+    exp_idx = np.where(osurv["cand_index"] >= 0, osurv["cand_index"] + g.offset, -1)
+    assert int(emitted_b[i_small]) == n_emit, "parity gate: emitted count of the batch differs"
+    assert np.array_equal(got["cand_index"], exp_idx) and np.array_equal(got["record"], osurv["record"]) and close(got["score"], osurv["score"]), \
+        "parity gate: the batch's survivors differ from the region scored alone"
+    # (3) sample of the largest region
+    rd, g = regions[i_big], grids[i_big]
+    _, s, r = chk.score_regions([rd], m)
+    rng = np.random.default_rng(20140101)
+    pick = rng.choice(g.count, size=min(sample, g.count), replace=False)
+    A = P.n_arm_pairs
+    lrc = np.array([rd.c.long_range_content[i] for i in range(capi.N_LRC)])
+    n_checked = 0
+    for idx in pick:
+        a = int(idx % A); row = int(idx // A); strand = row & 1; rest = row >> 1
+        ki, pi = rest % g.n_sizes, rest // g.n_sizes
+        cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
+        skipped, d = po.design(P, rd, cand)
+        flags = int(capi.rec_flags(r[idx:idx + 1])[0])
+        if skipped:
+            assert not (flags & capi.FLAG_VALID), "parity gate: a bounds-skipped candidate is marked valid"
+            continue
+        osc, _, oints = po.score_designed(d, m, lrc, om)
+        orec = int(po.oracle().mo_record_of(ctypes.byref(d), 1, ctypes.byref(oints)))
+        assert int(r[idx]) == orec, f"parity gate: integer record of candidate {idx} differs ({int(r[idx]):#x} vs {orec:#x})"
+        assert (np.isnan(osc) and np.isnan(s[idx])) or abs(s[idx] - osc) <= 1e-5, f"parity gate: score of candidate {idx} differs ({s[idx]} vs {osc})"
+        max_err = max(max_err, 0.0 if np.isnan(osc) else abs(float(s[idx]) - osc))
+        n_checked += 1
+    chk.close()
+    return {"parity_checked": True, "oracle": "oracle/_build/libmipgen_oracle.so (C restatement, pinned to the compiled reference: tests/test_oracle_golden.py)",
+            "full_region": {"index": i_small, "dense_candidates": int(grids[i_small].count), "emitted": n_emit,
+                            "checked": "records bit-exact, scores <= 1e-5, emitted mask, condensed survivors (alone and inside the bench batch)"},
+            "sampled_region": {"index": i_big, "dense_candidates": int(grids[i_big].count), "capture_sizes": int(grids[i_big].n_sizes), "candidates_checked": n_checked},
+            "max_abs_score_error": max_err, "seconds": time.perf_counter() - t_start}
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the real reference binary on this box's host cores
 # ---------------------------------------------------------------------------------------------------------------------------
 
+def physical_cores() -> int:
+    """Physical cores this process may run on (distinct (package, core) pairs of the affinity mask; SMT siblings count once)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            pkg = open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read().strip()
+            core = open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id").read().strip()
+            seen.add((pkg, core))
+        except OSError:
+            seen.add(("?", c))
+    return max(1, len(seen))
+
+
 def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
-    """The reference CPU path (oracle/_ref/mipgen_ref, the real reference compiled -O2 from /root/reference by oracle/Makefile) timed on
-    this box: one process alone, then C processes at once (the reference is single-threaded and not re-entrant: multi-core = independent
-    processes on BED shards).  Bounded sample of the practice62 / capture 140-180 / SVR workload: regions of
-    ~115-130 bp, where 2-3 capture sizes survive the static skip (~10-20 s of single-core work each)."""
+    """The reference CPU path (oracle/_ref: the real reference compiled from /root/reference by oracle/Makefile) timed on this box's host
+    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (regions of ~110-130 bp: 2-4 capture sizes survive the
+    static skip).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
+      leg A  one process per sample region, -O2, all_mips written: the emitted-candidate count of every sample region and the single-process
+             rate; beside them ONE process of the binary AS SHIPPED (/root/reference/makefile:3-4: no -O flag) on the shortest region;
+      leg B  C = all physical cores processes at once, -O2, -silent_mode on (no all_mips text): `value` = sum over the processes of
+             (emitted candidates of its region / its tile_regions time), every process timed while all the others run.  tile_regions time =
+             from the reference's own "[mipgen] bwa copy number analysis finished" line (mipgen.cpp:349) to exit: enumeration + scoring +
+             selection, WITHOUT the input stage and the FASTQ / stand-in bwa (awk) I/O, which the GPU figure does not cover either."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
@@ -186,7 +310,8 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
         cores_avail = len(os.sched_getaffinity(0))
     except AttributeError:
         cores_avail = os.cpu_count() or 1
-    cores = args.cpu_cores or min(cores_avail, 32)
+    phys = physical_cores()
+    cores = args.cpu_cores or phys
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -196,38 +321,57 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
     except OSError:
         pass
     pool = sorted(ivs, key=lambda v: abs((v.bed_end - v.bed_start) - 122))[:8]
-    work = tempfile.mkdtemp(prefix="mipgen_cpu_")
+    shortest = min(range(len(pool)), key=lambda i: pool[i].bed_end - pool[i].bed_start)
+    work = tempfile.mkdtemp(prefix="mipgen_cpu_")          # not /dev/shm: it is mounted noexec on the GPU boxes (the binary is copied beside its model)
 
-    def run_one(i: int):
+    def run_one(tag: str, i: int, o0: bool = False, silent: bool = False):
         iv = pool[i % len(pool)]
-        w = os.path.join(work, f"p{i}")
+        w = os.path.join(work, tag)
         os.makedirs(os.path.join(w, "genome"))
         synth.write_fasta(os.path.join(w, "genome", f"chr{iv.chrom}.fa"), f"chr{iv.chrom}", genome)
         synth.write_bed(os.path.join(w, "one.bed"), [iv])
         r = rr.run_reference(w, os.path.join(w, "genome"), os.path.join(w, "one.bed"), "cpu", 140, 180, score_method="svr", model_path=model_path,
-                             bwa_mode="unique", silent=False, timeout=900)
-        if r["returncode"] != 0:
+                             bwa_mode="unique", silent=silent, o0=o0, timeout=900, hot_marker=True)
+        if r["returncode"] != 0 or r["hot_seconds"] is None:
             raise RuntimeError(r["stderr"][-500:])
-        with open(r["all_mips"], "rb") as fh:
-            n = fh.read().count(b"\n") - 1
+        n = None
+        if not silent:
+            with open(r["all_mips"], "rb") as fh:
+                n = fh.read().count(b"\n") - 1
         shutil.rmtree(w, ignore_errors=True)
-        return n, r["seconds"], iv.bed_end - iv.bed_start
+        return {"n": n, "seconds": r["seconds"], "hot": r["hot_seconds"], "len": iv.bed_end - iv.bed_start}
 
     try:
         if rr.have_reference():
-            n1, t1, len1 = run_one(0)
+            have_o0 = rr.have_reference(o0=True)
+            with ThreadPoolExecutor(max_workers=len(pool) + 1) as ex:
+                fa = [ex.submit(run_one, f"a{i}", i) for i in range(len(pool))]
+                f0 = ex.submit(run_one, "o0", shortest, True) if have_o0 else None
+                A = [f.result() for f in fa]
+                O0 = f0.result() if f0 else None
+            counts = [a["n"] for a in A]
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=cores) as ex:
-                res = list(ex.map(run_one, range(cores)))
+                B = list(ex.map(lambda i: run_one(f"b{i}", i, False, True), range(cores)))
             wall = time.perf_counter() - t0
-            n_all = sum(r[0] for r in res)
-            return {"value": n_all / wall, "unit": "candidates/s", "cores": cores, "kind": "reference",
-                    "single_core_value": n1 / t1, "cpu_model": cpu_model, "host_cores_available": cores_avail,
-                    "scope": "reference binary end to end per region (enumeration + scoring + its FASTQ / stand-in bwa I/O and selection); "
-                             "the GPU figure covers the resident hot path only",
-                    "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2), one region each from the "
-                              f"{len(pool)} regions closest to 122 bp ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp; 2-4 capture sizes survive the static skip), "
-                              f"{n_all} emitted candidates in {wall:.1f} s wall; alone: {len1}-bp region, {n1} candidates in {t1:.1f} s"}
+            value = sum(counts[i % len(pool)] / B[i]["hot"] for i in range(cores))
+            n_all = sum(counts[i % len(pool)] for i in range(cores))
+            out = {"value": value, "unit": "candidates/s", "cores": cores, "kind": "reference",
+                   "single_core_value": A[shortest]["n"] / A[shortest]["hot"],
+                   "single_core_value_end_to_end": A[shortest]["n"] / A[shortest]["seconds"],
+                   "end_to_end_value": n_all / wall,
+                   "cpu_model": cpu_model, "host_threads_available": cores_avail, "physical_cores": phys,
+                   "scope": "reference binary, tile_regions only (enumeration + scoring + selection; from its 'bwa copy number analysis finished' line to exit), "
+                            "-O2, -silent_mode on in the multi-process leg; end_to_end_value includes its input stage and the stand-in bwa / FASTQ I/O",
+                   "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2, -silent_mode on), one region each from the "
+                             f"{len(pool)} regions closest to 122 bp ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp; 2-4 capture sizes survive the static skip), "
+                             f"{n_all} emitted candidates, tile_regions {min(b['hot'] for b in B):.1f}-{max(b['hot'] for b in B):.1f} s per process, {wall:.1f} s wall; "
+                             f"alone: {A[shortest]['len']}-bp region, {A[shortest]['n']} candidates, tile_regions {A[shortest]['hot']:.1f} s of {A[shortest]['seconds']:.1f} s"}
+            if O0:
+                out["as_shipped_O0"] = {"single_core_value": O0["n"] / O0["hot"], "single_core_value_end_to_end": O0["n"] / O0["seconds"],
+                                        "note": f"oracle/_ref/mipgen_ref_O0 = the reference's own flags (/root/reference/makefile:3-4: -g, no -O) on the {O0['len']}-bp region: "
+                                                f"{O0['n']} candidates, tile_regions {O0['hot']:.1f} s of {O0['seconds']:.1f} s; -O2 / -O0 = {O0['hot'] / A[shortest]['hot']:.2f}x"}
+            return out
         # port: the oracle's C restatement (same arithmetic as the reference, no text hop, -O2), one core
         from oracle import pyoracle as po
         P = capi.make_params(140, 180, score_method=capi.SCORE_SVR)
@@ -246,6 +390,47 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
 def newest_profile(pattern: str):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
+
+
+
+def exome_line(args, device: int, stream: int, model_path: str) -> dict:
+    """The metric's own multi-GPU config on ONE GPU (BASELINE configs[3]: exome200k, capture 150-170, SVR): one warm-up pass over the first result
+    window, then one timed pass over all of it through score_condense_all (records + k_svr_dense + replay / condense per result window)."""
+    import torch
+    from mipgen_amd import capi, workloads
+    P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
+    acc = capi.Accel(P, device=device, stream=stream)
+    acc.load_model_file(model_path)
+    t0 = time.perf_counter()
+    chrom_len, all_iv = workloads.exome_layout()
+    ivs = all_iv[:min(args.exome_regions, len(all_iv))]
+    regions = workloads.build_exome(acc, chrom_len, ivs, P, with_lrc=True)
+    grids = acc.upload(regions)
+    t_build = time.perf_counter() - t0
+    n_cand = acc.batch_candidates()
+    acc.set_timing(True)
+    acc.score_window(0, capi.SCORE_SVR)                       # warm-up: tile lists, result arrays, code objects
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    acc.score_condense_all(capi.SCORE_SVR)
+    torch.cuda.synchronize()
+    d1 = time.perf_counter() - t1
+    emitted, surv = acc.download_survivors()
+    n_sv = acc.model_info()[0]
+    ent = table_entries_min(P, grids)
+    flops = float(n_sv) * (3.0 * n_cand + 45.0 * ent)
+    line = {"what": f"exome200k (BASELINE configs[3]): the first {len(ivs)} of 200,000 exon-like intervals, capture 150-170, SVR n_sv={n_sv}, one timed pass on 1 GPU "
+                    f"({acc.window_count()} result windows; wall clock around score_condense_all)",
+            "value": n_cand / d1, "unit": "candidates/s", "seconds": d1, "dense_candidates": n_cand, "regions": len(regions),
+            "emitted_candidates": int(emitted.sum()), "survivors": int((surv["cand_index"] >= 0).sum()), "build_and_upload_seconds": t_build,
+            "roofline": {"bound": "fp64_valu", "achieved": flops / d1 / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / d1 / 1e12 / FP64_PEAK_TFLOPS,
+                         "kernel": "k_svr_dense (+ k_records, replay / condense: the whole pass is inside the clock)", "algorithmic_flops": flops,
+                         "table_entries_per_sv": ent,
+                         "hbm": {"achieved": ALG_BYTES_PER_CAND * n_cand / d1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ALG_BYTES_PER_CAND * n_cand / d1 / 1e9 / HBM_PEAK_GBS}}}
+    acc.close()
+    del regions
+    return line
 
 
 def main() -> None:
@@ -311,6 +496,10 @@ def main() -> None:
             pad[: n_surv * 24].copy_(send[: n_surv * 24])
             dist.gather(pad, recv, dst=0)
 
+    # correctness gate of this measurement: rank 0 checks its batch against the oracle before anything is timed
+    gate = None
+    if rank == 0 and not args.no_parity_gate:
+        gate = parity_gate(acc, P, regions, grids, method, model_path, local_rank, stream)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -390,6 +579,7 @@ def main() -> None:
                        "emitted_candidates_per_s_rank0": float(emitted.sum()) * args.steps / dt,
                        "survivors_gathered_per_step": survivors_gathered},
             "roofline": roof,
+            "parity_checked": bool(gate), "parity_gate": gate,
             "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},
         }
         if method == "svr":
@@ -401,13 +591,26 @@ def main() -> None:
                 c = json.load(open(ppath))["k_svr_dense"]
                 cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs
                 out["pmc_from_profile"] = {"file": os.path.relpath(ppath, ROOT), "measured_in_this_run": False,
-                                           "valu_instr_per_wave_pair": c["SQ_INSTS_VALU"] * 64.0 / (15541734.0 * 1024.0),
+                                           "valu_instr_per_wave_pair": c["SQ_INSTS_VALU"] * 64.0 / (float(n_cand) * float(n_sv)),
                                            "valu_issue_frac": c["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), "lds_busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)}
             except Exception:
                 pass
         # ---- extras (N = 1, default workload): throughput vs nSV, and the logistic scorer on the same batch -------------------------
         if not args.no_extras and not distributed and args.config == "practice62" and method == "svr":
             extra = []
+            if args.sustain_seconds > 0:
+                # the headline again, long enough for an outside observer (the driver's GPU-busy sampler) to see: same step, >= 2 s
+                reps = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    step()
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                extra.append({"what": f"sustained: the headline step {reps} times back to back", "value": n_cand * reps / d1, "unit": "candidates/s",
+                              "ms_per_step": d1 / reps * 1e3, "seconds": d1})
+            if args.exome_regions > 0:
+                extra.append(exome_line(args, local_rank, stream, model_path))
             for nsv in (256, 4096):
                 acc.load_model_file(workloads.svr_model_path(cache, model_genome, nsv, rho=MODEL_RHO))
                 acc.score_condense_all(capi.SCORE_SVR)
@@ -480,7 +683,10 @@ def main() -> None:
             acc.load_model_file(model_path)
         if not args.no_cpu_baseline and not distributed:
             mp = model_path or workloads.svr_model_path(cache, model_genome, args.nsv, rho=MODEL_RHO)
-            out["cpu_baseline"] = cpu_baseline(args, mp, args.nsv)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, mp, args.nsv)
+            except Exception as e:                          # the baseline leg must never take the measured line down with it
+                out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": 0, "kind": "reference", "sample": "failed", "error": repr(e)[:400]}
         print(json.dumps(out))
     acc.close()
     if distributed:

@@ -89,10 +89,18 @@ int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* c
 /*
  * tile_regions on the accelerator: one libmipgen_accel handle per device, regions sharded over the devices in contiguous ranges
  * balanced by dense-grid size, each device scoring / replaying / condensing its result windows on its own thread while the calling
- * thread consumes the windows in region order through mipgen_design_select_region.  n_devices <= 0: every visible HIP device
- * (or $MIPGEN_GPUS).  devices beyond the visible count wrap around (two handles on one GPU: a functional test of the sharding).
+ * thread consumes the windows in region order through mipgen_design_select_region.  n_devices <= 0: mipgen_design_set_devices / the
+ * command line's -gpus, else every visible HIP device.  Devices beyond the visible count wrap around (two handles on one GPU: a functional
+ * test of the sharding).  Non-silent designs receive their all_mips records as text formatted on the device, with any number of workers
+ * (records are numbered design-wide: each worker first counts what it emits, mipgen.cpp:474,488,792).
  */
 int mipgen_design_run(mipgen_design* d, int32_t n_devices);
+/* Front-end knobs (the library reads no environment variables): device workers of mipgen_design_run (0 = every visible device; option -gpus),
+ * cap on the candidates of one result window (0 = default policy; option -gpu_window_candidates; tests force several windows with it),
+ * stage timings on stderr (option -gpu_timing on). */
+int mipgen_design_set_devices(mipgen_design* d, int32_t n_devices);
+int mipgen_design_set_window_candidates(mipgen_design* d, int64_t max_candidates);
+int mipgen_design_set_timing(mipgen_design* d, int32_t on);
 
 /* The selection stage's private copy of glibc's never-seeded rand() stream (mipgen.cpp:1863 picks the first strand with rand() % 2):
  * its first n values, for checking it against the C library's. */

@@ -23,6 +23,7 @@ MAX_OLIGO = 64
 
 SCORE_LOGISTIC, SCORE_SVR, SCORE_MIXED = 0, 1, 2
 
+ABI_VERSION = 2          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
 FLAG_VALID, FLAG_GUARD, FLAG_MAPPING, FLAG_MASKING, FLAG_SNP, FLAG_HAS_SNP_MIP = 1, 2, 4, 8, 16, 32
 
 
@@ -84,7 +85,7 @@ def make_params(min_capture: int, max_capture: int, score_method: int = SCORE_LO
     """Defaults as mipgen::set_default_args / parse_arg_values (/root/reference/mipgen.cpp:164-188,209-216,243,264-265)."""
     from .synth import arm_pairs_from_sums
     p = Params()
-    p.abi_version = 1
+    p.abi_version = ABI_VERSION
     p.score_method = score_method
     p.min_capture_size, p.max_capture_size = min_capture, max_capture
     p.capture_increment = capture_increment if capture_increment != 0 else 1

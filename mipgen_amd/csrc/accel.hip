@@ -224,7 +224,7 @@ struct mipgen_accel {
     DevBuf<int64_t> region_pos0, region_base0;
     DevBuf<CollapseTile> col_tiles;
     DevBuf<int32_t> collapsed;
-    bool collapsed_valid = false;
+    std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
     int n_sv_pad = 0;
     double kmer_count_ms = -1.0;             // genome pass of the last mipgen_accel_count_oligo_copies
@@ -466,6 +466,14 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
         }
         r[SVR_COEF] = coef[i]; r[SVR_N_EXT] = ne; r[SVR_N_INS] = ni; r[SVR_N_LIG] = nl; r[SVR_N_JUNC] = nj;
         r[SVR_N_TOTAL] = tot; r[SVR_N_EXTRA] = 0.0;
+        // what one base adds to a block's 1-mer window sum: its 1-mer value, plus the GC-fraction value for C and G (mer order A, AA, .., C, ..:
+        // SVMipv4.cpp:69-70; the GC fraction sits before the "T" entry)
+        const int blk_base[3] = {F_EXT, F_INS, F_LIG}, blk_gc[3] = {F_EXT_GC, F_INS_GC, F_LIG_GC}, blk_step[3] = {5, 21, 5}, blk_thr[3] = {15, 63, 15};
+        for (int b = 0; b < 3; b++)
+            for (int c = 0; c < 4; c++) {
+                const int idx = blk_step[b] * c;
+                r[SVR_C1 + 4 * b + c] = x[blk_base[b] + idx + (idx >= blk_thr[b])] + ((c == BASE_C || c == BASE_G) ? x[blk_gc[b]] : 0.0);
+            }
         s_guard += coef[i] * exp(-gamma * tot);
     }
     if (h->model.reserve(rows.size())) return MIPGEN_E_NOMEM;
@@ -774,7 +782,7 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     HIP_TRY(hipStreamSynchronize(h->stream));             // host staging vectors die here
     DIAG_LAP("buffers + copies");
     h->n_regions = n; h->n_cand = cand_total; h->total_pos = pos_total;
-    h->scored = false; h->replayed = false; h->collapsed_valid = false; h->fmt_bytes = -1;
+    h->scored = false; h->replayed = false; h->win_state.assign(h->windows.size(), 0); h->fmt_bytes = -1;
     h->ev_used.assign(h->windows.size(), 0);
 #ifdef MIPGEN_DIAG
     fprintf(stderr, "[mipgen_accel] batch: %d regions, %lld candidates in %zu window(s)\n", n, (long long)cand_total, h->windows.size());
@@ -1057,6 +1065,7 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method)
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[2], h->stream)); h->ev_used[(size_t)w] |= 1; }
     h->cur_window = w; h->scored = true; h->replayed = false;
+    if ((size_t)w < h->win_state.size()) h->win_state[(size_t)w] = 0;          // its survivors / collapse results are of older scores now
     return MIPGEN_OK;
 }
 
@@ -1075,6 +1084,7 @@ static int replay_window_impl(mipgen_accel* h, bool want_mask)
     h->mask_valid = want_mask;
     if (h->timing && h->ev.size() >= 4 * ((size_t)w + 1)) { HIP_TRY(hipEventRecord(h->ev[4 * (size_t)w + 3], h->stream)); h->ev_used[(size_t)w] |= 2; }
     h->replayed = true;
+    if ((size_t)w < h->win_state.size()) h->win_state[(size_t)w] = 1;
     return MIPGEN_OK;
 }
 
@@ -1083,6 +1093,7 @@ static int collapse_window_impl(mipgen_accel* h)
     const Window& W = h->windows[(size_t)h->cur_window];
     HIP_TRY(mipgen_launch_collapse(h->stream, W.n_col_tiles, h->col_tiles.p + W.col_tile0, h->dp, h->regions.p, h->region_pos0.p, h->region_base0.p,
                                    h->survivors.p, h->copy.p, W.cand0, h->collapsed.p));
+    if ((size_t)h->cur_window < h->win_state.size()) h->win_state[(size_t)h->cur_window] |= 2;
     return MIPGEN_OK;
 }
 
@@ -1122,7 +1133,6 @@ int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
         if (int rc = replay_window_impl(h, false)) return rc;
         if (int rc = collapse_window_impl(h)) return rc;
     }
-    h->collapsed_valid = true;
     return MIPGEN_OK;
 }
 
@@ -1299,7 +1309,6 @@ int mipgen_accel_collapse(mipgen_accel* h)
     if (!h->replayed || h->cur_window < 0) return fail(MIPGEN_E_STATE, "collapse requested before replay + condense");
     HIP_TRY(hipSetDevice(h->device));
     if (int rc = collapse_window_impl(h)) return rc;
-    h->collapsed_valid = true;
     return MIPGEN_OK;
 }
 
@@ -1314,7 +1323,11 @@ int mipgen_accel_region_bases(const mipgen_accel* h, int32_t region, int64_t* fi
 int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* best_scan_index, int64_t capacity)
 {
     if (!h || !best_scan_index) return fail(MIPGEN_E_INVALID, "bad arguments");
-    if (!h->collapsed_valid) return fail(MIPGEN_E_STATE, "mipgen_accel_collapse / mipgen_accel_score_condense_all has not run on these survivors");
+    // validity is per result window: every window asked for must have been collapsed since it was last scored
+    for (size_t w = 0; w < h->win_state.size(); w++)
+        if ((window < 0 || (size_t)window == w) && !(h->win_state[w] & 2))
+            return fail(MIPGEN_E_STATE, "mipgen_accel_collapse / mipgen_accel_score_condense_all has not run on the current scores of window %zu", w);
+    if (h->win_state.empty()) return fail(MIPGEN_E_STATE, "no resident region batch");
     int64_t first = 0, count = h->h_region_base0.empty() ? 0 : h->h_region_base0.back();
     if (window >= 0) {
         if (window >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "window %d out of range", window);
@@ -1398,7 +1411,10 @@ int mipgen_accel_download_text(mipgen_accel* h, char* dst, int64_t capacity)
 int mipgen_accel_download_survivors(mipgen_accel* h, int64_t* emitted_per_region, mipgen_survivor* survivors, int64_t survivor_capacity)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
-    if (!h->replayed || h->cur_window != (int)h->windows.size() - 1) return fail(MIPGEN_E_STATE, "mipgen_accel_score_condense_all has not run on this batch");
+    // batch-wide survivors: every result window must have been replayed + condensed since it was last scored
+    if (h->win_state.empty()) return fail(MIPGEN_E_STATE, "mipgen_accel_score_condense_all has not run on this batch");
+    for (size_t w = 0; w < h->win_state.size(); w++)
+        if (!(h->win_state[w] & 1)) return fail(MIPGEN_E_STATE, "mipgen_accel_score_condense_all has not run on this batch (window %zu holds no current survivors)", w);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (emitted_per_region && h->n_regions)

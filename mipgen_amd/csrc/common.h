@@ -7,7 +7,7 @@
 //   unmap   : u8  [n_sizes_all][seq_len] per region (unmappable_positions slices), or absent
 //   regions : DevRegion[n]
 //   scores  : f64 [batch candidates]   records : u64 [batch candidates]     (dense-grid order, mipgen_accel.h)
-//   model   : f64 [n_sv][SV_ROW]  row = 192 SV values, coef, partial |sv|^2 per feature block
+//   model   : f64 [n_sv][SV_ROW]  row = 192 SV values, coef, partial |sv|^2 per feature block, 1-mer values with the GC slot folded in
 #pragma once
 #include <stdint.h>
 #include "../../include/mipgen_accel.h"
@@ -39,7 +39,7 @@
 #define F_LLC 191
 
 // model row
-#define SV_ROW 200
+#define SV_ROW 212
 #define SVR_COEF 192
 #define SVR_N_EXT 193    // sum sv_j^2, j in 0..20
 #define SVR_N_INS 194    // j in 66..150
@@ -48,6 +48,9 @@
 #define SVR_N_TOTAL 197  // all 192 + any libsvm index > 192
 #define SVR_N_EXTRA 198
 #define SVR_ZERO 199       // always 0.0: target of "no contribution" gathers  // libsvm indices > 192 (x has none: they contribute sv^2, svm.cpp:359-363)
+// 200..211: [feature block: ext, insert, lig][base A, C, G, T] = the SV's 1-mer value of that base + (C or G) its GC-fraction value:
+// what ONE base adds to the block's 1-mer window sum (the dense kernel's prefix scans gather one slot per base)
+#define SVR_C1 200
 
 struct DevRegion {
     int64_t out_off;       // first candidate in scores/records
@@ -144,8 +147,8 @@ struct SvrLayout {
     int n_ent;                                 // arm-window table entries per SV
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
-    int ins_sl, up_sl, dn_sl;                  // slots of one insert / upstream / downstream prefix array: len + 1 rounded up to 16 * 4k
-                                               // (a scan lane owns 4k consecutive slots; the padding gathers the always-zero SV slot)
+    int ins_sl, up_sl, dn_sl;                  // slots of one insert / upstream / downstream prefix array: len + 1 rounded up to 16 * (2k + 1)
+                                               // (a scan lane owns 2k + 1 consecutive slots; the padding gathers the always-zero SV slot)
 };
 
 // elements of prefix array k (without the trailing total slot): insert 1/2/3-mers, upstream 1/2-mers, downstream 1/2-mers
@@ -157,7 +160,8 @@ __attribute__((always_inline)) static inline int svr_arr_len(const SvrLayout& L,
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-__attribute__((always_inline)) static inline int svr_pad_slots(int len) { return ((len + 1 + 63) / 64) * 64; }
+__attribute__((always_inline)) static inline int svr_pad_slots(int len) { return (((len + 1 + 15) / 16) | 1) * 16; }   // 16 lanes x an ODD number of slots:
+                                                                    // the lanes of a scan row then write 16 distinct LDS bank pairs (lane stride = odd x 24 bytes)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -166,7 +170,7 @@ __attribute__((always_inline)) static inline int svr_arr_off(const SvrLayout& L,
     const int ki = k < 3 ? k : 3, ku = k < 3 ? 0 : (k < 5 ? k - 3 : 2), kd = k < 5 ? 0 : k - 5;
     return ki * L.ins_sl + ku * L.up_sl + kd * L.dn_sl;
 }
-// prefix-array slots per lane in that array's scan unit: one 16-lane DPP row per (array, SV); a multiple of 4
+// prefix-array slots per lane in that array's scan unit: one 16-lane DPP row per (array, SV); odd
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -186,7 +190,8 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.span_b = np + ssmax + 2 * Lmax + 1;
     L.rinv_len = (ssmax > Lmax ? ssmax : Lmax) + 2;
     int o = 0;
-    L.rinv = o; o += 4 * L.rinv_len;                    // records of {1/i, 1/(i-1), 1/(i-2), 0}: one ds_read_b128 (+ b64) per table entry
+    L.rinv = o; o += 3 * L.rinv_len;                    // records of {1/i, 1/(i-1), 1/(i-2)}: 24-byte pitch like every other table the table stage
+                                                        // reads with consecutive lengths in consecutive lanes (32 bytes was a 4-way bank conflict)
     L.lg10 = o; o += 102 + 44;                          // + the region's 44 long-range frequencies (read per SV by the constants unit)
     L.n_ent = np * n_up + L.nq * n_dn;
     L.rows = o; o += 2 * group * SV_ROW;
@@ -212,7 +217,7 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.bytes_ent = bytes; bytes += 2 * L.n_ent * 4;     // per entry: packed slots, packed fields
     L.bytes_psum = bytes; bytes += 2 * SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64) + 16;   // + the work counter of the table stage
     bytes = (bytes + 15) & ~15;
-    L.bytes_idx = bytes;                               // u32 per slot: byte offsets of the two SV-row slots it gathers
+    L.bytes_idx = bytes;                               // u32 per slot: byte offset of the SV-row slot it gathers
     bytes += 4 * (3 * L.ins_sl + 2 * L.up_sl + 2 * L.dn_sl);
     L.bytes_sb = bytes; bytes += L.span_b + 8;
     L.total_bytes = (bytes + 15) & ~15;

@@ -12,6 +12,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -60,6 +61,10 @@ struct mipgen_design {
     std::vector<std::string> genome;
     bool copies_deferred = false;
     std::mutex copies_mu;
+    // front-end knobs (mipgen_design_set_*; the command line's -gpus / -gpu_window_candidates / -gpu_timing extension options): no environment
+    int n_devices = 0;                           // device workers of mipgen_design_run (0 = every visible device)
+    int64_t window_candidates = 0;               // cap on the candidates of one result window (0 = the default policy)
+    bool timing = false;                         // stage timings on stderr
 };
 
 extern "C" {
@@ -67,10 +72,10 @@ extern "C" {
 const char* mipgen_host_last_error(void) { return g_err; }
 int mipgen_host_last_circumstance(void) { return g_circumstance; }
 
-// $MIPGEN_TIMING=1: wall-clock seconds of the front end's stages on stderr (diagnostics of the host side only; the accelerator library
-// reads no environment)
+// -gpu_timing on / mipgen_design_set_timing: wall-clock seconds of the front end's stages on stderr (neither library reads the environment)
 struct StageClock {
-    bool on = std::getenv("MIPGEN_TIMING") != nullptr;
+    bool on = false;
+    explicit StageClock(bool on_) : on(on_) {}
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void lap(const char* what)
     {
@@ -82,7 +87,9 @@ struct StageClock {
 
 int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
 {
-    StageClock clk;
+    bool timing_opt = false;
+    for (int i = 1; i + 1 < argc; i++) if (argv[i] && argv[i + 1] && std::string(argv[i]) == "-gpu_timing" && std::string(argv[i + 1]) == "on") timing_opt = true;
+    StageClock clk(timing_opt);
     if (!out_d || argc < 1 || !argv) return fail(MIPGEN_HOST_E_USAGE, 1, "null argument");
     *out_d = nullptr;
     g_err[0] = 0; g_circumstance = 0;
@@ -95,6 +102,9 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         if (!gpu_copies && std::system(o.arg("-bwa").c_str()) != 256) { std::cerr << "load bwa" << std::endl; throw 2; }            // mipgen.cpp:146-151
         if (o.arg("-trf") != "off" && std::system(o.arg("-trf").c_str()) != 65280) { std::cerr << "TRF directory invalid" << std::endl; throw 3; }
         finalize_options(o);
+        d->timing = o.arg("-gpu_timing") == "on";
+        d->n_devices = std::max(0, std::atoi(o.arg("-gpus").c_str()));
+        d->window_candidates = std::max<int64_t>(0, std::atoll(o.arg("-gpu_window_candidates").c_str()));
         d->model_path = o.file_dir + "mipgen_svr.model";                                                              // mipgen.cpp:409
         Outputs& out = d->out;
         out.progress.open(o.project_name + ".progress.txt");
@@ -250,7 +260,7 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
                         if (buf.size() > (1u << 20)) { out.all << buf; buf.clear(); }
                     }
             out.all << buf;
-        } else out.all_counter += (int)emitted;
+        } else out.all_counter += emitted;
         out.progress << "condensing feature #" << i + 1 << "\ncollapsing feature #" << i + 1 << '\n';
         std::vector<mipgen_survivor> rs(survivors, survivors + 2 * (size_t)grid->n_pos);
         for (auto& s : rs) if (s.cand_index >= 0) s.cand_index -= grid->offset;       // region-local for make_cand
@@ -269,6 +279,25 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
         return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
     }
     d->next_region = i + 1;
+    return 0;
+}
+
+int mipgen_design_set_devices(mipgen_design* d, int32_t n_devices)
+{
+    if (!d || n_devices < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad argument");
+    d->n_devices = n_devices;
+    return 0;
+}
+int mipgen_design_set_window_candidates(mipgen_design* d, int64_t max_candidates)
+{
+    if (!d || max_candidates < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad argument");
+    d->window_candidates = max_candidates;
+    return 0;
+}
+int mipgen_design_set_timing(mipgen_design* d, int32_t on)
+{
+    if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
+    d->timing = on != 0;
     return 0;
 }
 
@@ -305,11 +334,35 @@ struct WindowResult {
     std::string msg;
 };
 
+// all_mips records are numbered design-wide in generation order (mipgen.cpp:474,488,792): with several device workers a worker learns the
+// number of its first record from the emitted totals of the workers before it
+struct RecordOrder {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<int64_t> total;                  // records worker k emits (valid once done[k])
+    std::vector<char> done;
+    bool abort = false;
+    explicit RecordOrder(int n) : total((size_t)n, 0), done((size_t)n, 0) {}
+    void publish(int k, int64_t n) { std::lock_guard<std::mutex> lk(m); total[(size_t)k] = n; done[(size_t)k] = 1; cv.notify_all(); }
+    bool first_index(int k, int64_t* out)       // blocks until every worker before k has published; false when the run is aborting
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { if (abort) return true; for (int j = 0; j < k; j++) if (!done[(size_t)j]) return false; return true; });
+        if (abort) return false;
+        int64_t s = 0;
+        for (int j = 0; j < k; j++) s += total[(size_t)j];
+        *out = s;
+        return true;
+    }
+    void stop() { std::lock_guard<std::mutex> lk(m); abort = true; cv.notify_all(); }
+};
+
 struct Channel {                                 // worker -> consumer, at most two windows in flight per device
     std::mutex m;
     std::condition_variable cv;
     std::deque<std::unique_ptr<WindowResult>> q;
     bool abort = false;
+    bool aborted() { std::lock_guard<std::mutex> lk(m); return abort; }
     void push(std::unique_ptr<WindowResult> r)
     {
         std::unique_lock<std::mutex> lk(m);
@@ -345,17 +398,32 @@ struct SurvivorRescorer {                        // the SVR scores the worker co
     }
 };
 
-void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool device_text)
+void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel* ch, RecordOrder* order);
+
+void worker(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel* ch, RecordOrder* order)
 {
-    int64_t all_before = 0;                      // all_mip_counter at the start of the next window (device_text: this worker sees every window)
+    // nothing may leave a worker thread as an exception (std::terminate): a failed allocation of a multi-GB result vector ends the run
+    // through the channel like any accelerator error
+    try { worker_body(d, device, k_worker, r0, r1, ch, order); }
+    catch (std::exception& e) {
+        std::unique_ptr<WindowResult> r(new WindowResult());
+        r->error = 19; r->msg = std::string("device worker: ") + e.what(); r->last = true;
+        order->stop();
+        ch->push(std::move(r));
+    }
+}
+
+void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel* ch, RecordOrder* order)
+{
+    int64_t all_before = 0;                      // all_mip_counter at the start of the next window
     auto fail_out = [&](int code, const std::string& msg) {
         std::unique_ptr<WindowResult> r(new WindowResult());
         r->error = code; r->msg = msg; r->last = true;
+        order->stop();
         ch->push(std::move(r));
     };
     const Options& o = d->o;
-    // $MIPGEN_TIMING: seconds per stage of this worker
-    const bool timing = std::getenv("MIPGEN_TIMING") != nullptr;
+    const bool timing = d->timing;               // seconds per stage of this worker
     double t_stage[7] = {0, 0, 0, 0, 0, 0, 0};   // create + model, long-range content, upload, score + replay + collapse (+ downloads), text, mixed re-scores, copy numbers
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](int k) { const auto n_ = std::chrono::steady_clock::now(); t_stage[k] += std::chrono::duration<double>(n_ - t_prev).count(); t_prev = n_; };
@@ -400,13 +468,35 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
     for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)(r0 + i)], batch[(size_t)i], resident);
     std::vector<mipgen_grid> grids((size_t)n);
     // silent designs keep only survivors, so a window may fill the HBM; otherwise its dense results come to the host (17 B per candidate)
-    mipgen_accel_set_window_candidates(h, o.silent ? 0 : (int64_t)64 << 20);
-    if (const char* e = std::getenv("MIPGEN_WINDOW_CANDIDATES")) mipgen_accel_set_window_candidates(h, std::max<int64_t>(1, std::atoll(e)));   // tests force several windows
+    mipgen_accel_set_window_candidates(h, d->window_candidates > 0 ? d->window_candidates : (o.silent ? 0 : (int64_t)64 << 20));   // (tests force several windows)
     if (mipgen_accel_upload_regions(h, batch.data(), n, grids.data())) { bail(19); return; }
     lap(2);
     const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;               // mixed scans with logistic (:467)
     const int nw = mipgen_accel_window_count(h);
+    // Non-silent designs get their all_mips records as text from the device.  The records are numbered design-wide,
+    // so every worker first counts what it will emit (score + replay of its windows: the count depends on the scores), publishes the total
+    // and waits for the totals of the workers before it; a worker whose shard is one window keeps that window's results for the second pass.
+    const bool text = !o.silent;
+    bool first_window_ready = false;
+    if (text && order->total.size() > 1) {
+        int64_t mine = 0;
+        std::vector<int64_t> em;
+        for (int w = 0; w < nw; w++) {
+            if (ch->aborted()) { mipgen_accel_destroy(h); return; }
+            int32_t wr0 = 0, wn = 0;
+            mipgen_accel_window_info(h, w, &wr0, &wn, nullptr, nullptr, nullptr, nullptr);
+            if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
+            em.assign((size_t)wn, 0);
+            if (mipgen_accel_download_replay(h, em.data(), nullptr, 0, nullptr, 0)) { bail(19); return; }
+            for (int64_t e : em) mine += e;
+        }
+        first_window_ready = nw == 1;
+        order->publish(k_worker, mine);
+        if (!order->first_index(k_worker, &all_before)) { mipgen_accel_destroy(h); return; }
+        lap(3);
+    }
     for (int w = 0; w < nw; w++) {
+        if (ch->aborted()) { mipgen_accel_destroy(h); return; }       // the selection stage failed: do not score what nobody will consume
         int32_t wr0 = 0, wn = 0;
         int64_t c0 = 0, nc = 0, p0 = 0, np = 0;
         mipgen_accel_window_info(h, w, &wr0, &wn, &c0, &nc, &p0, &np);
@@ -415,7 +505,8 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
         for (auto& g : res->grids) g.offset -= c0;
         res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np));
-        if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h) || mipgen_accel_collapse(h)) { bail(19); return; }
+        if (!first_window_ready && (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h))) { bail(19); return; }
+        if (mipgen_accel_collapse(h)) { bail(19); return; }
         res->col_off.assign((size_t)wn + 1, 0);
         for (int bi = 0; bi < wn; bi++) {
             int64_t fe = 0; int32_t nb = 0;
@@ -424,7 +515,6 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
         }
         res->collapsed.resize((size_t)std::max<int64_t>(res->col_off[(size_t)wn], 1));
         if (mipgen_accel_download_collapsed(h, w, res->collapsed.data(), (int64_t)res->collapsed.size())) { bail(19); return; }
-        const bool text = !o.silent && device_text;
         if (!o.silent && !text) {
             res->scores.resize((size_t)nc); res->records.resize((size_t)nc); res->mask.resize((size_t)nc);
             if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
@@ -485,15 +575,35 @@ void worker(mipgen_design* d, int device, int r0, int r1, Channel* ch, bool devi
 
 }  // namespace
 
+// Relative device time of a region (the shard weights): the candidates of its dense grid - capture sizes after the static skip of
+// mipgen.cpp:429, positions of :421-425 - and, for the dense SVR scorer, the factor-table entries it builds per support vector, at the
+// kernel's instruction budget (~47 VALU per table entry against ~2.7 per candidate; mipgen_amd/csrc/accel.hip: build_svr_tiles).  Exons
+// with few capture sizes cost more per candidate than their dense-grid size says.  The same rule: mipgen_amd/dist.py: region_cost.
+static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_capture, int inc, int max_overlap, int n_pairs, int n_e, int n_l,
+                           int max_sum, int min_sum, bool svr)
+{
+    const int K_all = (max_capture - min_capture) / inc + 1;
+    int k0 = 0;
+    while (k0 < K_all) {
+        const int C = max_capture - k0 * inc;
+        if (C > stop_fl - start_fl + max_overlap && C - inc >= min_capture) k0++; else break;
+    }
+    const int64_t K = K_all - k0;
+    const int64_t n_pos = std::max(0, stop_fl - std::max(0, start_fl - max_capture + max_sum));
+    const int64_t cand = n_pos * K * n_pairs * 2;
+    if (!svr) return cand;
+    const int64_t ssr = (std::min<int64_t>(K, 9) - 1) * inc + max_sum - min_sum + 1;            // scan sizes of one run of <= 9 capture sizes
+    const int64_t runs = (K + 8) / 9;
+    const int64_t ent = 2 * runs * (n_pos * (n_e + n_l) + n_pos * ssr);                          // both strands
+    return (int64_t)(2.7 * (double)cand + 47.0 * (double)ent);
+}
+
 extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
 {
     if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
     const int visible = mipgen_accel_device_count();
     if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
-    if (n_devices <= 0) {
-        n_devices = visible;
-        if (const char* e = std::getenv("MIPGEN_GPUS")) n_devices = std::max(1, std::atoi(e));
-    }
+    if (n_devices <= 0) n_devices = d->n_devices > 0 ? d->n_devices : visible;
     const int n = (int)d->regions.size();
     n_devices = std::max(1, std::min(n_devices, n));
     // contiguous region ranges balanced by dense-grid size (the reference's region order is the order of the selection stage)
@@ -501,10 +611,12 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     int64_t total = 0;
     {
         const Options& o = d->o;
-        const int64_t A = (int64_t)o.arm_pairs.size(), K = (o.max_capture - o.min_capture) / o.capture_increment + 1;
+        std::set<int> es, ls;
+        for (auto& pr : o.arm_pairs) { es.insert(pr.first); ls.insert(pr.second); }
         for (int i = 0; i < n; i++) {
             const Region& r = d->regions[(size_t)i];
-            weight[(size_t)i] = (int64_t)(r.stop_fl - r.start_fl + o.max_capture) * K * A * 2;
+            weight[(size_t)i] = region_cost(r.start_fl, r.stop_fl, o.min_capture, o.max_capture, o.capture_increment, o.max_mip_overlap, (int)o.arm_pairs.size(),
+                                            (int)es.size(), (int)ls.size(), o.max_arm_sum, o.min_arm_sum, o.score_method == MIPGEN_SCORE_SVR);
             total += weight[(size_t)i];
         }
     }
@@ -523,12 +635,13 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     }
     std::vector<std::unique_ptr<Channel>> chans;
     std::vector<std::thread> threads;
+    RecordOrder order(n_devices);
     for (int k = 0; k < n_devices; k++) {
         chans.emplace_back(new Channel());
-        threads.emplace_back(worker, d, k % visible, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get(), n_devices == 1);
+        threads.emplace_back(worker, d, k % visible, k, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get(), &order);
     }
     int rc = 0;
-    StageClock clk;
+    StageClock clk(d->timing);
     double t_wait = 0.0, t_select = 0.0;
     for (int k = 0; k < n_devices && rc == 0; k++) {
         for (;;) {
@@ -561,6 +674,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     if (clk.on && d->selector) std::cerr << "[mipgen timing] selection stage: tables " << d->selector->stage_seconds[0] << " s, collapsed output " << d->selector->stage_seconds[1]
                                           << " s, pick " << d->selector->stage_seconds[2] << " s, clean-up " << d->selector->stage_seconds[3] << " s\n";
     for (auto& c : chans) c->stop();
+    if (rc) order.stop();
     if (rc) for (auto& c : chans) { std::lock_guard<std::mutex> lk(c->m); c->q.clear(); }
     for (auto& t : threads) t.join();
     return rc;

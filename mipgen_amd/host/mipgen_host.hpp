@@ -109,10 +109,11 @@ Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t 
 
 struct Outputs {
     std::ofstream all, collapsed, picked, snp, progress, gaps, double_gaps, minus_gaps, double_minus_gaps;
-    int all_counter = 0, collapsed_counter = 0, picked_counter = 0, bad_design_count = 0;
+    int64_t all_counter = 0, collapsed_counter = 0, picked_counter = 0;   // 64-bit: an exome design constructs > 2^31 candidates (the reference's int wraps)
+    int bad_design_count = 0;
 };
 void open_outputs(const Options& o, Outputs& out);       // headers as mipgen.cpp:349-399
-std::string format_record(const Options& o, const Region& r, const Tables& t, const Cand& c, int index, bool minor);
+std::string format_record(const Options& o, const Region& r, const Tables& t, const Cand& c, int64_t index, bool minor);
 
 // re-scoring hook for -score_method mixed (mipgen.cpp:1523-1527,1873-1877)
 struct Rescorer { virtual double svr(const Cand& c) = 0; virtual ~Rescorer() {} };

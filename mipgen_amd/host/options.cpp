@@ -21,7 +21,8 @@ static const char* k_options[] = {
     "-lig_min_length", "-bwa_threads", "-snp_file", "-double_tile_strand_unaware", "-double_tile_strands_separately",
     "-score_method", "-logistic_heuristic", "-file_of_parameters", "-logistic_priority_score", "-svr_priority_score",
     "-logistic_optimal_score", "-svr_optimal_score", "-max_arm_copy_product", "-target_arm_copy",
-    "-gpu_copy_counter"};          // extension (not in the reference): "on" = exact oligo copy numbers by k-mer counting on the GPU, no bwa
+    "-gpu_copy_counter",           // extension (not in the reference): "on" = exact oligo copy numbers by k-mer counting on the GPU, no bwa
+    "-gpus", "-gpu_window_candidates", "-gpu_timing"};   // extensions: device workers (0 = all visible), result-window cap (tests), stage timings on stderr
 
 static bool known(const std::string& p)
 {
@@ -63,7 +64,8 @@ static const char* k_doc =
     "misc\n"
     "  -silent_mode on   skip the all_mips / collapsed_mips files\n"
     "  -gpu_copy_counter on   (extension) arm copy numbers = exact occurrences in -genome_dir / the indexed fasta, counted on the GPU;\n"
-    "                         bwa is not run and the whole-window uniqueness flag is not set\n";
+    "                         bwa is not run and the whole-window uniqueness flag is not set\n"
+    "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n";
 
 static void set_defaults(Options& o)
 {
@@ -75,6 +77,7 @@ static void set_defaults(Options& o)
     a["-capture_increment"] = "5"; a["-max_mip_overlap"] = "30"; a["-score_method"] = "logistic";
     a["-lig_min_length"] = "18"; a["-ext_min_length"] = "16"; a["-max_arm_copy_product"] = "75";
     a["-target_arm_copy"] = "20"; a["-bwa_threads"] = "1"; a["-gpu_copy_counter"] = "off";
+    a["-gpus"] = "0"; a["-gpu_window_candidates"] = "0"; a["-gpu_timing"] = "off";
 }
 
 std::string parse_command_line(int argc, char** argv, Options& o)

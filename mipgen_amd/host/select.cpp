@@ -108,7 +108,7 @@ static void snp_arms(const Region& r, const Tables& t, const Cand& c, std::strin
 }
 
 // print_details, mipgen.cpp:765-794
-std::string format_record(const Options& o, const Region& r, const Tables& t, const Cand& c, int index, bool minor)
+std::string format_record(const Options& o, const Region& r, const Tables& t, const Cand& c, int64_t index, bool minor)
 {
     std::string ext = slice(r, c.ext_start, c.ext_len), lig = slice(r, c.lig_start, c.lig_len), ins = slice(r, c.scan_start, c.scan_size());
     if (c.strand == 1) { ext = revcomp(ext); lig = revcomp(lig); ins = revcomp(ins); }
@@ -124,7 +124,7 @@ std::string format_record(const Options& o, const Region& r, const Tables& t, co
        << c.scan_start << "\t" << c.scan_stop << "\t" << ins << "\t" << lig << o.middle << ext << "\t" << r.start - 1 << "\t" << r.stop << "\t"
        << st << "\t" << c.mapping_failed << c.snp_failed << c.masking_failed << "\t" << r.label << "_";
     char num[32];
-    snprintf(num, sizeof num, "%04d", index);
+    snprintf(num, sizeof num, "%04lld", (long long)index);
     ss << num << (c.snp_count == 1 ? (std::string("_SNP_") + (minor ? "b" : "a")) : std::string()) << "\n";
     return ss.str();
 }

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region",
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
     "mipgen_design_select_region_collapsed", "mipgen_design_counters",
-    "mipgen_design_run", "mipgen_host_rand_stream",
+    "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
 ]
 
 _lib = None
@@ -61,6 +61,9 @@ def load_library():
                                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int32, RESCORE_FN, vp]
     lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
+    lib.mipgen_design_set_devices.argtypes = [vp, C.c_int32]
+    lib.mipgen_design_set_window_candidates.argtypes = [vp, C.c_int64]
+    lib.mipgen_design_set_timing.argtypes = [vp, C.c_int32]
     lib.mipgen_host_rand_stream.argtypes = [C.POINTER(C.c_int32), C.c_int32]
     _lib = lib
     return lib
@@ -144,5 +147,9 @@ class Design:
         self._check(self.lib.mipgen_design_counters(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return {"all_mips": a.value, "collapsed": b.value, "picked": c.value, "gaps": d.value}
 
-    def run(self, n_devices: int = 0) -> None:
+    def run(self, n_devices: int = 0, window_candidates: int = 0, timing: bool = False) -> None:
+        if window_candidates:
+            self._check(self.lib.mipgen_design_set_window_candidates(self.h, window_candidates))
+        if timing:
+            self._check(self.lib.mipgen_design_set_timing(self.h, 1))
         self._check(self.lib.mipgen_design_run(self.h, n_devices))

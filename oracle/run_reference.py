@@ -25,8 +25,13 @@ def have_reference(o0: bool = False) -> bool:
 def run_reference(workdir: str, genome_dir: str, bed: str, project: str, min_capture: int, max_capture: int,
                   score_method: str = "logistic", model_path: Optional[str] = None, bwa_mode: str = "unique",
                   snp_file: Optional[str] = None, use_trf: bool = False, silent: bool = False,
-                  extra: Sequence[str] = (), o0: bool = False, timeout: Optional[float] = None) -> Dict[str, object]:
+                  extra: Sequence[str] = (), o0: bool = False, timeout: Optional[float] = None,
+                  hot_marker: bool = False) -> Dict[str, object]:
     """Run the reference in `workdir` (it writes <project>.* there).  Returns timing + paths.
+
+    hot_marker: additionally report "hot_seconds" = wall time from the reference's own stderr line
+    "[mipgen] bwa copy number analysis finished" (/root/reference/mipgen.cpp:349, printed right before tile_regions) to process exit,
+    i.e. tile_regions alone (enumeration + scoring + selection + output) without the input stage / FASTQ / stand-in bwa I/O.
 
     The SVR model is looked up next to argv[0] as `mipgen_svr.model` (/root/reference/mipgen.cpp:137-138,409),
     so the binary is copied into workdir and the model placed beside it."""
@@ -55,9 +60,27 @@ def run_reference(workdir: str, genome_dir: str, bed: str, project: str, min_cap
     env = dict(os.environ)
     env["FAKEBWA_MODE"] = bwa_mode
     t0 = time.perf_counter()
+    base = os.path.join(workdir, project)
+    if hot_marker:
+        t_mark = None
+        err_lines: List[str] = []
+        with subprocess.Popen(cmd, cwd=workdir, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) as pr:
+            for raw in pr.stderr:                                # cerr is unbuffered: the marker arrives when it is printed
+                line = raw.decode(errors="replace")
+                err_lines.append(line)
+                if t_mark is None and "bwa copy number analysis finished" in line:
+                    t_mark = time.perf_counter()
+                if timeout is not None and time.perf_counter() - t0 > timeout:
+                    pr.kill()
+            rc = pr.wait()
+        t1 = time.perf_counter()
+        return {"returncode": rc, "seconds": t1 - t0, "hot_seconds": (t1 - t_mark) if t_mark is not None else None,
+                "stderr": "".join(err_lines[-50:]), "stdout": "",
+                "all_mips": base + ".all_mips.txt", "collapsed_mips": base + ".collapsed_mips.txt",
+                "picked_mips": base + ".picked_mips.txt", "snp_mips": base + ".snp_mips.txt",
+                "progress": base + ".progress.txt", "cmd": cmd}
     proc = subprocess.run(cmd, cwd=workdir, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     dt = time.perf_counter() - t0
-    base = os.path.join(workdir, project)
     return {"returncode": proc.returncode, "seconds": dt, "stderr": proc.stderr.decode(errors="replace"),
             "stdout": proc.stdout.decode(errors="replace"),
             "all_mips": base + ".all_mips.txt", "collapsed_mips": base + ".collapsed_mips.txt",

@@ -167,8 +167,8 @@ def test_front_end_counts_where_the_regions_are_scored(tmp_path):
         work = str(tmp_path / ("w" + gpus))
         argv = H.prepare_cli_workdir(meta, work)
         argv[argv.index("-bwa") + 1] = "/nonexistent/bwa"
-        p = subprocess.run(argv + ["-gpu_copy_counter", "on"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
-                           env=dict(os.environ, MIPGEN_GPUS=gpus, MIPGEN_TIMING="1"))
+        p = subprocess.run(argv + ["-gpu_copy_counter", "on", "-gpus", gpus, "-gpu_timing", "on"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         assert b"arm copy numbers (resident)" in p.stderr
         outs[gpus] = {k: open(os.path.join(work, "out." + k + ".txt"), "rb").read() for k in ("all_mips", "collapsed_mips", "picked_mips", "snp_mips")}

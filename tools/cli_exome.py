@@ -52,7 +52,7 @@ def main() -> None:
             "-bwa_genome_index", os.path.join(work, "genome", "index.fa"), "-genome_dir", os.path.join(work, "genome"), "-score_method", method,
             "-silent_mode", "on", "-gpu_copy_counter", "on"]
     t1 = time.time()
-    p = subprocess.run(argv, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MIPGEN_TIMING="1"))
+    p = subprocess.run(argv + ["-gpu_timing", "on"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     dt = time.time() - t1
     print("rc", p.returncode, f"wall {dt:.1f} s")
     print("".join(l + "\n" for l in p.stderr.decode().split("\n") if "timing" in l or "[mipgen_accel]" in l))
