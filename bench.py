@@ -289,13 +289,30 @@ def physical_cores() -> int:
     return max(1, len(seen))
 
 
+def cgroup_cpu_quota() -> float:
+    """CPUs this container may use at once according to its cgroup (cpu.max / cfs quota); inf if unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return float("inf")
+
+
 def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
     """The reference CPU path (oracle/_ref: the real reference compiled from /root/reference by oracle/Makefile) timed on this box's host
-    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (regions of ~110-130 bp: 2-4 capture sizes survive the
-    static skip).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
+    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (its 8 shortest regions: seconds of CPU work each).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
       leg A  one process per sample region, -O2, all_mips written: the emitted-candidate count of every sample region and the single-process
              rate; beside them ONE process of the binary AS SHIPPED (/root/reference/makefile:3-4: no -O flag) on the shortest region;
-      leg B  C = all physical cores processes at once, -O2, -silent_mode on (no all_mips text): `value` = sum over the processes of
+      leg B  C = all physical cores (capped by the container's cgroup CPU quota, if any) processes at once, -O2, -silent_mode on (no all_mips text): `value` = sum over the processes of
              (emitted candidates of its region / its tile_regions time), every process timed while all the others run.  tile_regions time =
              from the reference's own "[mipgen] bwa copy number analysis finished" line (mipgen.cpp:349) to exit: enumeration + scoring +
              selection, WITHOUT the input stage and the FASTQ / stand-in bwa (awk) I/O, which the GPU figure does not cover either."""
@@ -311,7 +328,8 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
     except AttributeError:
         cores_avail = os.cpu_count() or 1
     phys = physical_cores()
-    cores = args.cpu_cores or phys
+    quota = cgroup_cpu_quota()
+    cores = args.cpu_cores or max(1, min(phys, int(quota) if quota != float("inf") else phys))
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -320,7 +338,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                 break
     except OSError:
         pass
-    pool = sorted(ivs, key=lambda v: abs((v.bed_end - v.bed_start) - 122))[:8]
+    pool = sorted(ivs, key=lambda v: (v.bed_end - v.bed_start))[:8]          # the 8 shortest regions: seconds of CPU work each
     shortest = min(range(len(pool)), key=lambda i: pool[i].bed_end - pool[i].bed_start)
     work = tempfile.mkdtemp(prefix="mipgen_cpu_")          # not /dev/shm: it is mounted noexec on the GPU boxes (the binary is copied beside its model)
 
@@ -361,10 +379,11 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                    "single_core_value_end_to_end": A[shortest]["n"] / A[shortest]["seconds"],
                    "end_to_end_value": n_all / wall,
                    "cpu_model": cpu_model, "host_threads_available": cores_avail, "physical_cores": phys,
+                   "cgroup_cpu_quota": None if quota == float("inf") else quota,
                    "scope": "reference binary, tile_regions only (enumeration + scoring + selection; from its 'bwa copy number analysis finished' line to exit), "
                             "-O2, -silent_mode on in the multi-process leg; end_to_end_value includes its input stage and the stand-in bwa / FASTQ I/O",
                    "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2, -silent_mode on), one region each from the "
-                             f"{len(pool)} regions closest to 122 bp ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp; 2-4 capture sizes survive the static skip), "
+                             f"{len(pool)} shortest regions ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp), "
                              f"{n_all} emitted candidates, tile_regions {min(b['hot'] for b in B):.1f}-{max(b['hot'] for b in B):.1f} s per process, {wall:.1f} s wall; "
                              f"alone: {A[shortest]['len']}-bp region, {A[shortest]['n']} candidates, tile_regions {A[shortest]['hot']:.1f} s of {A[shortest]['seconds']:.1f} s"}
             if O0:
