@@ -320,10 +320,25 @@ int mipgen_accel_download_text(mipgen_accel* h, char* dst, int64_t capacity);
  *   copy_out[r]               int32 [n_lengths][region_lens[r]]: exactly the mipgen_region.copy slices (copy[len][start - seq_start]);
  *                             oligos with a non-ACGT byte get 100 (a read without an X0 tag, :589-592), oligos that would run past the
  *                             region string 0 (never written, :829)
- * BWA's mismatch-tolerant uniqueness test of whole capture windows (:841-868) is not reproduced: pass unmappable = NULL. */
+ * The uniqueness test of whole capture windows (:841-868) is mipgen_accel_window_uniqueness() below. */
 int mipgen_accel_count_oligo_copies(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens,
                                     int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens,
                                     int32_t n_lengths, const int32_t* lengths, int32_t* const* copy_out);
+
+/* The capture-window half of check_copy_numbers (mipgen.cpp:806-823 writes every capture window to a FASTQ file, :841-868 marks a window start
+ * "unmappable" unless bwa's SAM line contains "X0:i:1" and "X1:i:0"; design_mip sets mapping_failed there, :615-625).  Model: a window taken from
+ * the genome matches itself exactly, so X0 = its exact occurrences on either strand and X1 = its occurrences with exactly ONE SUBSTITUTION
+ * (Hamming distance 1); bwa aln's gapped one-difference hits are not searched.  The substring tests of :852 are kept (X0 printed with a leading
+ * '1' passes: 1, 10-19, ...).  Seed-and-extend from the k-mer table: a window within distance 1 of a locus contains its first or its second
+ * seed_len-mer exactly, so only the loci of repeated seeds are extended (two streaming passes over the genome).
+ *   sizes                     capture sizes (any order), each >= 2 * seed_len
+ *   seed_len                  12..31; the design's longest arm oligo (30) is the natural choice
+ *   unmap_out[r]              uint8 [n_sizes][region_lens[r]]: 1 = the window of sizes[c] starting at index i of the region string is not unique
+ *                             (or holds a non-ACGT byte); 0 = unique, or the window does not fit into the region string.  The caller keeps
+ *                             the starts the reference enumerates ([start_flanked - C, stop_flanked), :808-812) - exactly mipgen_region.unmappable. */
+int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens,
+                                   int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens,
+                                   int32_t n_sizes, const int32_t* sizes, int32_t seed_len, uint8_t* const* unmap_out);
 
 /* The same counts, kept in the handle's device memory in the layout the scoring kernels read (288 GB of HBM: the tables of a whole exome
  * are 6.7 GB and would otherwise cross PCIe twice).  The oligo lengths are the ones the handle's arm pairs use.  The next

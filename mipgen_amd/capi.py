@@ -308,6 +308,8 @@ def load_library(path: Optional[str] = None):
                                                     C.POINTER(C.POINTER(C.c_int32))]
     lib.mipgen_accel_count_oligo_copies_resident.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, i64p,
                                                              C.POINTER(C.POINTER(BigCopy))]
+    lib.mipgen_accel_window_uniqueness.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, C.c_int32, i32p, C.c_int32,
+                                                   C.POINTER(C.POINTER(C.c_uint8))]
     lib.mipgen_accel_format_all_mips.argtypes = [vp, C.POINTER(RecordNames), C.c_char_p, C.c_int64, i64p, i64p]
     lib.mipgen_accel_download_text.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
@@ -315,7 +317,7 @@ def load_library(path: Optional[str] = None):
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "format_all_mips", "download_text"):
+                 "set_sv_split", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "format_all_mips", "download_text"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -333,7 +335,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
-    "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_set_logistic_subruns",
+    "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_set_logistic_subruns",
 ]
 
 
@@ -439,6 +441,21 @@ class Accel:
         self._check(self.lib.mipgen_accel_count_oligo_copies(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
                                                              rl.ctypes.data_as(C.POINTER(C.c_int32)), nl, la.ctypes.data_as(C.POINTER(C.c_int32)), op))
         return [{int(k): o[i] for i, k in enumerate(lengths)} for o in outs]
+
+    def window_uniqueness(self, chroms: Sequence[bytes], region_seqs: Sequence[bytes], sizes: Sequence[int], seed_len: int = 30) -> List[np.ndarray]:
+        """Per region uint8 [len(sizes)][len(seq)]: 1 = the capture window of that size starting there is not unique within one substitution
+        (both strands, whole genome) or holds a non-ACGT byte (mipgen.cpp:841-868 through bwa)."""
+        nc, nr, ns = len(chroms), len(region_seqs), len(sizes)
+        ca = (C.c_char_p * max(nc, 1))(*chroms)
+        cl = np.array([len(c) for c in chroms], dtype=np.int64)
+        ra = (C.c_char_p * max(nr, 1))(*region_seqs)
+        rl = np.array([len(r) for r in region_seqs], dtype=np.int32)
+        sz = np.array(list(sizes), dtype=np.int32)
+        outs = [np.zeros((ns, len(r)), dtype=np.uint8) for r in region_seqs]
+        op = (C.POINTER(C.c_uint8) * max(nr, 1))(*[o.ctypes.data_as(C.POINTER(C.c_uint8)) for o in outs])
+        self._check(self.lib.mipgen_accel_window_uniqueness(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
+                                                            rl.ctypes.data_as(C.POINTER(C.c_int32)), ns, sz.ctypes.data_as(C.POINTER(C.c_int32)), seed_len, op))
+        return outs
 
     def count_oligo_copies_resident(self, chroms: Sequence[bytes], region_seqs: Sequence[bytes]) -> List[Tuple[int, int, int, int]]:
         """The same counts for the handle's own oligo lengths, left on the device for an upload of the same regions with copy=COPY_RESIDENT;

@@ -1,6 +1,7 @@
 // accel.hip — host side of libmipgen_accel.so: the C-ABI of include/mipgen_accel.h over the gfx950 kernels.
 // No CPU scoring path exists in this library: every entry point either drives the GPU or fails.
 #include <hip/hip_runtime.h>
+#include <functional>
 
 #include <algorithm>
 #include <chrono>
@@ -1441,6 +1442,7 @@ namespace {
 struct KmerRun {
     KmerParams KP;
     int64_t total = 0;
+    int64_t pad = 0;                          // 'N' bytes behind the concatenation (readers that run past the last region: kernels_window.hip)
     std::vector<int64_t> roff;                // start of every region in the concatenation (one separator after each), then `total`
     DevBuf<char> dq, dg;
     DevBuf<uint64_t> dkeys;
@@ -1479,7 +1481,7 @@ int kmer_count_run(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_se
     }
     K.roff[(size_t)n_regions] = total;
     K.total = total;
-    std::vector<char> q((size_t)total, 'N');
+    std::vector<char> q((size_t)(total + K.pad), 'N');
     for (int r = 0; r < n_regions; r++) memcpy(&q[(size_t)K.roff[(size_t)r]], region_seqs[r], (size_t)region_lens[r]);
     uint64_t cap = 1024;
     while (cap < 2 * (uint64_t)total) cap <<= 1;
@@ -1490,12 +1492,12 @@ int kmer_count_run(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_se
     int64_t gmax = 0;
     for (int c = 0; c < n_chrom; c++) gmax = std::max(gmax, chrom_lens[c]);
     const size_t tab = (size_t)cap * (size_t)n_lengths;
-    if (K.dq.reserve((size_t)total) || K.dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || K.dkeys.reserve(tab) || K.dcounts.reserve(tab) ||
+    if (K.dq.reserve((size_t)(total + K.pad)) || K.dg.reserve((size_t)std::max<int64_t>(gmax, 1)) || K.dkeys.reserve(tab) || K.dcounts.reserve(tab) ||
         K.dfilter.reserve((size_t)1 << (KP.filter_bits - 5)) || K.dfolded.reserve((size_t)1 << 13) || K.out.reserve((size_t)total * (size_t)n_lengths))
         return MIPGEN_E_NOMEM;
     DIAG_LAP("concatenate + device buffers");
     HIP_TRY(hipEventCreate(&K.e0)); HIP_TRY(hipEventCreate(&K.e1));
-    HIP_TRY(hipMemcpyAsync(K.dq.p, q.data(), (size_t)total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(K.dq.p, q.data(), (size_t)(total + K.pad), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(K.dkeys.p, 0xFF, tab * sizeof(uint64_t), h->stream));
     HIP_TRY(hipMemsetAsync(K.dcounts.p, 0, tab * sizeof(unsigned int), h->stream));
     HIP_TRY(hipMemsetAsync(K.dfilter.p, 0, ((size_t)1 << (KP.filter_bits - 5)) * sizeof(uint32_t), h->stream));
@@ -1600,6 +1602,79 @@ int mipgen_accel_count_oligo_copies_resident(mipgen_accel* h, int32_t n_chrom, c
     h->resident_lens.assign(region_lens, region_lens + n_regions);
     if (n_big) *n_big = (int64_t)nb;
     if (big) *big = h->big_copies.data();
+    return MIPGEN_OK;
+}
+
+
+// ---- section 8f-3, second half: uniqueness of whole capture windows (kernels_window.hip) ---------------------------------------------------
+extern "C" hipError_t mipgen_launch_window_spans(hipStream_t st, const char* q, const int64_t* roff, int n_regions, uint16_t* dist_bad, uint16_t* dist_end, uint16_t* dist_start);
+extern "C" hipError_t mipgen_launch_seed_index(hipStream_t st, const char* q, int64_t total, int k, const uint64_t* keys, uint64_t cap_mask, unsigned int* rmult,
+                                               unsigned int* rstart, unsigned int* rfill, uint32_t* rlist, unsigned int* alloc, int phase);
+extern "C" hipError_t mipgen_launch_window_verify(hipStream_t st, const char* G, int64_t glen, const char* q, int64_t total, const int32_t* sizes, int n_sizes, int k,
+                                                  const uint64_t* keys, uint64_t cap_mask, const unsigned int* counts, const uint32_t* filter, int filter_bits,
+                                                  const unsigned int* rmult, const unsigned int* rstart, const uint32_t* rlist, const uint16_t* dist_start, unsigned int* ctr);
+extern "C" hipError_t mipgen_launch_window_flags(hipStream_t st, const char* q, int64_t total, const int32_t* sizes, int n_sizes, int k, const uint64_t* keys,
+                                                 uint64_t cap_mask, const unsigned int* counts, const uint16_t* dist_bad, const uint16_t* dist_end, const unsigned int* ctr,
+                                                 uint8_t* unmap);
+
+int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                   const char* const* region_seqs, const int32_t* region_lens, int32_t n_sizes, const int32_t* sizes, int32_t seed_len,
+                                   uint8_t* const* unmap_out)
+{
+    if (!h || n_chrom < 0 || n_regions < 0 || n_sizes < 1 || n_sizes > 64 || !sizes || (n_chrom && (!chrom_seqs || !chrom_lens)) ||
+        (n_regions && (!region_seqs || !region_lens || !unmap_out)))
+        return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (seed_len < 12 || seed_len > 31) return fail(MIPGEN_E_INVALID, "seed length %d: must be in [12, 31] (exact 2-bit keys)", seed_len);
+    int max_size = 0;
+    for (int i = 0; i < n_sizes; i++) {
+        if (sizes[i] < 2 * seed_len || sizes[i] > 60000) return fail(MIPGEN_E_INVALID, "capture size %d: must be in [2 x seed length, 60000] (two disjoint seeds per window)", sizes[i]);
+        max_size = std::max(max_size, sizes[i]);
+    }
+    if (n_regions == 0) return MIPGEN_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    KmerRun K(&h->pool);
+    K.pad = (int64_t)max_size + 1;
+    const int32_t lengths[1] = {seed_len};
+    if (int rc = kmer_count_run(h, n_chrom, chrom_seqs, chrom_lens, n_regions, region_seqs, region_lens, 1, lengths, K)) return rc;    // seeds + their genome loci
+    const int64_t total = K.total;
+    if (total >= ((int64_t)1 << 31)) return fail(MIPGEN_E_INVALID, "window uniqueness: more than 2^31 region bases in one call");
+    const uint64_t cap = K.KP.cap_mask + 1;
+    DevBuf<unsigned int> rmult, rstart, rfill, alloc, ctr;
+    DevBuf<uint32_t> rlist;
+    DevBuf<uint16_t> dbad, dend, dstart;
+    DevBuf<int64_t> droff;
+    DevBuf<uint8_t> dun;
+    struct Free { std::vector<std::function<void()>> f; ~Free() { for (auto& g : f) g(); } } fr;     // DevBuf has no destructor: release on every exit
+    fr.f = {[&] { rmult.release(); }, [&] { rstart.release(); }, [&] { rfill.release(); }, [&] { alloc.release(); }, [&] { ctr.release(); }, [&] { rlist.release(); },
+            [&] { dbad.release(); }, [&] { dend.release(); }, [&] { dstart.release(); }, [&] { droff.release(); }, [&] { dun.release(); }};
+    if (rmult.reserve(cap) || rstart.reserve(cap) || rfill.reserve(cap) || alloc.reserve(1) || ctr.reserve((size_t)n_sizes * (size_t)total) || rlist.reserve((size_t)total) ||
+        dbad.reserve((size_t)total) || dend.reserve((size_t)total) || dstart.reserve((size_t)total) || droff.reserve(K.roff.size()) ||
+        dun.reserve((size_t)n_sizes * (size_t)total))
+        return MIPGEN_E_NOMEM;
+    HIP_TRY(hipMemsetAsync(rmult.p, 0, cap * sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemsetAsync(rfill.p, 0, cap * sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemsetAsync(alloc.p, 0, sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemsetAsync(ctr.p, 0, (size_t)n_sizes * (size_t)total * sizeof(unsigned int), h->stream));
+    HIP_TRY(hipMemcpyAsync(droff.p, K.roff.data(), K.roff.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(mipgen_launch_window_spans(h->stream, K.dq.p, droff.p, n_regions, dbad.p, dend.p, dstart.p));
+    for (int phase = 0; phase < 3; phase++)
+        HIP_TRY(mipgen_launch_seed_index(h->stream, K.dq.p, total, seed_len, K.dkeys.p, K.KP.cap_mask, rmult.p, rstart.p, rfill.p, rlist.p, alloc.p, phase));
+    for (int c = 0; c < n_chrom; c++) {                                // second genome pass: extend the loci of the repeated seeds
+        if (chrom_lens[c] <= 0) continue;
+        HIP_TRY(hipMemcpyAsync(K.dg.p, chrom_seqs[c], (size_t)chrom_lens[c], hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(mipgen_launch_window_verify(h->stream, K.dg.p, chrom_lens[c], K.dq.p, total, sizes, n_sizes, seed_len, K.dkeys.p, K.KP.cap_mask, K.dcounts.p,
+                                            K.dfilter.p, K.KP.filter_bits, rmult.p, rstart.p, rlist.p, dstart.p, ctr.p));
+        HIP_TRY(hipStreamSynchronize(h->stream));                      // the next chromosome overwrites the genome buffer
+    }
+    HIP_TRY(mipgen_launch_window_flags(h->stream, K.dq.p, total, sizes, n_sizes, seed_len, K.dkeys.p, K.KP.cap_mask, K.dcounts.p, dbad.p, dend.p, ctr.p, dun.p));
+    std::vector<uint8_t> img((size_t)n_sizes * (size_t)total);
+    HIP_TRY(hipMemcpyAsync(img.data(), dun.p, img.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < n_regions; r++) {
+        if (!unmap_out[r]) continue;
+        const int len = region_lens[r];
+        for (int c = 0; c < n_sizes; c++) memcpy(unmap_out[r] + (size_t)c * (size_t)len, &img[(size_t)c * (size_t)total + (size_t)K.roff[(size_t)r]], (size_t)len);
+    }
     return MIPGEN_OK;
 }
 

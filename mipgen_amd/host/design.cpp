@@ -132,7 +132,7 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
             load_genome(o, d->regions, d->genome);
             d->copies_deferred = true;
             for (Region& r : d->regions) r.copy_deferred = true;
-            out.progress << "0 ambiguously mapping start positions must be avoided\nexact oligo copy numbers counted on the accelerator\n";
+            out.progress << "exact oligo copy numbers and capture-window uniqueness counted on the accelerator\n";
             std::cerr << "[mipgen] oligo copy numbers counted on the accelerator (no bwa)\n";
         } else {
             const std::string copy_status = check_copy_numbers(o, d->regions, d->tables);
@@ -462,6 +462,8 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
         if (mipgen_accel_count_oligo_copies_resident(h, (int32_t)cs.size(), cs.data(), cl.data(), n, rs.data(), rl.data(), &n_big, &big)) { bail(11); return; }
         for (int i = 0; i < n; i++) { Region& r = d->regions[(size_t)(r0 + i)]; r.copy_resident = true; r.big_copy.clear(); }
         for (int64_t k = 0; k < n_big; k++) d->regions[(size_t)(r0 + big[k].region)].big_copy[{big[k].length, big[k].start}] = big[k].copies;
+        // the capture-window half of check_copy_numbers (mapping_failed, mipgen.cpp:615-625, 841-868) for the same shard
+        try { gpu_window_flags(o, h, d->genome, d->regions, r0, r1); } catch (int) { bail(11); return; }
     }
     lap(6);
     std::vector<mipgen_region> batch((size_t)n);

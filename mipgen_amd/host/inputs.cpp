@@ -4,6 +4,7 @@
 // the same command lines so that real bwa / tabix / trf (or the test stand-ins) see what the reference would hand them.
 // One deliberate change: without -genome_dir the region sequences are sliced from the .fai-indexed
 // reference directly instead of forking `samtools faidx` twice per region.
+#include <dirent.h>
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -412,20 +413,82 @@ void attach_tables(const Options& o, const Tables& t, Region& r)
 
 // the arm-oligo copy numbers (mipgen.cpp:558-596, 825-835) as exact occurrence counts against the whole genome,
 // counted by the accelerator in one streaming pass per chromosome - no FASTQ files, no bwa.
-// the genome the reference's bwa index was built from: every chr*.fa of -genome_dir, or every record of the indexed fasta
+// The genome bwa would have searched = the whole -bwa_genome_index: that FASTA itself when it is readable, else EVERY chr*.fa of -genome_dir
+// (not only the chromosomes that carry a region: an oligo's copies on the other chromosomes count, mipgen.cpp:560-561 aligns against the
+// whole index).  Which files were counted against is reported on stderr.
 void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<std::string>& chroms)
 {
     chroms.clear();
     auto read_fasta = [&](const std::string& path) { return slurp_fasta(path, chroms); };
-    if (o.has("-genome_dir")) {
-        const std::string dir = o.arg("-genome_dir");
-        std::set<std::string> seen;
-        for (const Region& r : regs) if (seen.insert(r.chr).second && !read_fasta(dir + "/chr" + r.chr + ".fa")) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; throw 7; }
-        // chromosomes without a region still count towards copy numbers when they sit next to the others: chr*.fa listed in <dir>/chromosomes.txt
-        std::ifstream lst(dir + "/chromosomes.txt");
-        std::string name;
-        while (lst >> name) if (seen.insert(name).second) read_fasta(dir + "/chr" + name + ".fa");
-    } else if (!read_fasta(o.bwa_genome_index)) { std::cerr << "genome fasta could not be opened; check file path and permissions?" << std::endl; throw 9; }
+    {
+        std::ifstream probe(o.bwa_genome_index);
+        char c = 0;
+        if (probe.is_open() && probe.get(c) && c == '>') {
+            if (!read_fasta(o.bwa_genome_index)) { std::cerr << "genome fasta could not be opened; check file path and permissions?" << std::endl; throw 9; }
+            std::cerr << "[mipgen] -gpu_copy_counter: counting against the " << chroms.size() << " sequence(s) of " << o.bwa_genome_index << std::endl;
+            return;
+        }
+    }
+    if (!o.has("-genome_dir")) { std::cerr << "genome fasta could not be opened; check file path and permissions?" << std::endl; throw 9; }
+    const std::string dir = o.arg("-genome_dir");
+    std::vector<std::string> files;
+    if (DIR* dh = opendir(dir.c_str())) {
+        while (struct dirent* e = readdir(dh)) {
+            const std::string n = e->d_name;
+            if (n.size() > 6 && n.compare(0, 3, "chr") == 0 && n.compare(n.size() - 3, 3, ".fa") == 0) files.push_back(n);
+        }
+        closedir(dh);
+    }
+    std::sort(files.begin(), files.end());
+    std::set<std::string> have(files.begin(), files.end());
+    for (const Region& r : regs) if (!have.count("chr" + r.chr + ".fa")) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; throw 7; }
+    for (const std::string& f : files) if (!read_fasta(dir + "/" + f)) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; throw 7; }
+    std::cerr << "[mipgen] -gpu_copy_counter: -bwa_genome_index is not a readable FASTA; counting against the " << files.size() << " chr*.fa file(s) of " << dir
+              << " (copies elsewhere in the genome are NOT seen)" << std::endl;
+}
+
+// -gpu_copy_counter on: the capture-window half of check_copy_numbers (mipgen.cpp:806-823, 841-868) through mipgen_accel_window_uniqueness, for the
+// regions [r0, r1): Region::unmappable = 1 for the window starts the reference enumerates ([start_fl - C, stop_fl), :808-813) whose window is
+// not unique within one substitution.  Skipped with -check_copy_number off (the flag is then never consulted, :619).
+void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1)
+{
+    if (o.arg("-check_copy_number") == "off" || r1 <= r0) return;
+    const int K = (o.max_capture - o.min_capture) / o.capture_increment + 1;
+    std::vector<int32_t> sizes((size_t)K);
+    for (int k = 0; k < K; k++) sizes[(size_t)k] = o.max_capture - k * o.capture_increment;
+    const int seed = std::min(31, std::max(12, o.oligo_sizes.empty() ? 30 : *o.oligo_sizes.rbegin()));
+    if (o.min_capture < 2 * seed) {
+        std::cerr << "[mipgen] -gpu_copy_counter: capture sizes below " << 2 * seed << " bases: the window uniqueness test is skipped" << std::endl;
+        return;
+    }
+    std::vector<const char*> cs; std::vector<int64_t> cl;
+    for (const std::string& c : chroms) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
+    std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<uint8_t*> outp;
+    for (int i = r0; i < r1; i++) {
+        Region& r = regs[(size_t)i];
+        rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size());
+        r.unmappable.assign((size_t)K * r.seq.size(), 0);
+        outp.push_back(r.unmappable.data());
+    }
+    if (mipgen_accel_window_uniqueness(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(), K, sizes.data(), seed, outp.data())) {
+        std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
+        throw 11;
+    }
+    for (int i = r0; i < r1; i++) {
+        Region& r = regs[(size_t)i];
+        const size_t n = r.seq.size();
+        bool any = false;
+        for (int k = 0; k < K; k++) {
+            const int C = sizes[(size_t)k];
+            uint8_t* row = r.unmappable.data() + (size_t)k * n;
+            for (size_t j = 0; j < n; j++) {
+                const long pos = (long)r.seq_start + (long)j;                 // current_mip_start of mipgen.cpp:808-813
+                if (row[j] && !(pos >= (long)r.start_fl - C && pos < r.stop_fl && pos > 0 && pos + C - 1 <= r.seq_stop)) row[j] = 0;
+                any |= row[j] != 0;
+            }
+        }
+        if (!any) r.unmappable.clear();
+    }
 }
 
 // the counts as host tables (Region::copy_flat): for callers that score through their own accelerator handle
@@ -446,6 +509,7 @@ void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, 
     const int rc = mipgen_accel_count_oligo_copies(h, (int32_t)cs.size(), cs.data(), cl.data(), (int32_t)regs.size(), rs.data(), rl.data(),
                                                    (int32_t)lengths.size(), lengths.data(), outp.data());
     if (rc) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; mipgen_accel_destroy(h); throw 11; }
+    try { gpu_window_flags(o, h, chroms, regs, 0, (int)regs.size()); } catch (...) { mipgen_accel_destroy(h); throw; }
     mipgen_accel_destroy(h);
     for (Region& r : regs) r.copy_ready = true;
 }

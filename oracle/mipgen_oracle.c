@@ -862,3 +862,49 @@ int mo_print_details(const char* chr, const char* label, int feature_start, int 
         feature_start - 1, feature_stop, st, d->mapping_failed, d->snp_failed, d->masking_failed,
         label, mip_index, suffix);
 }
+
+
+/* ------------------------------------------------------------------------------------------------ */
+/* capture-window uniqueness by brute force (see mipgen_oracle.h)             */
+/* ------------------------------------------------------------------------------------------------ */
+static int win_code(char c)
+{
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+
+void mo_window_unmappable(const char* seq, int seq_len, int size, const char* const* chroms, const int64_t* chrom_lens, int n_chrom,
+                          uint8_t* out, int32_t* x0_out, int32_t* x1_out)
+{
+    uint8_t* w = (uint8_t*)malloc((size_t)size), *wr = (uint8_t*)malloc((size_t)size);
+    for (int i = 0; i < seq_len; i++) {
+        out[i] = 0;
+        if (x0_out) x0_out[i] = 0;
+        if (x1_out) x1_out[i] = 0;
+        if (i + size > seq_len) continue;                       /* the window does not fit: never written (mipgen.cpp:813) */
+        int bad = 0;
+        for (int j = 0; j < size; j++) { w[j] = (uint8_t)win_code(seq[i + j]); if (w[j] > 3) bad = 1; }
+        if (bad) { out[i] = 1; continue; }
+        for (int j = 0; j < size; j++) wr[j] = (uint8_t)(3 - w[size - 1 - j]);        /* reverse complement */
+        long x0 = 0, x1 = 0;
+        for (int c = 0; c < n_chrom; c++) {
+            const char* g = chroms[c];
+            for (int64_t p = 0; p + size <= chrom_lens[c]; p++) {
+                for (int strand = 0; strand < 2; strand++) {
+                    const uint8_t* q = strand ? wr : w;
+                    int mm = 0;
+                    for (int j = 0; j < size && mm < 2; j++) {
+                        const int b = win_code(g[p + j]);
+                        if (b > 3 || b != q[j]) mm++;
+                    }
+                    if (mm == 0) x0++; else if (mm == 1) x1++;
+                }
+            }
+        }
+        if (x0_out) x0_out[i] = (int32_t)x0;
+        if (x1_out) x1_out[i] = (int32_t)x1;
+        long lead = x0;
+        while (lead >= 10) lead /= 10;
+        out[i] = (lead == 1 && x1 == 0) ? 0 : 1;
+    }
+    free(w); free(wr);
+}

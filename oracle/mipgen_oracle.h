@@ -114,6 +114,18 @@ int mo_print_details(const char* chr, const char* label, int feature_start, int 
                      const mo_designed* d, double score, const char* middle, int mip_index, int minor,
                      char* buf, int bufsize);
 
+/* ---- checker of the opt-in capture-window uniqueness (mipgen_accel_window_uniqueness) ------------------------
+ * The reference decides this through bwa (mipgen.cpp:806-823 writes the windows, :841-868 reads "X0:i:" / "X1:i:" back); bwa is absent here, so
+ * parity against bwa itself stays unpinned.  This is the DEFINITION the device path is held to, by brute force: every window of
+ * `size` bases starting at seq[i] is compared with every genome locus on both strands; X0 = loci at Hamming distance 0, X1 = loci at Hamming
+ * distance exactly 1 (bytes outside ACGT never match).  bwa aln defaults modelled: -n 0.04 (>= 6 differences allowed for >= 120-base reads: never
+ * binding at <= 1 difference), hits counted per locus and strand (X0 = best hits, X1 = hits with one more difference); NOT modelled: its gapped
+ * one-difference alignments (-o 1 -e -1 -i 5 -d 16), the seed / queue heuristics (-l 32 -k 2 -m), the -R 30 cut-off, and its handling of N.
+ * out[i] = 1 unless the reference's substring tests (:852) pass: decimal X0 starts with '1' and X1 == 0; 1 for a window with a non-ACGT byte;
+ * 0 for windows that do not fit into seq (never written, :813). */
+void mo_window_unmappable(const char* seq, int seq_len, int size, const char* const* chroms, const int64_t* chrom_lens, int n_chrom,
+                          uint8_t* out, int32_t* x0_out, int32_t* x1_out);
+
 #ifdef __cplusplus
 }
 #endif

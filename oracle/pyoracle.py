@@ -87,6 +87,8 @@ def oracle():
     lib.mo_enumerate_region.argtypes = [PP, RP, vp, C.c_int, cp, C.POINTER(Emitted), C.c_int64]
     lib.mo_enumerate_region.restype = C.c_int64
     lib.mo_print_details.argtypes = [cp, cp, C.c_int, C.c_int, C.c_int, C.POINTER(Designed), C.c_double, cp, C.c_int, C.c_int, cp, C.c_int]
+    lib.mo_window_unmappable.argtypes = [cp, C.c_int, C.c_int, C.POINTER(cp), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32)]
     _o = lib
     return lib
 
@@ -286,4 +288,21 @@ def count_oligo_copies(chroms: Sequence[bytes], seq: bytes, lengths: Sequence[in
             else:
                 col[i] = want[min(s, s.translate(_RC)[::-1])]
         out[int(k)] = col
+    return out
+
+
+def window_unmappable(chroms: Sequence[bytes], seq: bytes, sizes: Sequence[int]):
+    """Brute-force checker of mipgen_accel_window_uniqueness (oracle/mipgen_oracle.h: mo_window_unmappable): per capture size
+    (flags uint8[len(seq)], X0 int32[len(seq)], X1 int32[len(seq)]) - Hamming distance 0 / exactly 1 against every genome locus, both strands."""
+    n = len(chroms)
+    ca = (C.c_char_p * n)(*chroms)
+    cl = (C.c_int64 * n)(*[len(c) for c in chroms])
+    out = {}
+    for size in sizes:
+        f = np.zeros(len(seq), dtype=np.uint8)
+        x0 = np.zeros(len(seq), dtype=np.int32)
+        x1 = np.zeros(len(seq), dtype=np.int32)
+        oracle().mo_window_unmappable(seq, len(seq), int(size), ca, cl, n, f.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      x0.ctypes.data_as(C.POINTER(C.c_int32)), x1.ctypes.data_as(C.POINTER(C.c_int32)))
+        out[int(size)] = (f, x0, x1)
     return out

@@ -189,3 +189,106 @@ def test_front_end_counts_where_the_regions_are_scored(tmp_path):
             got = np.ctypeslib.as_array(r.copy[k], shape=(r.seq_len,))
             assert np.array_equal(got, exp[k]), (i, k)
     d.close()
+
+
+# ---- capture-window uniqueness (mapping_failed) without bwa: mipgen_accel_window_uniqueness vs the brute-force Hamming counter ------------------
+
+def _genome_with_window_repeats():
+    """One 80 kb chromosome + a 30 kb one with planted copies of pieces of the test region g[20_000:21_000]:
+    an exact forward copy, an inverted copy with ONE substitution, a copy with two substitutions 90 bases apart (windows that hold one of
+    them are X1 hits, windows that hold both are not hits at all), a copy whose substitution sits in the window's FIRST seed (found through the
+    second seed only), eleven more exact copies of one piece (X0 = 12: the reference's substring test "X0:i:1" accepts it), an N, lower case,
+    and a reverse-palindromic 30-mer."""
+    a = bytearray(synth.random_genome(80_000, 41))
+    b = bytearray(synth.random_genome(30_000, 42))
+    pal = bytes(a[20_300:20_315])
+    a[20_315:20_330] = pal.translate(_RC)[::-1]                       # a[20300:20330] reads the same on both strands
+
+    def sub(seg, *at):
+        seg = bytearray(seg)
+        for i in at:
+            seg[i] = ord("A") if seg[i] != ord("A") else ord("C")
+        return bytes(seg)
+    a[50_000:50_260] = a[20_040:20_300]                               # exact forward copy
+    b[5_000:5_250] = sub(a[20_350:20_600], 125).translate(_RC)[::-1]  # inverted, one substitution
+    a[60_000:60_300] = sub(a[20_600:20_900], 100, 190)                # two substitutions 90 apart
+    b[12_000:12_200] = sub(a[20_100:20_300], 10)                      # substitution inside the first 30-mer of the windows starting at +0..+10
+    for k in range(11):
+        b[15_000 + 300 * k:15_000 + 300 * k + 170] = a[20_820:20_990]  # eleven more exact copies
+    a[20_700] = ord("N")
+    for i in range(20_500, 20_520):
+        a[i] = ord(chr(a[i]).lower())
+    return bytes(a), bytes(b)
+
+
+def test_window_uniqueness_vs_brute_force():
+    g1, g2 = _genome_with_window_repeats()
+    P = capi.make_params(120, 180)
+    acc = capi.Accel(P)
+    sizes = [180, 150, 120]
+    regions = [g1[19_800:21_200].upper(), g2[4_900:5_400].upper(), g1[100:400].upper(), b"ACGT" * 40]
+    got = acc.window_uniqueness([g1, g2], regions, sizes, seed_len=30)
+    n_flagged = 0
+    for seq, tab in zip(regions, got):
+        exp = po.window_unmappable([g1, g2], seq, sizes)
+        for c, size in enumerate(sizes):
+            f, x0, x1 = exp[size]
+            bad = np.nonzero(tab[c] != f)[0]
+            assert bad.size == 0, (size, bad[:8], tab[c][bad[:8]], f[bad[:8]], x0[bad[:8]], x1[bad[:8]])
+            n_flagged += int(f.sum())
+    exp0 = po.window_unmappable([g1, g2], regions[0], [120])[120]
+    assert (exp0[1] == 2).any() and (exp0[2] >= 1).any() and (exp0[1] == 12).any()      # the planted cases really occur: X0 = 2, X1 > 0, X0 = 12
+    assert int(exp0[0][(exp0[1] == 12) & (exp0[2] == 0)].sum()) == 0                      # "X0:i:12" contains "X0:i:1": accepted (mipgen.cpp:852)
+    assert n_flagged > 500
+    # a shorter seed finds the same windows (the pigeonhole holds for any seed <= size / 2)
+    got20 = acc.window_uniqueness([g1, g2], regions[:2], sizes, seed_len=20)
+    for t30, t20 in zip(got, got20):
+        assert np.array_equal(t30, t20)
+    with pytest.raises(capi.AccelError):
+        acc.window_uniqueness([g1], regions, [50], seed_len=30)                           # a window must hold two disjoint seeds
+    acc.close()
+
+
+def test_cli_mapping_flag_from_gpu_counter(tmp_path):
+    """`-gpu_copy_counter on` sets mapping_failed (first character of the failure_flags column, mipgen.cpp:615-625,791) for every candidate
+    whose footprint starts at a window start that is not unique within one substitution - checked record by record against the brute-force
+    counter; with -check_copy_number off the flag stays 0."""
+    g1, g2 = _genome_with_window_repeats()
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "genome"))
+    synth.write_fasta(os.path.join(work, "genome", "chr1.fa"), "chr1", g1.upper())
+    synth.write_fasta(os.path.join(work, "genome", "chr2.fa"), "chr2", g2.upper())       # carries no region: its copies must still be seen
+    with open(os.path.join(work, "regions.bed"), "w") as fh:
+        fh.write("chr1\t20100\t20260\tamp1\n")
+    exe = os.path.join(work, "mipgen")
+    os.symlink(H.CLI_BIN, exe)
+    argv = [exe, "-regions_to_scan", os.path.join(work, "regions.bed"), "-project_name", "out", "-min_capture_size", "120", "-max_capture_size", "130",
+            "-bwa_genome_index", os.path.join(work, "genome", "index.fa"), "-bwa", "/nonexistent/bwa", "-genome_dir", os.path.join(work, "genome"),
+            "-arm_length_sums", "44,45", "-gpu_copy_counter", "on"]
+    p = subprocess.run(argv, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b"chr*.fa file(s)" in p.stderr                                                 # it says what it counted against
+    lines = open(os.path.join(work, "out.all_mips.txt"), "rb").read().split(b"\n")[1:-1]
+    assert len(lines) > 10_000
+    # the region string of the design: [start_fl - maxC, stop_fl + maxC + 14] (mipgen.cpp:1200-1220), 1-based
+    seq_start = 20_101 - 130
+    seq = g1.upper()[seq_start - 1:20_260 + 130 + 15]
+    exp = po.window_unmappable([g1.upper(), g2.upper()], seq, [130, 125, 120])
+    n_failed = 0
+    for ln in lines:
+        f = ln.split(b"\t")
+        ext_start, ext_stop, lig_start, lig_stop, strand, flags = int(f[3]), int(f[4]), int(f[7]), int(f[8]), f[17], f[18]
+        first, last = min(ext_start, lig_start), max(ext_stop, lig_stop)
+        C = last - first + 1
+        mip_start = ext_start if strand == b"+" else lig_start                            # get_mip_start(): Plus/MinusSVMipv4
+        assert mip_start == first
+        want = int(exp[C][0][mip_start - seq_start])
+        assert flags[:1] == (b"1" if want else b"0"), (ln[:200], want)
+        n_failed += want
+    assert n_failed > 200 and n_failed < len(lines)
+    # the copies on chr2 (no region there) are counted: an arm inside the eleven-fold repeat would show them - here: the oligo copy of the
+    # exact forward copy at chr1:50,000 and the one-substitution copy on chr2 are both needed to flag these windows
+    p = subprocess.run(argv + ["-check_copy_number", "off", "-project_name", "off"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    off = open(os.path.join(work, "off.all_mips.txt"), "rb").read().split(b"\n")[1:-1]
+    assert off and all(ln.split(b"\t")[18][:1] == b"0" for ln in off)
