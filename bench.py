@@ -133,7 +133,7 @@ def assemble(args, rank: int, world: int):
             parts.append((genome, ivs))
         all_ivs = [(k, iv) for k, (_, ivs) in enumerate(parts) for iv in ivs]
         weights = workloads.dense_candidates([iv for _, iv in all_ivs], P)
-        lo, hi = mdist.shard_regions(weights.tolist(), world)[rank]
+        lo, hi = mdist.shard_regions(workloads.shard_weights([iv for _, iv in all_ivs], P, method == "svr").tolist(), world)[rank]
         mine = all_ivs[lo:hi]
 
         def build(acc):
@@ -146,7 +146,7 @@ def assemble(args, rank: int, world: int):
         total = n_regions * (world if args.scaling == "weak" else 1)
         ivs = workloads.regions5k_intervals(min(total, 1000))
         weights = workloads.dense_candidates(ivs, P)
-        lo, hi = mdist.shard_regions(weights.tolist(), world)[rank]
+        lo, hi = mdist.shard_regions(workloads.shard_weights(ivs, P, method == "svr").tolist(), world)[rank]
 
         def build(acc):
             return workloads.build_regions5k(acc, workloads.regions5k_genome(), ivs[lo:hi], P, with_lrc=method == "svr")
@@ -156,7 +156,7 @@ def assemble(args, rank: int, world: int):
         chrom_len, all_iv = workloads.exome_layout()
         ivs = all_iv[:min(total, len(all_iv))]
         weights = workloads.dense_candidates(ivs, P)
-        lo, hi = mdist.shard_regions(weights.tolist(), world)[rank]
+        lo, hi = mdist.shard_regions(workloads.shard_weights(ivs, P, method == "svr").tolist(), world)[rank]
 
         def build(acc):
             return workloads.build_exome(acc, chrom_len, ivs[lo:hi], P, snps=args.config == "exome_snp", with_lrc=method == "svr")

@@ -357,6 +357,11 @@ int mipgen_accel_count_oligo_copies_resident(mipgen_accel* h, int32_t n_chrom, c
  * in a fixed order: results are deterministic for a given split).  0 = chosen per launch from the tile count (default), n >= 1 forces
  * n parts - e.g. to compare two differently sized batches bit for bit. */
 int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
+/* SVR scores that sit within the device kernels' error (~1e-12) of a midpoint between two 6-significant-digit numbers - the precision the
+ * front end prints scores with (mipgen.cpp:774) - are re-scored in the reference's own operation order (svm.cpp:329-368, 2511-2515: index-order
+ * sums, every operation rounded on its own) and overwritten, so that the printed digit is the reference's.  On by default; 0 switches it off
+ * (measurements, tests of the mechanism).  Dense windows and candidate lists (mixed designs) alike. */
+int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on);
 /* The dense logistic kernel gives a workgroup `n` consecutive runs of scan positions (it stages the bases once and slides its downstream-arm
  * table from run to run).  0 = chosen from the batch size (1 for small batches, which need every workgroup they can get; 2 or 3 for large ones),
  * 1..8 forced.  Results do not depend on it. */

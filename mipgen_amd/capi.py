@@ -300,6 +300,7 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_download_survivors.argtypes = [vp, i64p, C.POINTER(Survivor), C.c_int64]
     lib.mipgen_accel_survivors_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
     lib.mipgen_accel_set_sv_split.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_set_print_exact.argtypes = [vp, C.c_int32]
     lib.mipgen_accel_set_logistic_subruns.argtypes = [vp, C.c_int32]
     lib.mipgen_accel_collapse.argtypes = [vp]
     lib.mipgen_accel_region_bases.argtypes = [vp, C.c_int32, i64p, i32p]
@@ -317,7 +318,7 @@ def load_library(path: Optional[str] = None):
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "format_all_mips", "download_text"):
+                 "set_sv_split", "set_print_exact", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "format_all_mips", "download_text"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -335,7 +336,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
-    "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_set_logistic_subruns",
+    "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_set_print_exact", "mipgen_accel_set_logistic_subruns",
 ]
 
 
@@ -514,6 +515,9 @@ class Accel:
 
     def set_logistic_subruns(self, n: int) -> None:
         self._check(self.lib.mipgen_accel_set_logistic_subruns(self.h, n))
+
+    def set_print_exact(self, on: bool) -> None:
+        self._check(self.lib.mipgen_accel_set_print_exact(self.h, int(on)))
 
     def set_sv_split(self, n_split: int) -> None:
         self._check(self.lib.mipgen_accel_set_sv_split(self.h, n_split))

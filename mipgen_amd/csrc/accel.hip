@@ -32,7 +32,12 @@ hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t
                                    const uint64_t* records, double* scores, int64_t n_cand, int n_split, double* partials);
 hipError_t mipgen_launch_candidates(hipStream_t, int n, const DevParams*, const DevRegion*, const mipgen_candidate*, const uint8_t*,
                                     const int32_t*, const uint8_t*, const HostConsts*, const double* model, int n_sv, double gamma,
-                                    double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*);
+                                    double rho, int method, double*, uint64_t*, double*, mipgen_candidate_ints*, int literal, const unsigned int* n_dev);
+hipError_t mipgen_launch_print_boundary_scan(hipStream_t, const DevParams*, const DevRegion*, int r0, int r1, const double* scores, const uint64_t* records, int64_t n,
+                                             double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap, int n_cu);
+hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t, const mipgen_candidate* cands, const double* scores, const uint64_t* records, int n, double tol_rel,
+                                                  double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
+hipError_t mipgen_launch_scatter_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
@@ -225,6 +230,13 @@ struct mipgen_accel {
     DevBuf<int64_t> region_pos0, region_base0;
     DevBuf<CollapseTile> col_tiles;
     DevBuf<int32_t> collapsed;
+    // scores on a rounding boundary of the 6 printed digits are re-scored in the reference's operation order (fix_print_boundaries)
+    bool print_exact = true;
+    double sum_abs_coef = 0.0;
+    DevBuf<mipgen_candidate> pb_cands;
+    DevBuf<int64_t> pb_idx;
+    DevBuf<double> pb_scores;
+    DevBuf<unsigned int> pb_count;
     std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
     int n_sv_pad = 0;
@@ -480,6 +492,8 @@ int mipgen_accel_set_model(mipgen_accel* h, int32_t n_sv, double gamma, double r
     if (h->model.reserve(rows.size())) return MIPGEN_E_NOMEM;
     HIP_TRY(hipMemcpy(h->model.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
     h->n_sv = n_sv; h->gamma = gamma; h->rho = rho; h->s_guard = s_guard - rho;
+    h->sum_abs_coef = 0.0;
+    for (int i = 0; i < n_sv; i++) h->sum_abs_coef += fabs(coef[i]);
     return build_list_model(h, rows, n_sv);
 }
 
@@ -569,6 +583,13 @@ int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates)
 {
     if (!h || max_candidates < 0) return fail(MIPGEN_E_INVALID, "bad arguments");
     h->window_cap = max_candidates;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    h->print_exact = on != 0;
     return MIPGEN_OK;
 }
 
@@ -1038,6 +1059,25 @@ static int ensure_tiles(mipgen_accel* h, int32_t method)
     return build_logistic_tiles(h);
 }
 
+// SVR scores within the dense / list kernels' error of a midpoint between two 6-significant-digit numbers (what the front end prints,
+// mipgen.cpp:774) are re-scored by k_candidates in the reference's own operation order and overwritten, so that the printed digit is the
+// reference's (its error against the reference's double is ~1e-16 relative: the libm exponential).  No host round trip: the list length
+// stays on the device, the re-scoring grid is the list's capacity.  list = nullptr: the dense results of regions [r0, r1).
+static int fix_print_boundaries(mipgen_accel* h, int r0, int r1, const mipgen_candidate* list, double* scores, const uint64_t* records, int64_t n)
+{
+    if (!h->print_exact || n <= 0 || h->n_sv <= 0) return MIPGEN_OK;
+    const unsigned int cap = (unsigned int)std::min<int64_t>(n / 1024 + 4096, (int64_t)1 << 24);
+    if (h->pb_cands.reserve(cap) || h->pb_idx.reserve(cap) || h->pb_scores.reserve(cap) || h->pb_count.reserve(1)) return MIPGEN_E_NOMEM;
+    const double tol_rel = 1e-10, tol_abs = 1e-13 * std::max(1.0, h->sum_abs_coef);
+    HIP_TRY(hipMemsetAsync(h->pb_count.p, 0, sizeof(unsigned int), h->stream));
+    if (list) HIP_TRY(mipgen_launch_print_boundary_scan_list(h->stream, list, scores, records, (int)n, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap));
+    else HIP_TRY(mipgen_launch_print_boundary_scan(h->stream, h->dp, h->regions.p, r0, r1, scores, records, n, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap, h->n_cu));
+    HIP_TRY(mipgen_launch_candidates(h->stream, (int)cap, h->dp, h->regions.p, h->pb_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
+                                     h->gamma, h->rho, MIPGEN_SCORE_SVR, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
+    HIP_TRY(mipgen_launch_scatter_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, scores));
+    return MIPGEN_OK;
+}
+
 static int score_window_impl(mipgen_accel* h, int w, int32_t method)
 {
     if (method == MIPGEN_SCORE_SVR && !h->svr_geometry_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_geometry_error.c_str());
@@ -1063,6 +1103,7 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method)
         HIP_TRY(mipgen_launch_svr_dense(h->stream, W.n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p,
                                         h->svr_tiles.p + W.svr_tile0, h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */,
                                         h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, split, h->partials.p));
+        if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand)) return rc;
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[2], h->stream)); h->ev_used[(size_t)w] |= 1; }
     h->cur_window = w; h->scored = true; h->replayed = false;
@@ -1205,11 +1246,12 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
     else
         HIP_TRY(mipgen_launch_candidates(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
                                          h->model.p, h->n_sv, h->gamma, h->rho, method, batched ? nullptr : h->cand_scores.p, h->cand_records.p,
-                                         (features || batched) ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr));
+                                         (features || batched) ? h->cand_feats.p : nullptr, ints ? h->cand_ints.p : nullptr, 0, nullptr));
     if (time_list) HIP_TRY(hipEventRecord(le[1], h->stream));
     if (batched) HIP_TRY(mipgen_launch_svr_gemm(h->stream, n, h->cand_feats.p, h->cand_records.p, h->model_t.p, h->sv_norm.p, h->sv_coef.p, h->sv_center.p, h->n_sv_pad,
                                             h->gamma, h->rho, h->cand_scores.p));
     if (time_list) HIP_TRY(hipEventRecord(le[2], h->stream));
+    if (batched) { if (int rc = fix_print_boundaries(h, 0, 0, h->cand_in.p, h->cand_scores.p, h->cand_records.p, n)) return rc; }
     if (scores) HIP_TRY(hipMemcpyAsync(scores, h->cand_scores.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (records) HIP_TRY(hipMemcpyAsync(records, h->cand_records.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     if (features) HIP_TRY(hipMemcpyAsync(features, h->cand_feats.p, (size_t)n * MIPGEN_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -8,6 +8,7 @@
 //     exp(-gamma*d2) and the partial sums coef*k are reduced with wavefront shuffles (svm.cpp:2511-2515).
 // It doubles as an on-device cross-check of the window-separable dense kernel (kernels_svr.hip).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "common.h"
 #include "device_utils.h"
 #include "logistic_device.h"
@@ -51,8 +52,10 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     const uint8_t* __restrict__ bases, const int32_t* __restrict__ copy, const uint8_t* __restrict__ unmap,
     const HostConsts* __restrict__ HC, const double* __restrict__ model, int n_sv, double gamma, double rho, int method,
     double* __restrict__ scores, uint64_t* __restrict__ records, double* __restrict__ features,
-    mipgen_candidate_ints* __restrict__ ints_out)
+    mipgen_candidate_ints* __restrict__ ints_out, int literal, const unsigned int* __restrict__ n_dev)
 {
+    if (n_dev && blockIdx.x >= *n_dev) return;          // a device-side list length (the grid is the list's capacity): no host round trip
+    __shared__ double s_term[CAND_THREADS];
     __shared__ uint8_t s_ext[MIPGEN_MAX_OLIGO + 2], s_lig[MIPGEN_MAX_OLIGO + 2], s_ins[MAX_INSERT + 2];
     __shared__ uint8_t s_raw[2][MIPGEN_MAX_OLIGO + 2];     // the arms' bytes as stored (code | masked bit | SNP class), in genome order
     __shared__ int s_cnt[128];          // 0..83 insert mers, 84..103 ext mers, 104..123 lig mers
@@ -227,6 +230,32 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     }
     if (method != MIPGEN_SCORE_SVR || !scores) return;
 
+    if (literal) {
+        // the reference's own operation order (svm.cpp:329-368 k_function: d = x - y, sum += d * d in index order; :2511-2515 svm_predict_values:
+        // sum += coef * k in support-vector order, then - rho), every operation rounded on its own (g++ on x86-64 does not contract to FMA):
+        // what mipgen_accel prints for the scores that sit on a rounding boundary of the 6 printed digits (accel.hip: fix_print_boundaries)
+        double total = 0.0;
+        for (int base = 0; base < n_sv; base += CAND_THREADS) {
+            const int i = base + tid;
+            double term = 0.0;
+            if (i < n_sv) {
+                const double* sv = model + (int64_t)i * SV_ROW;
+                double sum = 0.0;
+                for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
+                    const double d = __dsub_rn(s_x[j], sv[j]);
+                    sum = __dadd_rn(sum, __dmul_rn(d, d));
+                }
+                sum = __dadd_rn(sum, sv[SVR_N_EXTRA]);
+                term = __dmul_rn(sv[SVR_COEF], exp(__dmul_rn(-gamma, sum)));
+            }
+            s_term[tid] = term;
+            __syncthreads();
+            if (tid == 0) { const int m = min(CAND_THREADS, n_sv - base); for (int q = 0; q < m; q++) total = __dadd_rn(total, s_term[q]); }
+            __syncthreads();
+        }
+        if (tid == 0) scores[blockIdx.x] = __dsub_rn(total, rho);
+        return;
+    }
     // SVR: lanes own support vectors; 192-dimension walk in index order, then shuffle reduction
     double part = 0.0;
     for (int i = tid; i < n_sv; i += CAND_THREADS) {
@@ -405,11 +434,115 @@ extern "C" hipError_t mipgen_launch_features_batch(hipStream_t stream, int n, co
 extern "C" hipError_t mipgen_launch_candidates(
     hipStream_t stream, int n, const DevParams* P, const DevRegion* regions, const mipgen_candidate* cands, const uint8_t* bases,
     const int32_t* copy, const uint8_t* unmap, const HostConsts* HC, const double* model, int n_sv, double gamma, double rho,
-    int method, double* scores, uint64_t* records, double* features, mipgen_candidate_ints* ints)
+    int method, double* scores, uint64_t* records, double* features, mipgen_candidate_ints* ints, int literal, const unsigned int* n_dev)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_candidates, dim3(n), dim3(CAND_THREADS), 0, stream, P, regions, cands, bases, copy, unmap, HC, model,
-                       n_sv, gamma, rho, method, scores, records, features, ints);
+                       n_sv, gamma, rho, method, scores, records, features, ints, literal, n_dev);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Scores on a rounding boundary of the printed digits.  The front end prints scores with 6 significant digits (mipgen.cpp:774: default
+// ostream precision); a dense SVR score differs from the reference's double by ~1e-12 (another summation order, table factors), so a
+// score within that distance of a midpoint between two 6-digit numbers could print another last digit.  k_print_boundary_scan lists the
+// dense-grid candidates of a window whose score lies within tol of such a midpoint (guard / zero-copy candidates carry exact constants and
+// are skipped); they are re-scored by k_candidates in the reference's own operation order and written back (k_scatter_scores).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_print_boundary_scan(const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, int r0, int r1,
+                                                             const double* __restrict__ scores, const uint64_t* __restrict__ records, int64_t n,
+                                                             double tol_rel, double tol_abs, mipgen_candidate* __restrict__ out, int64_t* __restrict__ out_idx,
+                                                             unsigned int* __restrict__ count, unsigned int cap)
+{
+    const int A = P->n_pairs;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const double s = scores[idx];
+        const double a = fabs(s);
+        if (!(a > 1e-300) || !(a < 1e300)) continue;                        // 0, NaN, inf
+        // 6 significant digits: unit = 10^(floor(log10 a) - 5); midpoints are (k + 0.5) * unit
+        int e10 = (int)floor(log10(a));
+        double unit = pow(10.0, (double)(e10 - 5));
+        double t = a / unit;
+        if (t >= 1e6) { unit *= 10.0; t = a / unit; } else if (t < 1e5) { unit *= 0.1; t = a / unit; }     // log10 rounding at powers of ten
+        const double frac = t - floor(t);
+        const double dist = fabs(frac - 0.5) * unit;
+        if (dist > tol_rel * a + tol_abs) continue;
+        const uint64_t rec = records[idx];
+        const uint32_t flags = MIPGEN_REC_FLAGS(rec);
+        if (!(flags & MIPGEN_FLAG_VALID) || (flags & MIPGEN_FLAG_GUARD) || MIPGEN_REC_EXT_COPY(rec) == 0 || MIPGEN_REC_LIG_COPY(rec) == 0) continue;
+        int lo = r0, hi = r1 - 1;                                           // the region of the candidate: the last one that starts at or before idx
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (regions[mid].out_off <= idx) lo = mid; else hi = mid - 1; }
+        const DevRegion& R = regions[lo];
+        const int64_t local = idx - R.out_off;
+        const int a_i = (int)(local % A);
+        const int64_t row = local / A;
+        const int strand = (int)(row & 1);
+        const int64_t rest = row >> 1;
+        const int ki = (int)(rest % R.n_sizes);
+        const int pi = (int)(rest / R.n_sizes);
+        if (pi >= R.n_pos) continue;                                        // (empty regions share an offset with their successor)
+        const unsigned int at = atomicAdd(count, 1u);
+        if (at < cap) {
+            mipgen_candidate c;
+            c.region = lo; c.scan_start = R.first_pos + pi; c.capture_size = P->max_capture - (R.k0 + ki) * P->inc;
+            c.ext_len = P->arm_ext[a_i]; c.lig_len = P->arm_lig[a_i]; c.strand = strand;
+            out[at] = c; out_idx[at] = idx;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_scores(const double* __restrict__ src, const int64_t* __restrict__ idx, int cap, const unsigned int* __restrict__ n_dev,
+                                                        double* __restrict__ scores)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap && (unsigned int)i < *n_dev) scores[idx[i]] = src[i];
+}
+
+// the same test over a candidate LIST (mixed designs: the survivors re-scored by the matrix-core scorer): entry i of the list
+__global__ __launch_bounds__(256) void k_print_boundary_scan_list(const mipgen_candidate* __restrict__ cands, const double* __restrict__ scores,
+                                                                  const uint64_t* __restrict__ records, int n, double tol_rel, double tol_abs,
+                                                                  mipgen_candidate* __restrict__ out, int64_t* __restrict__ out_idx,
+                                                                  unsigned int* __restrict__ count, unsigned int cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s = scores[i];
+    const double a = fabs(s);
+    if (!(a > 1e-300) || !(a < 1e300)) return;
+    int e10 = (int)floor(log10(a));
+    double unit = pow(10.0, (double)(e10 - 5));
+    double t = a / unit;
+    if (t >= 1e6) { unit *= 10.0; t = a / unit; } else if (t < 1e5) { unit *= 0.1; t = a / unit; }
+    const double frac = t - floor(t);
+    if (fabs(frac - 0.5) * unit > tol_rel * a + tol_abs) return;
+    const uint64_t rec = records[i];
+    const uint32_t flags = MIPGEN_REC_FLAGS(rec);
+    if (!(flags & MIPGEN_FLAG_VALID) || (flags & MIPGEN_FLAG_GUARD) || MIPGEN_REC_EXT_COPY(rec) == 0 || MIPGEN_REC_LIG_COPY(rec) == 0) return;
+    const unsigned int at = atomicAdd(count, 1u);
+    if (at < cap) { out[at] = cands[i]; out_idx[at] = i; }
+}
+
+extern "C" hipError_t mipgen_launch_print_boundary_scan(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, const double* scores,
+                                                        const uint64_t* records, int64_t n, double tol_rel, double tol_abs, mipgen_candidate* out,
+                                                        int64_t* out_idx, unsigned int* count, unsigned int cap, int n_cu)
+{
+    if (n <= 0 || r1 <= r0) return hipSuccess;
+    const int64_t want = (n + 255) / 256;
+    const unsigned grid = (unsigned)std::min<int64_t>(want, (int64_t)std::max(n_cu, 1) * 16);
+    hipLaunchKernelGGL(k_print_boundary_scan, dim3(grid), dim3(256), 0, stream, P, regions, r0, r1, scores, records, n, tol_rel, tol_abs, out, out_idx, count, cap);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t stream, const mipgen_candidate* cands, const double* scores, const uint64_t* records, int n,
+                                                             double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_print_boundary_scan_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cands, scores, records, n, tol_rel, tol_abs, out, out_idx, count, cap);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_scatter_scores(hipStream_t stream, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores)
+{
+    if (cap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_scores, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src, idx, cap, n_dev, scores);
     return hipGetLastError();
 }
 

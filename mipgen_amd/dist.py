@@ -15,8 +15,25 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
+def region_cost(dense_candidates: Sequence[int], n_pos: Sequence[int], n_sizes: Sequence[int], n_e: int, n_l: int, inc: int, sum_range: int,
+                svr: bool) -> np.ndarray:
+    """Relative device time per region = the shard weights (the same rule as mipgen_amd/host/design.cpp: region_cost): the dense-grid
+    candidates and, for the dense SVR scorer, the factor-table entries it builds per support vector at the kernel's instruction budget (~47 VALU
+    per table entry against ~2.7 per candidate: mipgen_amd/csrc/accel.hip: build_svr_tiles) - exons with few capture sizes cost more per
+    candidate than their dense-grid size says.  sum_range = max arm sum - min arm sum."""
+    cand = np.asarray(dense_candidates, dtype=np.float64)
+    if not svr:
+        return cand
+    K = np.asarray(n_sizes, dtype=np.float64)
+    P = np.asarray(n_pos, dtype=np.float64)
+    ssr = (np.minimum(K, 9) - 1) * inc + sum_range + 1
+    runs = np.ceil(K / 9.0)
+    ent = 2.0 * runs * (P * (n_e + n_l) + P * ssr)
+    return 2.7 * cand + 47.0 * ent
+
+
 def shard_regions(weights: Sequence[int], world: int) -> List[Tuple[int, int]]:
-    """Contiguous region ranges [lo, hi) per rank, balanced by the given weights (dense-grid candidate counts).
+    """Contiguous region ranges [lo, hi) per rank, balanced by the given weights (dense-grid candidate counts or region_cost).
     Contiguity keeps the reference's region order, which the sequential pick stage on rank 0 needs."""
     n = len(weights)
     total = float(sum(weights))

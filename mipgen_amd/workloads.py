@@ -208,12 +208,23 @@ def build_exome(acc: Optional[capi.Accel], chrom_len: Dict[str, int], ivs: Seque
     return out
 
 
-def dense_candidates(ivs: Sequence[synth.Interval], params: capi.Params) -> np.ndarray:
-    """Dense-grid size of every interval (the shard weights of mipgen_amd.dist.shard_regions): mipgen.cpp:421-429."""
+def shard_weights(ivs: Sequence[synth.Interval], params: capi.Params, svr: bool) -> np.ndarray:
+    """Relative device time of every interval (mipgen_amd.dist.region_cost): what contiguous region ranges are balanced by."""
+    from . import dist as mdist
+    pairs = capi.arm_pairs_of(params)
+    sums = [e + l for e, l in pairs]
+    cand, n_pos, n_sizes = dense_candidates(ivs, params, detail=True)
+    return mdist.region_cost(cand, n_pos, n_sizes, len({e for e, _ in pairs}), len({l for _, l in pairs}), params.capture_increment, max(sums) - min(sums), svr)
+
+
+def dense_candidates(ivs: Sequence[synth.Interval], params: capi.Params, detail: bool = False):
+    """Dense-grid size of every interval: mipgen.cpp:421-429 (detail: also the scan positions and surviving capture sizes)."""
     pairs = capi.arm_pairs_of(params)
     max_sum = max(e + l for e, l in pairs)
     K = capi.n_sizes_all(params)
     out = np.empty(len(ivs), dtype=np.int64)
+    npos = np.empty(len(ivs), dtype=np.int64)
+    nk = np.empty(len(ivs), dtype=np.int64)
     for i, iv in enumerate(ivs):
         sf, ef = iv.bed_start + 1, iv.bed_end
         cur = max(0, sf - params.max_capture_size + max_sum)
@@ -225,4 +236,6 @@ def dense_candidates(ivs: Sequence[synth.Interval], params: capi.Params) -> np.n
             else:
                 break
         out[i] = max(0, ef - cur) * (K - k0) * len(pairs) * 2
-    return out
+        npos[i] = max(0, ef - cur)
+        nk[i] = K - k0
+    return (out, npos, nk) if detail else out

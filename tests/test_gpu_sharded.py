@@ -83,3 +83,45 @@ def test_sharded_survivors_through_rank0_pick(name, tmp_path):
     for w in ("one", "two"):
         H.compare_outputs(meta, str(tmp_path / w), keys=("picked_mips", "snp_mips"), check_all=False)
     assert c1["picked"] == meta["lines"]["picked_mips"] - 1 and c1["all_mips"] == meta["lines"]["all_mips"] - 1
+
+
+def test_bench_two_ranks_strong_scaling_child_process():
+    """bench.py --gpus 2: the launcher path the driver's SCALE run takes (one process per GPU over RCCL, the exome BED cut two ways by the
+    region cost model, one gather of the condensed survivors per step).  Runs as a CHILD process - a GPU-initialised process never execs -
+    and only where two devices are visible."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--regions", "2048", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "exome200k" in line["config"]["workload"]
+    assert line["parity_checked"] is True and line["value"] > 0
+    assert line["config"]["survivors_gathered_per_step"] > 0
+
+
+def test_region_cost_weights_balance_the_svr_shards():
+    """The shard weights follow the SVR kernel's cost model (table entries + candidates), not the raw dense-grid size: the two shards of an
+    exome-shaped batch take the same k_svr_dense time within 10 %."""
+    from mipgen_amd import workloads
+    P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
+    chrom_len, all_iv = workloads.exome_layout()
+    ivs = all_iv[:1536]
+    w = workloads.shard_weights(ivs, P, True)
+    (lo0, hi0), (lo1, hi1) = mdist.shard_regions(w.tolist(), 2)
+    ms = []
+    for lo, hi in ((lo0, hi0), (lo1, hi1)):
+        acc = capi.Accel(P)
+        acc.load_model_file(workloads.svr_model_path("/tmp/mipgen_test_models", workloads.practice62()[0], 256))
+        acc.upload(workloads.build_exome(acc, chrom_len, ivs[lo:hi], P))
+        acc.set_timing(True)
+        acc.score_condense_all(capi.SCORE_SVR)
+        acc.score_condense_all(capi.SCORE_SVR)
+        ms.append(acc.last_kernel_ms(0))
+        acc.close()
+    assert abs(ms[0] - ms[1]) <= 0.10 * max(ms), ms
