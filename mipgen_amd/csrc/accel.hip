@@ -38,6 +38,9 @@ hipError_t mipgen_launch_print_boundary_scan(hipStream_t, const DevParams*, cons
 hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t, const mipgen_candidate* cands, const double* scores, const uint64_t* records, int n, double tol_rel,
                                                   double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
 hipError_t mipgen_launch_scatter_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores);
+hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t, const DevParams*, const DevRegion*, int r0, int r1, const mipgen_survivor* surv, int64_t n, int64_t cand0,
+                                                  double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
+hipError_t mipgen_launch_scatter_surv_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
@@ -1078,7 +1081,26 @@ static int fix_print_boundaries(mipgen_accel* h, int r0, int r1, const mipgen_ca
     return MIPGEN_OK;
 }
 
-static int score_window_impl(mipgen_accel* h, int w, int32_t method)
+// the silent path (mipgen_accel_score_condense_all): only the condensed survivors of the window are ever printed, so only they are tested
+// and re-scored (2 per scan position instead of the whole dense grid); the value goes into the survivor's score field
+static int fix_print_boundaries_survivors(mipgen_accel* h, int w)
+{
+    const Window& W = h->windows[(size_t)w];
+    const int64_t n = 2 * W.n_pos;
+    if (!h->print_exact || n <= 0 || h->n_sv <= 0) return MIPGEN_OK;
+    const unsigned int cap = (unsigned int)std::min<int64_t>(n / 256 + 1024, (int64_t)1 << 22);
+    if (h->pb_cands.reserve(cap) || h->pb_idx.reserve(cap) || h->pb_scores.reserve(cap) || h->pb_count.reserve(1)) return MIPGEN_E_NOMEM;
+    const double tol_rel = 1e-10, tol_abs = 1e-13 * std::max(1.0, h->sum_abs_coef);
+    mipgen_survivor* surv = h->survivors.p + 2 * W.pos0;
+    HIP_TRY(hipMemsetAsync(h->pb_count.p, 0, sizeof(unsigned int), h->stream));
+    HIP_TRY(mipgen_launch_print_boundary_scan_surv(h->stream, h->dp, h->regions.p, W.r0, W.r1, surv, n, W.cand0, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap));
+    HIP_TRY(mipgen_launch_candidates(h->stream, (int)cap, h->dp, h->regions.p, h->pb_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
+                                     h->gamma, h->rho, MIPGEN_SCORE_SVR, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
+    HIP_TRY(mipgen_launch_scatter_surv_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, surv));
+    return MIPGEN_OK;
+}
+
+static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_dense = true)
 {
     if (method == MIPGEN_SCORE_SVR && !h->svr_geometry_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_geometry_error.c_str());
     if (int rc = ensure_tiles(h, method)) return rc;
@@ -1103,7 +1125,7 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method)
         HIP_TRY(mipgen_launch_svr_dense(h->stream, W.n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p,
                                         h->svr_tiles.p + W.svr_tile0, h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */,
                                         h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, split, h->partials.p));
-        if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand)) return rc;
+        if (fix_dense) { if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand)) return rc; }
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[2], h->stream)); h->ev_used[(size_t)w] |= 1; }
     h->cur_window = w; h->scored = true; h->replayed = false;
@@ -1171,8 +1193,9 @@ int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
     HIP_TRY(hipSetDevice(h->device));
     std::fill(h->ev_used.begin(), h->ev_used.end(), 0);
     for (int w = 0; w < (int)h->windows.size(); w++) {
-        if (int rc = score_window_impl(h, w, method)) return rc;
+        if (int rc = score_window_impl(h, w, method, false)) return rc;
         if (int rc = replay_window_impl(h, false)) return rc;
+        if (method == MIPGEN_SCORE_SVR) { if (int rc = fix_print_boundaries_survivors(h, w)) return rc; }
         if (int rc = collapse_window_impl(h)) return rc;
     }
     return MIPGEN_OK;

@@ -449,6 +449,32 @@ extern "C" hipError_t mipgen_launch_candidates(
 // dense-grid candidates of a window whose score lies within tol of such a midpoint (guard / zero-copy candidates carry exact constants and
 // are skipped); they are re-scored by k_candidates in the reference's own operation order and written back (k_scatter_scores).
 // ---------------------------------------------------------------------------------------------------------
+
+// distance of |s| to the nearest midpoint between two 6-significant-digit decimal numbers (what "%g" / the default ostream precision prints,
+// mipgen.cpp:774), relative test against tol: decade from the binary exponent + a table for 1e-13 .. 1e13, log10 / pow outside
+__device__ __forceinline__ bool near_print_midpoint(double s, double tol_rel, double tol_abs)
+{
+    const double a = fabs(s);
+    if (!(a > 1e-300) || !(a < 1e300)) return false;                        // 0, NaN, inf
+    double unit;
+    if (a >= 1e-8 && a < 1e8) {
+        constexpr double P10[32] = {1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e0,
+                                    1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
+        const int e2 = (int)((__double2hiint(a) >> 20) & 0x7FF) - 1023;
+        int e10 = (e2 * 1233) >> 12;                                        // ~ floor(e2 * log10(2)), off by at most one
+        if (a < P10[e10 + 15]) e10--; else if (a >= P10[e10 + 16]) e10++;
+        unit = P10[e10 + 10];                                               // 10^(e10 - 5)
+    } else {
+        int e10 = (int)floor(log10(a));
+        unit = pow(10.0, (double)(e10 - 5));
+        const double t0 = a / unit;
+        if (t0 >= 1e6) unit *= 10.0; else if (t0 < 1e5) unit *= 0.1;        // log10 rounding at powers of ten
+    }
+    const double t = a / unit;
+    const double frac = t - floor(t);
+    return fabs(frac - 0.5) * unit <= tol_rel * a + tol_abs;
+}
+
 __global__ __launch_bounds__(256) void k_print_boundary_scan(const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, int r0, int r1,
                                                              const double* __restrict__ scores, const uint64_t* __restrict__ records, int64_t n,
                                                              double tol_rel, double tol_abs, mipgen_candidate* __restrict__ out, int64_t* __restrict__ out_idx,
@@ -456,17 +482,7 @@ __global__ __launch_bounds__(256) void k_print_boundary_scan(const DevParams* __
 {
     const int A = P->n_pairs;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        const double s = scores[idx];
-        const double a = fabs(s);
-        if (!(a > 1e-300) || !(a < 1e300)) continue;                        // 0, NaN, inf
-        // 6 significant digits: unit = 10^(floor(log10 a) - 5); midpoints are (k + 0.5) * unit
-        int e10 = (int)floor(log10(a));
-        double unit = pow(10.0, (double)(e10 - 5));
-        double t = a / unit;
-        if (t >= 1e6) { unit *= 10.0; t = a / unit; } else if (t < 1e5) { unit *= 0.1; t = a / unit; }     // log10 rounding at powers of ten
-        const double frac = t - floor(t);
-        const double dist = fabs(frac - 0.5) * unit;
-        if (dist > tol_rel * a + tol_abs) continue;
+        if (!near_print_midpoint(scores[idx], tol_rel, tol_abs)) continue;
         const uint64_t rec = records[idx];
         const uint32_t flags = MIPGEN_REC_FLAGS(rec);
         if (!(flags & MIPGEN_FLAG_VALID) || (flags & MIPGEN_FLAG_GUARD) || MIPGEN_REC_EXT_COPY(rec) == 0 || MIPGEN_REC_LIG_COPY(rec) == 0) continue;
@@ -506,15 +522,7 @@ __global__ __launch_bounds__(256) void k_print_boundary_scan_list(const mipgen_c
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double s = scores[i];
-    const double a = fabs(s);
-    if (!(a > 1e-300) || !(a < 1e300)) return;
-    int e10 = (int)floor(log10(a));
-    double unit = pow(10.0, (double)(e10 - 5));
-    double t = a / unit;
-    if (t >= 1e6) { unit *= 10.0; t = a / unit; } else if (t < 1e5) { unit *= 0.1; t = a / unit; }
-    const double frac = t - floor(t);
-    if (fabs(frac - 0.5) * unit > tol_rel * a + tol_abs) return;
+    if (!near_print_midpoint(scores[i], tol_rel, tol_abs)) return;
     const uint64_t rec = records[i];
     const uint32_t flags = MIPGEN_REC_FLAGS(rec);
     if (!(flags & MIPGEN_FLAG_VALID) || (flags & MIPGEN_FLAG_GUARD) || MIPGEN_REC_EXT_COPY(rec) == 0 || MIPGEN_REC_LIG_COPY(rec) == 0) return;
@@ -532,6 +540,62 @@ extern "C" hipError_t mipgen_launch_print_boundary_scan(hipStream_t stream, cons
     hipLaunchKernelGGL(k_print_boundary_scan, dim3(grid), dim3(256), 0, stream, P, regions, r0, r1, scores, records, n, tol_rel, tol_abs, out, out_idx, count, cap);
     return hipGetLastError();
 }
+
+// the same test over the condensed survivors of a window (silent designs print nothing else): entry i of the survivor array; the re-scored
+// value goes back into the survivor's score field
+__global__ __launch_bounds__(256) void k_print_boundary_scan_surv(const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, int r0, int r1,
+                                                                  const mipgen_survivor* __restrict__ surv, int64_t n, int64_t cand0, double tol_rel, double tol_abs,
+                                                                  mipgen_candidate* __restrict__ out, int64_t* __restrict__ out_idx,
+                                                                  unsigned int* __restrict__ count, unsigned int cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mipgen_survivor sv = surv[i];
+    if (sv.cand_index < 0 || !near_print_midpoint(sv.score, tol_rel, tol_abs)) return;
+    const uint32_t flags = MIPGEN_REC_FLAGS(sv.record);
+    if (!(flags & MIPGEN_FLAG_VALID) || (flags & MIPGEN_FLAG_GUARD) || MIPGEN_REC_EXT_COPY(sv.record) == 0 || MIPGEN_REC_LIG_COPY(sv.record) == 0) return;
+    const int64_t idx = sv.cand_index - cand0;                             // window-relative, like DevRegion::out_off
+    const int A = P->n_pairs;
+    int lo = r0, hi = r1 - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (regions[mid].out_off <= idx) lo = mid; else hi = mid - 1; }
+    const DevRegion& R = regions[lo];
+    const int64_t local = idx - R.out_off;
+    const int a_i = (int)(local % A);
+    const int64_t row = local / A;
+    const int64_t rest = row >> 1;
+    const int ki = (int)(rest % R.n_sizes), pi = (int)(rest / R.n_sizes);
+    if (pi >= R.n_pos) return;
+    const unsigned int at = atomicAdd(count, 1u);
+    if (at < cap) {
+        mipgen_candidate c;
+        c.region = lo; c.scan_start = R.first_pos + pi; c.capture_size = P->max_capture - (R.k0 + ki) * P->inc;
+        c.ext_len = P->arm_ext[a_i]; c.lig_len = P->arm_lig[a_i]; c.strand = (int)(row & 1);
+        out[at] = c; out_idx[at] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_surv_scores(const double* __restrict__ src, const int64_t* __restrict__ idx, int cap, const unsigned int* __restrict__ n_dev,
+                                                             mipgen_survivor* __restrict__ surv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap && (unsigned int)i < *n_dev) surv[idx[i]].score = src[i];
+}
+
+extern "C" hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, const mipgen_survivor* surv,
+                                                             int64_t n, int64_t cand0, double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx,
+                                                             unsigned int* count, unsigned int cap)
+{
+    if (n <= 0 || r1 <= r0) return hipSuccess;
+    hipLaunchKernelGGL(k_print_boundary_scan_surv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, regions, r0, r1, surv, n, cand0, tol_rel, tol_abs, out, out_idx, count, cap);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_scatter_surv_scores(hipStream_t stream, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv)
+{
+    if (cap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_surv_scores, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src, idx, cap, n_dev, surv);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t stream, const mipgen_candidate* cands, const double* scores, const uint64_t* records, int n,
                                                              double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap)
 {
