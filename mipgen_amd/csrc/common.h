@@ -134,7 +134,6 @@ struct SvrGeom {
 #define SVR_N_ARR 7          // prefix arrays per support vector: insert 1/2/3-mers, upstream arm 1/2-mers, downstream arm 1/2-mers
 struct SvrLayout {
     int rinv, lg10, rows, pf, tb, it;          // SV-independent: reciprocals, log10(0..101); then the buffers
-    int ent_n, ni;                             // window norms (f64, pre-scaled by -gamma*log2 e): arm-window entries [n_ent], inserts [np][ssr]
     // the seven prefix arrays of a PF block (len+1 slots each) are described by svr_arr_len / svr_arr_off / svr_arr_chunk
     // below: plain scalars only, so that the device copy of this struct stays in SGPRs (an indexed member would put it in scratch)
     int ku, kd, ci, pf_stride;                 // PF block: per-length constants, insert constant; slots per SV
@@ -145,6 +144,7 @@ struct SvrLayout {
                                                // descriptors (2 x u32), per-slot SV-row indices of the scans (2 x u16), bases (u8),
                                                // arm-pair sums (u16)
     int n_ent;                                 // arm-window table entries per SV
+    int n_ent_lds;                             // descriptors kept in LDS (all of them: registers are at their budget)
     int total_bytes;
     int nq, ins_len, up_cnt, dn_cnt, span_b, rinv_len;
     int ins_sl, up_sl, dn_sl;                  // slots of one insert / upstream / downstream prefix array: len + 1 rounded up to 16 * (2k + 1)
@@ -178,7 +178,7 @@ __attribute__((always_inline)) static inline int svr_arr_chunk(const SvrLayout& 
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-__attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group, int n_up, int n_dn)
+__attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ssmin, int ssmax, int Lmax, int n_arm, int group, int n_up, int n_dn, int n_threads)
 {
     SvrLayout L;
     const int ssr = ssmax - ssmin + 1;
@@ -210,11 +210,10 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.tb = o; o += group * L.tb_stride;
     L.ssr_p = ssr | 1;
     L.it = o; o += group * np * L.ssr_p;
-    L.ent_n = o; o += L.n_ent;                          // window norms stay in f64: no precision is given away before the exponentials
-    L.ni = o; o += np * ssr;
     int bytes = o * 8;
     L.bytes_desc = bytes; bytes += SVR_N_ARR * 16 * 4;
-    L.bytes_ent = bytes; bytes += 2 * L.n_ent * 4;     // per entry: packed slots, packed fields
+    L.n_ent_lds = L.n_ent; (void)n_threads;
+    L.bytes_ent = bytes; bytes += 2 * L.n_ent_lds * 4; // per entry: packed slots, packed fields
     L.bytes_psum = bytes; bytes += 2 * SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64) + 16;   // + the work counter of the table stage
     bytes = (bytes + 15) & ~15;
     L.bytes_idx = bytes;                               // u32 per slot: byte offset of the SV-row slot it gathers
