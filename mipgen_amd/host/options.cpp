@@ -63,8 +63,8 @@ static const char* k_doc =
     "  -logistic_priority_score f (0.9)  -svr_priority_score f (1.5)\n"
     "misc\n"
     "  -silent_mode on   skip the all_mips / collapsed_mips files\n"
-    "  -gpu_copy_counter on   (extension) arm copy numbers = exact occurrences in -genome_dir / the indexed fasta, counted on the GPU;\n"
-    "                         bwa is not run and the whole-window uniqueness flag is not set\n"
+    "  -gpu_copy_counter on   (extension) arm copy numbers = exact occurrences in the whole -bwa_genome_index fasta (else every chr*.fa of -genome_dir),\n"
+    "                         capture-window uniqueness (mapping flag) = no other locus within one substitution; both on the GPU, bwa is not run\n"
     "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n";
 
 static void set_defaults(Options& o)
