@@ -38,3 +38,27 @@ def test_two_rank_gather_over_gloo(tmp_path):
     res = json.load(open(out))
     assert res["ok"] and res["total"] == res["expected_total"]
     assert len(res["shards"]) == 2 and res["shards"][0][1] == res["shards"][1][0]
+
+
+def test_region_cost_weights_and_contiguous_shards():
+    """Shard weights follow the kernels' cost model (mipgen_amd/dist.py: region_cost = design.cpp: region_cost): for SVR designs a region with few
+    capture sizes costs more per candidate than its dense-grid size says; logistic weights are the dense counts; shards stay contiguous and cover
+    every region once."""
+    import numpy as np
+    from mipgen_amd import capi, dist as mdist, workloads
+    P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
+    _, ivs = workloads.exome_layout()
+    ivs = ivs[:3000]
+    dense = workloads.dense_candidates(ivs, P)
+    w_svr = workloads.shard_weights(ivs, P, True)
+    w_log = workloads.shard_weights(ivs, P, False)
+    assert np.array_equal(w_log, dense.astype(np.float64))
+    cand, n_pos, n_sizes = workloads.dense_candidates(ivs, P, detail=True)
+    per_cand = w_svr / np.maximum(cand, 1)
+    few, many = per_cand[(n_sizes == 1) & (cand > 0)], per_cand[(n_sizes == n_sizes.max()) & (cand > 0)]
+    assert few.size and many.size and few.min() > many.max()            # K = 1 exons: more table entries per candidate
+    for world in (2, 3, 8):
+        sh = mdist.shard_regions(w_svr.tolist(), world)
+        assert sh[0][0] == 0 and sh[-1][1] == len(ivs) and all(a[1] == b[0] for a, b in zip(sh, sh[1:])) and all(hi > lo for lo, hi in sh)
+        tot = [w_svr[lo:hi].sum() for lo, hi in sh]
+        assert max(tot) / (sum(tot) / world) < 1.05
