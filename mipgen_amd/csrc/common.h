@@ -140,6 +140,7 @@ struct SvrLayout {
     int tj, ti;                                // PF block: junction terms [18], insert scan-size terms [ssr] (per SV, like the rest of the block)
     int tu, td, tb_stride;                     // TB block: first upstream / downstream slot; slots per SV
     int ssr_p;                                 // IT row pitch in slots (scan-size range rounded up to odd: bank spread)
+    int bytes_kpar;                            // 16 ints: the scalars of the window-norm pass after the SV loop
     int bytes_desc, bytes_ent, bytes_idx, bytes_sb, bytes_psum;   // byte offsets: scan descriptors (int), table-entry
                                                // descriptors (2 x u32), per-slot SV-row indices of the scans (2 x u16), bases (u8),
                                                // arm-pair sums (u16)
@@ -216,6 +217,7 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.bytes_ent = bytes; bytes += 2 * L.n_ent_lds * 4; // per entry: packed slots, packed fields
     L.bytes_psum = bytes; bytes += 2 * SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64) + 16;   // + the work counter of the table stage
     bytes = (bytes + 15) & ~15;
+    L.bytes_kpar = bytes; bytes += 64;
     L.bytes_idx = bytes;                               // u32 per slot: byte offset of the SV-row slot it gathers
     bytes += 4 * (3 * L.ins_sl + 2 * L.up_sl + 2 * L.dn_sl);
     L.bytes_sb = bytes; bytes += L.span_b + 8;
