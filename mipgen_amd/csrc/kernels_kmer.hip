@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_kmer_insert(const char* __restrict__ se
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     walk(seq, i, len, P, [&](int slot, uint64_t key) {
-        if (slot == 0) { const uint32_t b = filter_index(key, P.filter_bits); atomicOr(&filter[b >> 5], 1u << (b & 31)); }   // canonical kmin-mer of this position
+        if (slot == 0) { const uint32_t b = P.k[0] <= 16 ? filter_index32((uint32_t)key, P.filter_bits) : filter_index(key, P.filter_bits); atomicOr(&filter[b >> 5], 1u << (b & 31)); }   // canonical kmin-mer of this position
         uint64_t* part = keys + (uint64_t)slot * (P.cap_mask + 1);
         uint64_t h = mix64(key) & P.cap_mask;
         for (;;) {
@@ -51,99 +51,163 @@ __global__ __launch_bounds__(256) void k_kmer_fold(const uint32_t* __restrict__ 
     if ((threadIdx.x & 63) == 0) { folded[B >> 5] = (uint32_t)m; folded[(B >> 5) + 1] = (uint32_t)(m >> 32); }
 }
 
-__global__ __launch_bounds__(256) void k_kmer_count(const char* __restrict__ genome, int64_t len, KmerParams P, const uint64_t* __restrict__ keys,
-                                                    const uint32_t* __restrict__ filter, const uint32_t* __restrict__ folded,
-                                                    unsigned int* __restrict__ counts)
+// bit pairs of x in reverse order (pair 0 <-> pair 31): a 2-bit packed k-mer read backwards
+__device__ __forceinline__ uint64_t pair_reverse64(uint64_t x)
 {
+    x = __brevll(x);
+    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+
+// The genome pass.  Persistent workgroups of KMER_THREADS threads walk chunks of KMER_CHUNK window starts.  A chunk is staged as 2 bits per base
+// (16 bases per word, base i at bits 2i) + one "not ACGT" bit per base, double buffered: the 16-byte global loads of the NEXT chunk are in flight
+// while this one is scanned.  A thread owns 16 consecutive window starts: its first kmin-1 bases are placed directly (the packed word IS the
+// reverse-complement key up to a complement; the forward key is its pair reversal), then 16 rolling updates with compile-time register indices -
+// on 32-bit words when the shortest requested length is <= 16 (K32: the default arm lengths start at 16), else on 64-bit ones.
+template <bool K32>
+__global__ __launch_bounds__(KMER_THREADS, 6) void k_kmer_count(const char* __restrict__ genome, int64_t len, KmerParams P, const uint64_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ filter, const uint32_t* __restrict__ folded,
+                                                             unsigned int* __restrict__ counts)
+{
+    constexpr int NV = (KMER_CHUNK + 48) / 16;                            // 16-base words of a chunk: its window starts + the 48 bases behind them
     __shared__ uint32_t s_bits[1 << (KMER_LDS_BITS - 5)];                 // fold of the filter: bit b = OR of the filter bits with hash prefix b
-    __shared__ uint8_t s_code[KMER_CHUNK + 64];                           // base codes of the chunk (+ the bases the last windows reach into)
-    __shared__ uint32_t s_queue[KMER_CHUNK];                              // chunk-relative positions that passed the LDS filter
-    __shared__ uint32_t s_nq;
+    __shared__ uint32_t s_pk[2][NV + 1];                                  // 2-bit base codes
+    __shared__ uint16_t s_bad[2][NV + 3];                                 // bit i: base i of the word is not ACGT
+    constexpr uint32_t QCAP = KMER_CHUNK * 3 / 4;                         // (three workgroups per compute unit: 51 KB each)
+    __shared__ uint16_t s_queue[QCAP];                                    // chunk-relative positions that passed the filter; the overflow is walked in place
+    __shared__ uint32_t s_nq[2];
     const int tid = threadIdx.x;
     const int kmin = P.k[0];
     const uint64_t kmask = kmin >= 32 ? ~0ull : ((1ull << (2 * kmin)) - 1);
     // the LDS fold pays while it rejects most positions: up to ~2^16 region positions (then <= 22 % pass it)
     const bool use_fold = P.filter_bits <= KMER_LDS_BITS + 3;
-    if (use_fold) for (int w = tid; w < (1 << (KMER_LDS_BITS - 5)); w += 256) s_bits[w] = folded[w];      // the 32 KB fold of the filter (k_kmer_fold)
+    if (use_fold) for (int w = tid; w < (1 << (KMER_LDS_BITS - 5)); w += KMER_THREADS) s_bits[w] = folded[w];      // the 32 KB fold of the filter (k_kmer_fold)
+    if (tid < 2) s_nq[tid] = 0;
     const int64_t n_chunks = (len + KMER_CHUNK - 1) / KMER_CHUNK;
-    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const int64_t g0 = c * KMER_CHUNK;
-        __syncthreads();                                                   // the fold is complete / the previous chunk's queue is drained
-        if (tid == 0) s_nq = 0;
-        {
-            // 16 bytes per thread (the chunk starts on a multiple of 4096 of a 256-byte aligned buffer), the 48 bytes behind it by three more loads
-            for (int v = tid; v < (KMER_CHUNK + 48) / 16; v += 256) {
-                const int64_t g = g0 + (int64_t)v * 16;
-                uint32_t w[4] = {0, 0, 0, 0};
-                if (g + 16 <= len) { const uint4 q = *(const uint4*)(genome + g); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
-                else for (int b = 0; b < 16; b++) if (g + b < len) w[b >> 2] |= (uint32_t)(uint8_t)genome[g + b] << (8 * (b & 3));   // (a zero byte is "other")
-                uint32_t o[4];
+
+    // 16 genome bytes of word v of chunk c (the chunk starts on a multiple of KMER_CHUNK of a 256-byte aligned buffer; bytes past the end read as 0 = "other")
+    auto fetch = [&](int64_t c, int v) -> uint4 {
+        const int64_t g = c * KMER_CHUNK + (int64_t)v * 16;
+        if (g + 16 <= len) return *(const uint4*)(genome + g);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 16; b++) if (g + b < len) w[b >> 2] |= (uint32_t)(uint8_t)genome[g + b] << (8 * (b & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    auto pack = [&](int buf, int v, const uint4& q) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint32_t pk = 0, bad = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t c4 = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) c4 |= (uint32_t)code_of((char)(w[q] >> (8 * b))) << (8 * b);
-                    o[q] = c4;
-                }
-                *(uint4*)(s_code + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-            }
+        for (int b = 0; b < 16; b++) {
+            const int c = code_of((char)(w[b >> 2] >> (8 * (b & 3))));
+            pk |= (uint32_t)(c & 3) << (2 * b);
+            bad |= (uint32_t)(c > 3) << b;
         }
-        __syncthreads();
-        // ---- one rolling kmin-mer per thread over KMER_PER_THREAD window starts ----
+        s_pk[buf][v] = pk; s_bad[buf][v] = (uint16_t)bad;
+    };
+    // a window start that passed the filter: its k-mers of every requested length against the table, shortest first
+    auto survivor = [&](int buf, int rel) {
+        uint64_t kf = 0, kr = 0;
+        int slot = 0;
+        for (int j = 0; j < P.kmax && slot < P.n_k; j++) {
+            const int at = rel + j;
+            if ((s_bad[buf][at >> 4] >> (at & 15)) & 1) break;
+            const uint64_t b = (s_pk[buf][at >> 4] >> (2 * (at & 15))) & 3u;
+            kf = (kf << 2) | b; kr |= (3 - b) << (2 * j);
+            if (j + 1 != P.k[slot]) continue;
+            const uint64_t key = kf < kr ? kf : kr;
+            const uint64_t base = (uint64_t)slot * (P.cap_mask + 1);
+            uint64_t h = mix64(key) & P.cap_mask;
+            bool found = false;
+            for (;;) {
+                const uint64_t cur = keys[base + h];
+                if (cur == key) { atomicAdd(&counts[base + h], 1u); found = true; break; }
+                if (cur == KMER_EMPTY) break;
+                h = (h + 1) & P.cap_mask;
+            }
+            // Absent at this length = absent at every longer one: a longer genome window that equals a region oligo (or its reverse complement)
+            // starts with this window, which then equals the oligo's own prefix (or the reverse complement of its suffix) - a region oligo
+            // of this length that k_kmer_insert has stored.  The filter's false positives end here after ONE dependent probe instead of n_k.
+            if (!found) break;
+            slot++;
+        }
+    };
+    // a thread stages word tid; the first threads also the NV - KMER_THREADS words behind the chunk
+    constexpr int NX = NV - KMER_THREADS;
+    int64_t c = blockIdx.x;
+    if (c < n_chunks) {
+        pack(0, tid, fetch(c, tid));
+        if (tid < NX) pack(0, KMER_THREADS + tid, fetch(c, KMER_THREADS + tid));
+    }
+    for (int it = 0; c < n_chunks; c += gridDim.x, it++) {
+        const int buf = it & 1;
+        __syncthreads();                                                   // this chunk is staged (and the fold, the first time); the previous chunk's survivors are done
+        const int64_t cn = c + gridDim.x;
+        uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = make_uint4(0, 0, 0, 0);
+        if (cn < n_chunks) { raw0 = fetch(cn, tid); if (tid < NX) raw1 = fetch(cn, KMER_THREADS + tid); }   // in flight across the scan
+        // ---- one rolling kmin-mer per thread over 16 window starts ----
         {
-            const int p0 = tid * KMER_PER_THREAD;
-            // the 48 codes this thread's windows can touch, in registers (three aligned 16-byte LDS reads)
-            uint32_t cw[12];
-#pragma unroll
-            for (int q = 0; q < 3; q++) { const uint4 v = *(const uint4*)(s_code + p0 + 16 * q); cw[4 * q] = v.x; cw[4 * q + 1] = v.y; cw[4 * q + 2] = v.z; cw[4 * q + 3] = v.w; }
-            uint64_t fwd = 0, rc = 0;
-            int run = 0;                                                   // ACGT bases since the last other byte
+            const uint32_t w0 = s_pk[buf][tid], w1 = s_pk[buf][tid + 1], w2 = s_pk[buf][tid + 2];
+            const uint64_t v01 = (uint64_t)w0 | ((uint64_t)w1 << 32);      // bases 0..31 of this thread, base j at bits 2j
+            const int pre = kmin - 1;                                      // bases before the first window end
             const int rc_shift = 2 * (kmin - 1);
-            // pass A: the filter bit index of every window start (0xFFFFFFFF = no window); with a selective LDS fold the positions it
-            // rejects never touch memory, otherwise (large designs) the filter words are fetched directly - all loads of a thread in flight
-            uint32_t fidx[KMER_PER_THREAD];
+            // bit q of `inval`: window q holds a byte that is not ACGT (a window that starts at or behind the end of the genome does: the bytes
+            // there are staged as "other") - the OR of the kmin bits from q on, by doubling
+            uint64_t inval = (uint64_t)s_bad[buf][tid] | ((uint64_t)s_bad[buf][tid + 1] << 16) | ((uint64_t)s_bad[buf][tid + 2] << 32);
+            for (int have = 1; have < kmin;) { const int sh = min(have, kmin - have); inval |= inval >> sh; have += sh; }
+            const uint32_t ok16 = ~(uint32_t)inval;
+            const int fold_shift = P.filter_bits - KMER_LDS_BITS;
+            uint32_t fidx[16];
+            if constexpr (K32) {
+                // kmin <= 16: the keys are 32-bit words (pre <= 15: the first 16 bases hold the prefix, bases pre .. pre + 15 lie inside bases 0..31)
+                const uint32_t kmask32 = kmin >= 16 ? ~0u : ((1u << (2 * kmin)) - 1u), pmask32 = (1u << (2 * pre)) - 1u;
+                uint32_t fwd = pre ? __brev(w0 & pmask32) : 0u;
+                fwd = (((fwd & 0x55555555u) << 1) | ((fwd >> 1) & 0x55555555u)) >> (pre ? 32 - 2 * pre : 0);
+                uint32_t rc = ((~w0) & pmask32) << 2;
+                const uint32_t tl = (uint32_t)(v01 >> (2 * pre));
 #pragma unroll
-            for (int q = 0; q < KMER_PER_THREAD; q++) fidx[q] = 0xFFFFFFFFu;
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t b = (tl >> (2 * q)) & 3u;
+                    fwd = ((fwd << 2) | b) & kmask32; rc = (rc >> 2) | ((3u - b) << rc_shift);
+                    // straight-line: the hash and the fold test are evaluated for every lane (any fold index is in range), one select at the end
+                    const uint32_t bi = filter_index32(min(fwd, rc), P.filter_bits);
+                    bool pass = (ok16 >> q) & 1;
+                    if (use_fold) { const uint32_t lb = bi >> fold_shift; pass = pass && ((s_bits[lb >> 5] >> (lb & 31)) & 1); }
+                    fidx[q] = pass ? bi : 0xFFFFFFFFu;
+                }
+            } else {
+                const uint64_t v12 = (uint64_t)w1 | ((uint64_t)w2 << 32);      // bases 16..47
+                const uint64_t pmask = (1ull << (2 * pre)) - 1;
+                // after `pre` rolling steps: fwd = the bases in reading order in the low 2*pre bits, rc = their complements, base j at bits 2(j+1)
+                uint64_t fwd = pair_reverse64(v01 & pmask) >> (64 - 2 * pre);  // pre >= 16 here
+                uint64_t rc = ((~v01) & pmask) << 2;
+                const uint32_t tl = (uint32_t)(v12 >> (2 * (pre - 16)));       // the 16 bases that end the 16 windows: bases pre .. pre + 15 <= 45
 #pragma unroll
-            for (int j = 0; j < KMER_PER_THREAD + KMER_MAX_K - 1; j++) {   // byte j ends the window that starts at j - (kmin - 1)
-                if (j >= kmin - 1 + KMER_PER_THREAD) continue;          // (no break: the loop must unroll for the register arrays)
-                const int b = (int)((cw[j >> 2] >> (8 * (j & 3))) & 0xFF);
-                fwd = ((fwd << 2) | (uint64_t)(b & 3)) & kmask; rc = (rc >> 2) | ((uint64_t)(3 - (b & 3)) << rc_shift);
-                run = b > 3 ? 0 : run + 1;
-                const int st = j - (kmin - 1);
-                if (st >= 0 && run >= kmin && g0 + p0 + st < len) {
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t b = (tl >> (2 * q)) & 3u;
+                    fwd = ((fwd << 2) | (uint64_t)b) & kmask; rc = (rc >> 2) | ((uint64_t)(3u - b) << rc_shift);
                     const uint32_t bi = filter_index(fwd < rc ? fwd : rc, P.filter_bits);
-                    bool pass = true;
-                    if (use_fold) { const uint32_t lb = bi >> (P.filter_bits - KMER_LDS_BITS); pass = (s_bits[lb >> 5] >> (lb & 31)) & 1; }
-                    // static register index: st = j - (kmin - 1) with kmin uniform
-#pragma unroll
-                    for (int q = 0; q < KMER_PER_THREAD; q++) if (q == st && pass) fidx[q] = bi;
+                    bool pass = (ok16 >> q) & 1;
+                    if (use_fold) { const uint32_t lb = bi >> fold_shift; pass = pass && ((s_bits[lb >> 5] >> (lb & 31)) & 1); }
+                    fidx[q] = pass ? bi : 0xFFFFFFFFu;
                 }
             }
-            uint32_t fw[KMER_PER_THREAD];
+            // the filter words of the positions the fold let through: all loads of a thread in flight
+            uint32_t fw[16];
 #pragma unroll
-            for (int q = 0; q < KMER_PER_THREAD; q++) fw[q] = fidx[q] != 0xFFFFFFFFu ? filter[fidx[q] >> 5] : 0u;
+            for (int q = 0; q < 16; q++) fw[q] = fidx[q] != 0xFFFFFFFFu ? filter[fidx[q] >> 5] : 0u;
 #pragma unroll
-            for (int q = 0; q < KMER_PER_THREAD; q++)
-                if ((fw[q] >> (fidx[q] & 31)) & 1) s_queue[atomicAdd(&s_nq, 1u)] = (uint32_t)(p0 + q);
+            for (int q = 0; q < 16; q++)
+                if ((fw[q] >> (fidx[q] & 31)) & 1) {
+                    const uint32_t at = atomicAdd(&s_nq[buf], 1u);
+                    if (at < QCAP) s_queue[at] = (uint16_t)(tid * 16 + q); else survivor(buf, tid * 16 + q);     // (a genome of repeats of the design)
+                }
         }
         __syncthreads();
-        // ---- survivors: the full filter, then every requested length against the table ----
-        const uint32_t nq = s_nq;
-        for (uint32_t q = tid; q < nq; q += 256) {
-            const int rel = (int)s_queue[q];
-            walk_codes(s_code + rel, (int)std::min<int64_t>(len - (g0 + rel), KMER_CHUNK + 48 - rel), P, [&](int slot, uint64_t key) -> bool {
-                const uint64_t base = (uint64_t)slot * (P.cap_mask + 1);
-                uint64_t h = mix64(key) & P.cap_mask;
-                for (;;) {
-                    const uint64_t cur = keys[base + h];
-                    if (cur == key) { atomicAdd(&counts[base + h], 1u); break; }
-                    if (cur == KMER_EMPTY) break;
-                    h = (h + 1) & P.cap_mask;
-                }
-                return true;
-            });
-        }
+        // ---- survivors: every requested length against the table, shortest first ----
+        const uint32_t nq = min(s_nq[buf], QCAP);
+        if (tid == 0) s_nq[buf ^ 1] = 0;                                   // the next chunk's counter (last read before this chunk's first barrier)
+        for (uint32_t q = tid; q < nq; q += KMER_THREADS) survivor(buf, (int)s_queue[q]);
+        // ---- the next chunk's bases into the other buffer (last read by the previous chunk's survivors) ----
+        if (cn < n_chunks) { pack(buf ^ 1, tid, raw0); if (tid < NX) pack(buf ^ 1, KMER_THREADS + tid, raw1); }
     }
 }
 
@@ -218,7 +282,8 @@ extern "C" hipError_t mipgen_launch_kmer_count(hipStream_t s, const char* genome
     // persistent workgroups (the LDS fold of the filter is built once per workgroup): three per compute unit, each walking chunks of KMER_CHUNK positions
     const int64_t n_chunks = (len + KMER_CHUNK - 1) / KMER_CHUNK;
     const unsigned grid = (unsigned)std::min<int64_t>(n_chunks, (int64_t)std::max(n_cu, 1) * 3);
-    hipLaunchKernelGGL(k_kmer_count, dim3(grid), dim3(256), 0, s, genome, len, *P, keys, filter, folded, counts);
+    if (P->k[0] <= 16) hipLaunchKernelGGL(k_kmer_count<true>, dim3(grid), dim3(KMER_THREADS), 0, s, genome, len, *P, keys, filter, folded, counts);
+    else hipLaunchKernelGGL(k_kmer_count<false>, dim3(grid), dim3(KMER_THREADS), 0, s, genome, len, *P, keys, filter, folded, counts);
     return hipGetLastError();
 }
 extern "C" hipError_t mipgen_launch_kmer_lookup(hipStream_t s, const char* seq, int64_t len, const KmerParams* P, const uint64_t* keys,

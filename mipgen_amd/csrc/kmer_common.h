@@ -18,14 +18,18 @@ struct KmerParams {
 };
 
 #define KMER_LDS_BITS 18               // the LDS fold of the filter: 2^18 bits = 32 KB
-#define KMER_CHUNK 4096                // genome positions per workgroup pass
-#define KMER_PER_THREAD 16             // consecutive positions per thread (256 threads)
+#define KMER_THREADS 512                // threads of a genome-pass workgroup, 16 consecutive window starts each
+#define KMER_CHUNK (KMER_THREADS * 16) // genome positions per workgroup pass
 
 namespace {
 
+// 0..3 = A C G T (either case), 4 = anything else.  Branch-free: bits 1-2 of the four letters are distinct (A 00, C 01, G 11, T 10), the byte is
+// then compared with the letter that code stands for.  (A switch compiles to divergent branches: the genome pass spent two thirds of its time in it.)
 __device__ __forceinline__ int code_of(char c)
 {
-    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+    const uint32_t x = (uint8_t)c;
+    const uint32_t code = ((x >> 1) ^ (x >> 2)) & 3u;
+    return (x & 0xDFu) == ((0x54474341u >> (8 * code)) & 0xFFu) ? (int)code : 4;
 }
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -37,6 +41,12 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 __device__ __forceinline__ uint32_t filter_index(uint64_t key, int bits)
 {
     return (uint32_t)(((key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+}
+
+// the same for designs whose shortest oligo has <= 16 bases (32-bit keys): one multiply (k_kmer_insert and k_kmer_count agree on the choice)
+__device__ __forceinline__ uint32_t filter_index32(uint32_t key, int bits)
+{
+    return ((key ^ (key >> 15)) * 0x9E3779B1u) >> (32 - bits);
 }
 
 // f returns void, or bool = "go on to the longer lengths"
