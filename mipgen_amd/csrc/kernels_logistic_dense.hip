@@ -47,18 +47,21 @@ extern "C" size_t mipgen_logistic_dense_lds_bytes(int np_all, int np, int ssr, i
 
 namespace {
 
-// Integer word of an arm window, laid out so that a candidate's record is (almost) the sum of its two windows' words:
+// Integer word of an arm window, laid out so that a candidate's record is its two windows' words combined by one ADD (the counts), one OR
+// (everything else) and one bit-field insert:
 //   low dword   copy number saturated to 16 bits, in the record's field of the window's ROLE (extension: bits 0..15, ligation: 16..31)
-//   high dword  bits 0..7 masked-sequence N count | 8..15 SNP count | role nibble (extension: bits 16..19, ligation: 20..23):
-//               guard (N or '-' in the window), an SNP with an alternate-allele arm, an SNP without one, copy number <= 0
+//   high dword  bits 0..7 masked-sequence N count | 8..15 SNP count (<= 30 each: the sum of two never carries out of its byte)
+//               | bits 16..23 the record's flag byte as far as this window decides it: MIPGEN_FLAG_GUARD (N or '-' in the window), MIPGEN_FLAG_SNP
+//                 (an SNP without an alternate-allele arm), MIPGEN_FLAG_HAS_SNP_MIP (one with), LD_COPY0 (copy number <= 0: the score is NaN; not a
+//                 record flag, cleared before the record is written)
 //               | bits 24..31 the record's junction byte (ligation role: 4*b0+b1 of the oriented arm, 255 = not ACGT; extension role: 0)
-// The two nibbles never overlap and the counts are <= 30 each, so the 32-bit ADD of the two high dwords carries nothing across fields.
+#define LD_COPY0 0x40u
 __device__ __forceinline__ uint64_t pack_word(bool lig_role, int copy, uint32_t masked, uint32_t snp_any, uint32_t snp_bad, bool snp_ok, bool guard, uint32_t jc)
 {
     const uint32_t c16 = (uint32_t)min(max(copy, 0), 65535);
-    const uint32_t nib = (uint32_t)guard | ((uint32_t)snp_ok << 1) | ((uint32_t)(snp_bad != 0) << 2) | ((uint32_t)(copy <= 0) << 3);
+    const uint32_t fl = (guard ? MIPGEN_FLAG_GUARD : 0u) | (snp_ok ? MIPGEN_FLAG_HAS_SNP_MIP : 0u) | (snp_bad != 0 ? MIPGEN_FLAG_SNP : 0u) | (copy <= 0 ? LD_COPY0 : 0u);
     const uint32_t lo = lig_role ? c16 << 16 : c16;
-    const uint32_t hi = min(masked, 255u) | (min(snp_any, 255u) << 8) | (nib << (lig_role ? 20 : 16)) | (lig_role ? (jc < 16 ? jc : 255u) << 24 : 0u);
+    const uint32_t hi = min(masked, 255u) | (min(snp_any, 255u) << 8) | (fl << 16) | (lig_role ? (jc < 16 ? jc : 255u) << 24 : 0u);
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
         const double a_c = (double)(minus ? nT : nA) * rl, g_c = (double)(minus ? nC : nG) * rl, gc_c = (double)(nC + nG) * rl;
         const double lcopy = cp > 100 ? 2.0 : (cp >= 0 ? LG[cp] : __longlong_as_double(0x7FF8000000000000LL));   // as log_copy_dev
         if (!lig_role) {
-            e[0] = MLG_FE(a_c, g_c, gc_c, dl, lcopy);
+            e[0] = (MIPGEN_LOGISTIC_C0 - MIPGEN_LOGISTIC_C1) + MLG_FE(a_c, g_c, gc_c, dl, lcopy);     // the constant term rides on the extension-arm entry
             e[1] = MLG_G_LG(a_c, g_c, gc_c, dl, lcopy); e[2] = MLG_G_LLC(a_c, g_c, gc_c, dl, lcopy); e[3] = MLG_G_LLEN(a_c, g_c, gc_c, dl, lcopy);
             e[4] = MLG_G_JS(a_c, g_c, gc_c, dl, lcopy); e[5] = MLG_G_LA(a_c, g_c, gc_c, dl, lcopy);
             e[6] = MLG_HE_BPS(a_c, g_c, gc_c, dl, lcopy); e[7] = MLG_HE_TGC(a_c, g_c, gc_c, dl, lcopy);
@@ -247,18 +250,22 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     LD_STAMP(3)
 
     // ---- candidates: one (position, capture size) row per wavefront pass, lanes on the arm pairs ----------------------------------------
+    // The loop is instruction-issue bound (about 100 vector instructions per row before this layout, most of them VOP3 = 4 cycles): whatever is
+    // the same for the whole row is computed on the scalar unit - the row's table addresses, its output address, the bounds tests of
+    // interior rows -, a lane adds its constant part.
     const double thr = P->masked_arm_threshold;
-    const double x0 = MIPGEN_LOGISTIC_C0 - MIPGEN_LOGISTIC_C1;
     constexpr double xc[4] = EXP2_TAB_POLY;
     const double EXP_MAGIC = 6755399441055744.0;                        // 1.5 * 2^52: rounds to an integer, which lands in the low mantissa bits
     const double k256 = HC->ln_base * (1.4426950408889634074 * 256.0);   // exponent -> units of 1/256 of a binary order
     const int n_rows = np * rkc;
+    const int arm_hi = max(P->e_max, P->l_max), arm_lo = min(P->e_min, P->l_min);
     for (int a0 = 0; a0 < A; a0 += WAVE) {
         const int a = a0 + lane;
         const bool have = a < A;
-        const int e = have ? P->arm_ext[a] : 2, l = have ? P->arm_lig[a] : 2, S = e + l;
+        const int e = have ? P->arm_ext[a] : P->arm_ext[0], l = have ? P->arm_lig[a] : P->arm_lig[0], S = e + l;   // (idle lanes compute pair 0, store nothing)
         const int ulen = minus ? l : e, dlen = minus ? e : l;
         const int u_col = ulen - up_min, d_col = dlen - dn_min;
+        const int arm_mx = max(e, l), arm_mn = min(e, l);
         const double dl_lig = (double)l;
         // masking_failed is "masked N count / (l + e) > threshold" (mipgen.cpp:610,626): the smallest count that satisfies it, found with the
         // reference's own double division once per pair - the candidates then compare integers
@@ -269,82 +276,92 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
             mthr = est >= 1.0 ? (est < den + 2.0 ? (int)est - 1 : l + e + 1) : 0;      // a safe start just below the boundary, then <= 3 exact tests
             while (mthr <= l + e && !((double)mthr / den > thr)) mthr++;
         }
-        // LDS byte offsets of the pair's table columns (32-bit arithmetic in the row loop)
-        const uint32_t u_off = (uint32_t)u_col * (LD_ARM_STRIDE * 8), d_off = (uint32_t)d_col * (LD_ARM_STRIDE * 8);
-        const uint32_t u_pitch = (uint32_t)n_up * (LD_ARM_STRIDE * 8), d_pitch = (uint32_t)n_dn * (LD_ARM_STRIDE * 8), t_pitch = (uint32_t)ssr * (LD_INS_STRIDE * 8);
         typedef __attribute__((address_space(3))) const double lds_cd;
         typedef __attribute__((address_space(3))) const uint64_t lds_cq;
+        typedef __attribute__((address_space(3))) const uint16_t lds_ch;
+        const uint32_t u_pitch = (uint32_t)n_up * (LD_ARM_STRIDE * 8), d_pitch = (uint32_t)n_dn * (LD_ARM_STRIDE * 8), t_pitch = (uint32_t)ssr * (LD_INS_STRIDE * 8);
         const uint32_t tu_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TU, td_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TD, tt_a = (uint32_t)(__UINTPTR_TYPE__)(lds_cd*)TT;
+        const uint32_t um_a = (uint32_t)(__UINTPTR_TYPE__)(lds_ch*)UM;
+        // lane parts of the table addresses.  Upstream entry of (pl, pair): TU + pl * u_pitch + u_col * 72; downstream entry: TD + (pl + ss - ssmin) * d_pitch
+        // + d_col * 72 with ss = C - S: the scalar part holds pl and C, the lane part the pair
+        const uint32_t c_up = (uint32_t)u_col * (LD_ARM_STRIDE * 8);
+        const uint32_t c_dn = (uint32_t)d_col * (LD_ARM_STRIDE * 8) - (uint32_t)S * d_pitch;
+        const uint32_t c_ext = minus ? c_dn : c_up, c_lig = minus ? c_up : c_dn;     // extension-role / ligation-role entry of this strand
+        const uint32_t c_ins = (uint32_t)0 - (uint32_t)S * (LD_INS_STRIDE * 8);
+        const uint32_t c_um = (uint32_t)u_col * 2u;
+        const uint32_t a8 = (uint32_t)a * 8u;
+        int pl = wid / rkc, kci = wid - pl * rkc;                                  // scalars; row + NW -> kci + NW, carried into pl (no division per row)
         for (int row = wid; row < n_rows; row += NW) {
-            const int pl = row / rkc, kci = row - pl * rkc;
-            const int C = Cmax_t - kci * inc, p = p_first + pb + pl, ss = C - S;
-            const int64_t out = R.out_off + ((((int64_t)(tile.p0 + pb + pl) * nK + (rk0 + kci)) * 2 + (minus ? 1 : 0)) * A) + a;
-            if (!have) continue;
-            // bounds skips, mipgen.cpp:443-444
-            const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) && ss > 0;
-            uint64_t rec = 0;
-            double score = 0.0;
-            if (valid) {                                                   // the only divergent branch of the row; everything inside is selects
-                const uint32_t ua = tu_a + __umul24((uint32_t)pl, u_pitch) + u_off;
-                const uint32_t da = td_a + __umul24((uint32_t)(pl + ss - ssmin), d_pitch) + d_off;
-                lds_cd* T = (lds_cd*)(unsigned long)(tt_a + __umul24((uint32_t)pl, t_pitch) + (uint32_t)(ss - ssmin) * (LD_INS_STRIDE * 8));
-                lds_cd* Ee = (lds_cd*)(unsigned long)(minus ? da : ua);    // extension-role entry
-                lds_cd* Le = (lds_cd*)(unsigned long)(minus ? ua : da);    // ligation-role entry
-                const uint64_t we = ((lds_cq*)Ee)[8], wl_ = ((lds_cq*)Le)[8];
-                const uint32_t um = UM[pl * n_up + u_col];
-                // ---- exponent (no dependence on the integer words) ----
-                double x = x0 + Ee[0];
-                x += Le[0];
-                x += T[0];
-                x = fma(Le[1], Ee[1], x);                                  // LG  * gLG
-                x = fma(Le[2], Ee[2], x);                                  // LLC * gLLC
-                x = fma(dl_lig, Ee[3], x);                                 // LLEN * gLLEN
-                x = fma(Le[3], Ee[4], x);                                  // JS  * gJS
-                x = fma(Le[4], Ee[5], x);                                  // LA  * gLA
-                x = fma(T[1], Ee[6] + Le[5], x);                           // BPS * (hE + hL)
-                x = fma(T[2], Ee[7] + Le[7], x);                           // TGC * (hE + hL)
-                x = fma(T[3], Le[6], x);                                   // TA  * hL
-                // ---- record: the sum of the two windows' words, then the flag logic of design_mip ----
-                const uint32_t lo32 = (uint32_t)we | (uint32_t)wl_;
-                const uint32_t m = (uint32_t)(we >> 32) + (uint32_t)(wl_ >> 32);
-                const uint32_t nib = (m >> 16) | (m >> 20);               // bit 0 guard, 1 SNP with an alternate-allele arm, 2 SNP without, 3 copy <= 0
-                const uint32_t masked_n = m & 0xFFu, snp_all = (m >> 8) & 0xFFu;
-                const bool mapping = (um >> kci) & 1;                       // early return of design_mip: masking / SNP fields stay at their defaults
-                const bool guard = nib & 1;
-                uint32_t flags = MIPGEN_FLAG_VALID | ((nib & 1) << 1);      // MIPGEN_FLAG_GUARD = 2
-                uint32_t f2 = ((int)masked_n >= mthr ? MIPGEN_FLAG_MASKING : 0u)                                          // :610,626
-                              | (((nib & 4) || snp_all > 1) ? MIPGEN_FLAG_SNP : 0u)                                      // :690-693,759-760
-                              | ((nib & 2) << 4);                                                                        // MIPGEN_FLAG_HAS_SNP_MIP = 0x20
-                flags |= mapping ? MIPGEN_FLAG_MAPPING : f2;
-                const uint32_t snp_count = mapping ? 0u : snp_all;
-                const uint32_t hi32 = masked_n | (snp_count << 8) | (flags << 16) | (m & 0xFF000000u);
-                rec = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
-                // ---- score = b^x / (1 + b^x), b = 2.71828 (SVMipv4.cpp:247): 2^(t/256) = 2^n * T[j] * (1 + r p(r)) with a 256-entry table ----
-                const double t = x * k256;
-                if (!(fabs(t) < 256000.0)) {                               // overflowing exponent (never seen: the libm route keeps the reference's inf / NaN)
-                    const double y = exp(x * HC->ln_base);
-                    score = y / (1.0 + y);
-                } else {
-                    const double tm = t + EXP_MAGIC;
-                    const int ti = __double2loint(tm);
-                    const double Tj = ((lds_cd*)XT)[ti & 255];
-                    const double r = t - (tm - EXP_MAGIC);
-                    double pp = fma(xc[3], r, xc[2]);
-                    pp = fma(pp, r, xc[1]);
-                    pp = fma(pp, r, xc[0]);
-                    const double y0 = fma(pp * r, Tj, Tj);
-                    const double y = __hiloint2double(__double2hiint(y0) + ((ti & ~255) << 12), __double2loint(y0));
-                    const double d = 1.0 + y;
-                    double rc = __builtin_amdgcn_rcp(d);
-                    rc = fma(fma(-d, rc, 1.0), rc, rc);
-                    const double q = y * rc;
-                    score = fma(fma(-d, q, y), rc, q);                     // one correction of the quotient: within an ulp of the division
-                }
-                if (nib & 8) score = __longlong_as_double(0xFFF8000000000000LL);   // a copy number <= 0: log10(0) = -inf (or NaN) meets terms of both signs: NaN
-                if (guard) score = -1000.0;                                // SVMipv4.cpp:116
+            const int C = Cmax_t - kci * inc, p = p_first + pb + pl;
+            // scalar parts of the addresses
+            const uint32_t s_up = tu_a + (uint32_t)pl * u_pitch, s_dn = td_a + (uint32_t)(pl + C - ssmin) * d_pitch;
+            const uint32_t s_ext = minus ? s_dn : s_up, s_lig = minus ? s_up : s_dn;
+            const uint32_t s_ins = tt_a + (uint32_t)pl * t_pitch + (uint32_t)(C - ssmin) * (LD_INS_STRIDE * 8);
+            const uint32_t s_um = um_a + (uint32_t)(pl * n_up) * 2u;
+            const int64_t out_row = R.out_off + ((((int64_t)(tile.p0 + pb + pl) * nK + (rk0 + kci)) * 2 + (minus ? 1 : 0)) * A);
+            char* const rrow = (char*)(records + out_row);
+            char* const srow = (char*)(scores + out_row);
+            // bounds skips, mipgen.cpp:443-444: no lane can fail them in a row this far inside the region (scalar test); otherwise three compares per lane
+            const int over = p + C - 1 - R.seq_stop;                              // the arms must be longer than this
+            bool valid = have;
+            if (!(p > arm_hi && over <= arm_lo && C > P->max_sum)) valid = have && p > arm_mx && over <= arm_mn && C > S;
+            lds_cd* T = (lds_cd*)(unsigned long)(s_ins + c_ins);
+            lds_cd* Ee = (lds_cd*)(unsigned long)(s_ext + c_ext);      // extension-role entry
+            lds_cd* Le = (lds_cd*)(unsigned long)(s_lig + c_lig);      // ligation-role entry
+            const uint64_t we = ((lds_cq*)Ee)[8], wl_ = ((lds_cq*)Le)[8];
+            const uint32_t um = *(lds_ch*)(unsigned long)(s_um + c_um);
+            // ---- exponent (no dependence on the integer words); the constant term is part of Ee[0] ----
+            double x = Ee[0] + Le[0];
+            x += T[0];
+            x = fma(Le[1], Ee[1], x);                                  // LG  * gLG
+            x = fma(Le[2], Ee[2], x);                                  // LLC * gLLC
+            x = fma(dl_lig, Ee[3], x);                                 // LLEN * gLLEN
+            x = fma(Le[3], Ee[4], x);                                  // JS  * gJS
+            x = fma(Le[4], Ee[5], x);                                  // LA  * gLA
+            x = fma(T[1], Ee[6] + Le[5], x);                           // BPS * (hE + hL)
+            x = fma(T[2], Ee[7] + Le[7], x);                           // TGC * (hE + hL)
+            x = fma(T[3], Le[6], x);                                   // TA  * hL
+            // ---- record: counts from the sum of the two windows' words, flags and junction from their OR, then the flag logic of design_mip ----
+            const uint32_t lo32 = (uint32_t)we | (uint32_t)wl_;
+            const uint32_t hs = (uint32_t)(we >> 32) + (uint32_t)(wl_ >> 32), ho = (uint32_t)(we >> 32) | (uint32_t)(wl_ >> 32);
+            const uint32_t hw = (hs & 0x0000FFFFu) | (ho & 0xFFFF0000u);
+            const uint32_t f_mask = (int)(hs & 0xFFu) >= mthr ? (MIPGEN_FLAG_MASKING << 16) : 0u;                        // :610,626
+            const uint32_t f_snp = ((hs >> 8) & 0xFFu) > 1u ? (MIPGEN_FLAG_SNP << 16) : 0u;                             // :690-693,759-760 (or an SNP without an arm: in hw)
+            const uint32_t h_full = (hw & ~(LD_COPY0 << 16)) | f_mask | f_snp | (MIPGEN_FLAG_VALID << 16);
+            // early return of design_mip when the MIP does not map uniquely: masking / SNP fields stay at their defaults
+            const uint32_t h_map = (hw & (0xFF0000FFu | (MIPGEN_FLAG_GUARD << 16))) | ((MIPGEN_FLAG_VALID | MIPGEN_FLAG_MAPPING) << 16);
+            const uint32_t hi32 = ((um >> kci) & 1u) ? h_map : h_full;
+            uint64_t rec = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+            // ---- score = b^x / (1 + b^x), b = 2.71828 (SVMipv4.cpp:247): 2^(t/256) = 2^n * T[j] * (1 + r p(r)) with a 256-entry table ----
+            double t = x * k256;
+            asm volatile("" : "+v"(t));                                // rounded on its own: not contracted into the two uses below
+            const double tm = t + EXP_MAGIC;
+            const int ti = __double2loint(tm);
+            const double Tj = ((lds_cd*)XT)[ti & 255];
+            const double r = t - (tm - EXP_MAGIC);
+            double pp = fma(xc[3], r, xc[2]);
+            pp = fma(pp, r, xc[1]);
+            pp = fma(pp, r, xc[0]);
+            const double y0 = fma(pp * r, Tj, Tj);
+            const double y = __hiloint2double(__double2hiint(y0) + ((ti & ~255) << 12), __double2loint(y0));
+            const double d = 1.0 + y;
+            double rc = __builtin_amdgcn_rcp(d);
+            rc = fma(fma(-d, rc, 1.0), rc, rc);
+            const double q = y * rc;
+            double score = fma(fma(-d, q, y), rc, q);                  // one correction of the quotient: within an ulp of the division
+            // the rare cases, skipped by the whole wavefront when no lane has one: an exponent beyond the table route (never seen: the libm route keeps
+            // the reference's inf / NaN), a copy number <= 0 (log10(0) = -inf or NaN meets terms of both signs: NaN), the guard (SVMipv4.cpp:116)
+            const bool odd = !(fabs(t) < 256000.0);
+            const uint32_t special = ho & ((LD_COPY0 | MIPGEN_FLAG_GUARD) << 16);
+            if (__builtin_expect(__ballot(odd || special != 0) != 0, 0)) {
+                if (odd) { const double yy = exp(x * HC->ln_base); score = yy / (1.0 + yy); }
+                if (special & (LD_COPY0 << 16)) score = __longlong_as_double(0xFFF8000000000000LL);
+                if (special & (MIPGEN_FLAG_GUARD << 16)) score = -1000.0;
             }
-            records[out] = rec;
-            scores[out] = score;
+            if (__builtin_expect(__ballot(have && !valid) != 0, 0)) { if (!valid) { rec = 0; score = 0.0; } }
+            if (have) { *(uint64_t*)(rrow + a8) = rec; *(double*)(srow + a8) = score; }
+            kci += NW;
+            while (kci >= rkc) { kci -= rkc; pl++; }
         }
     }
     LD_STAMP(4)
