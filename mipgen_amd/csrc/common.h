@@ -202,9 +202,9 @@ __attribute__((always_inline)) static inline SvrLayout svr_layout(int np, int ss
     L.tj = g; g += 18;                                  // junction term of a ligation-arm window: code 0 / 17 -> 0, 1..16 -> the 16 junctions
     L.ti = g; g += ssr;                                 // (scan size - sv_len)^2 term + the insert-side constants, per scan size
     L.pf_stride = g;
-    // the phase-0 scratch (np * 80 u16 counters) aliases the PF area
+    // the scratch of the window-norm pass after the SV loop (np * 80 u32 k-mer counters + np * ssr * 4 ints) aliases the PF area
     int pf_doubles = 2 * group * L.pf_stride;                 // double buffered: scan(k+1) runs beside tables(k)
-    const int scratch_doubles = (np * 80 * 2 + 7) / 8;
+    const int scratch_doubles = (np * (80 * 4 + ssr * 16) + 7) / 8;
     if (pf_doubles < scratch_doubles) pf_doubles = scratch_doubles;
     L.pf = o; o += pf_doubles;
     L.tu = 0; L.td = np * n_arm; L.tb_stride = np * n_arm + L.nq * n_arm;
