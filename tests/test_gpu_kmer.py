@@ -49,6 +49,29 @@ def test_copy_counter_vs_dictionary_counter():
     acc.close()
 
 
+@pytest.mark.parametrize("lengths", [[8, 11, 15], [12, 16, 17], [17, 22, 31], [31], [16]])
+def test_copy_counter_key_widths_and_chunk_borders(lengths):
+    """The genome pass rolls 32-bit keys when the shortest length is <= 16 and 64-bit keys above, places the first kmin - 1 bases of a thread's
+    16 window starts directly from the packed chunk, and stages 8,192 starts per pass: regions are planted across chunk and thread borders, next to
+    N runs and at the very end of a chromosome."""
+    g1 = bytearray(synth.random_genome(3 * 8192 + 1000, 41, n_run_frac=0.001, n_run_len=5))
+    g2 = bytearray(synth.random_genome(9000, 42))
+    unit = bytes(g1[8192 - 40:8192 + 60])                     # straddles the first chunk border
+    g1[16_384 - 7:16_384 + 93] = unit                         # a second copy across the next border, at another thread phase
+    g2[-100:] = unit                                          # a third one ends with the chromosome
+    g2[4000:4003] = b"NNN"
+    g1, g2 = bytes(g1), bytes(g2)
+    regions = [g1[8192 - 60:8192 + 80].upper(), g2[3950:4060].upper(), g2[-130:].upper(), g1[16_000:16_030].upper()]
+    acc = capi.Accel(capi.make_params(152, 162))
+    got = acc.count_oligo_copies([g1, g2], regions, lengths)
+    for seq, tab in zip(regions, got):
+        exp = po.count_oligo_copies([g1, g2], seq, lengths)
+        for k in lengths:
+            assert np.array_equal(tab[k], exp[k]), (k, np.nonzero(tab[k] != exp[k])[0][:5], tab[k][:8], exp[k][:8])
+    assert max(int(t[lengths[0]].max()) for t in got) >= 3
+    acc.close()
+
+
 def test_copy_counter_large_design_takes_the_unfolded_filter():
     """More than 2^16 region positions: the LDS fold of the Bloom filter is skipped and every genome position tests the full bitmap
     (kernels_kmer.hip: use_fold); same counts as the dictionary counter."""
