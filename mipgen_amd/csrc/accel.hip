@@ -71,7 +71,8 @@ hipError_t mipgen_launch_kmer_lookup(hipStream_t, const char* seq, int64_t len, 
 hipError_t mipgen_launch_kmer_place(hipStream_t, const int32_t* src, int64_t len, const KmerParams*, const int64_t* roff, int n_regions, int32_t* dst, void* big,
                                     unsigned int* n_big, unsigned int big_cap);
 hipError_t mipgen_launch_collapse(hipStream_t, int n_tiles, const CollapseTile* tiles, const DevParams*, const DevRegion*, const int64_t* region_pos0,
-                                  const int64_t* region_base0, const mipgen_survivor* survivors, const int32_t* copy, int64_t cand_base, int32_t* collapsed);
+                                  const int64_t* region_base0, const mipgen_survivor* survivors, const int32_t* copy, int64_t cand_base, int32_t* collapsed,
+                                  int max_scan_all);
 }
 
 // ---- errors ----------------------------------------------------------------------------------------------
@@ -1156,7 +1157,7 @@ static int collapse_window_impl(mipgen_accel* h)
 {
     const Window& W = h->windows[(size_t)h->cur_window];
     HIP_TRY(mipgen_launch_collapse(h->stream, W.n_col_tiles, h->col_tiles.p + W.col_tile0, h->dp, h->regions.p, h->region_pos0.p, h->region_base0.p,
-                                   h->survivors.p, h->copy.p, W.cand0, h->collapsed.p));
+                                   h->survivors.p, h->copy.p, W.cand0, h->collapsed.p, h->hp.max_capture - h->hp.min_sum));
     if ((size_t)h->cur_window < h->win_state.size()) h->win_state[(size_t)h->cur_window] |= 2;
     return MIPGEN_OK;
 }

@@ -627,51 +627,74 @@ __global__ __launch_bounds__(256) void k_collapse(int n_tiles, const CollapseTil
                                                   const int64_t* __restrict__ region_base0, const mipgen_survivor* __restrict__ survivors,
                                                   const int32_t* __restrict__ copy, int64_t cand_base, int32_t* __restrict__ collapsed)
 {
+    // Two passes per workgroup (128 bases x 2 strands).  What a survivor contributes does not depend on the base: its last covered base, whether
+    // the copy / masking filters keep it (:1628-1629), its SNP count and score are worked out once per survivor - the candidate index is taken
+    // apart there, two integer divisions - and parked in LDS; a base then folds its <= max scan size survivors from there in scan-start order.
+    extern __shared__ __align__(16) unsigned char col_smem[];
     const CollapseTile t = tiles[blockIdx.x];
     const DevRegion& R = regions[t.region];
     const int A = P->n_pairs, nK = R.n_sizes;
     const int max_scan = P->max_capture - R.k0 * P->inc - P->min_sum;
     const int n_base = R.n_pos + max_scan - 1;
-    const int j = t.j0 + (threadIdx.x >> 1), s = threadIdx.x & 1;
-    if (j >= n_base || nK <= 0) return;
+    if (nK <= 0) return;
+    const int p_lo = max(0, t.j0 - max_scan + 1), p_hi = min(t.j0 + 127, R.n_pos - 1), n_sv = 2 * (p_hi - p_lo + 1);
+    double* s_score = (double*)col_smem;                                   // [n_sv]
+    int* s_end = (int*)(s_score + max(n_sv, 0));                           // last base the survivor's scan target covers; -1: filtered out / absent
+    int* s_snp = s_end + max(n_sv, 0);
     const int64_t per_pos = (int64_t)nK * A * 2;
     const mipgen_survivor* sv = survivors + 2 * region_pos0[t.region];
     const int target = P->target_arm_copy;
     const int64_t max_product = P->max_arm_copy_product;
     const double thr = P->masked_arm_threshold;
+    for (int q = threadIdx.x; q < n_sv; q += blockDim.x) {
+        const int pi = p_lo + (q >> 1), s = q & 1;
+        const mipgen_survivor m = sv[2 * (int64_t)pi + s];
+        int end = -1, snp = 0;
+        if (m.cand_index >= 0) {
+            const int rel = (int)(m.cand_index - cand_base - R.out_off - (int64_t)pi * per_pos);     // < per_pos: the candidate inside its position
+            const int a = rel % A, ki = rel / (2 * A);
+            const int e = P->arm_ext[a], l = P->arm_lig[a];
+            const int C = P->max_capture - (R.k0 + ki) * P->inc, ss = C - e - l;
+            int ext_copy = (int)MIPGEN_REC_EXT_COPY(m.record), lig_copy = (int)MIPGEN_REC_LIG_COPY(m.record);
+            if ((ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0) {  // saturated record fields: the true counts (see k_replay_condense)
+                const int p = R.first_pos + pi;
+                const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
+                const int se = P->len_slot[e], sl = P->len_slot[l];
+                const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
+                ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
+                lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
+            }
+            const bool keep = !((int64_t)ext_copy * lig_copy > max_product || ext_copy > target || lig_copy > target)          // :1628
+                              && !((double)MIPGEN_REC_MASKED_N(m.record) / (double)(l + e) > thr);                          // :1629
+            if (keep) end = pi + ss - 1;
+            snp = (int)MIPGEN_REC_SNP_COUNT(m.record);
+        }
+        s_end[q] = end; s_snp[q] = snp; s_score[q] = m.score;
+    }
+    __syncthreads();
+    const int j = t.j0 + (threadIdx.x >> 1), s = threadIdx.x & 1;
+    if (j >= n_base) return;
     int best = -1, best_snp = 0;
     double best_score = 0.0;
     for (int pi = max(0, j - max_scan + 1); pi <= min(j, R.n_pos - 1); pi++) {
-        const mipgen_survivor m = sv[2 * (int64_t)pi + s];
-        if (m.cand_index < 0) continue;
-        const int64_t rel = m.cand_index - cand_base - R.out_off - (int64_t)pi * per_pos;
-        const int a = (int)(rel % A), ki = (int)(rel / (2 * A));
-        const int e = P->arm_ext[a], l = P->arm_lig[a];
-        const int C = P->max_capture - (R.k0 + ki) * P->inc, ss = C - e - l;
-        if (pi + ss - 1 < j) continue;                                       // its scan target ends before this base
-        int ext_copy = (int)MIPGEN_REC_EXT_COPY(m.record), lig_copy = (int)MIPGEN_REC_LIG_COPY(m.record);
-        if ((ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0) {  // saturated record fields: the true counts (see k_replay_condense)
-            const int p = R.first_pos + pi;
-            const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
-            const int se = P->len_slot[e], sl = P->len_slot[l];
-            const int ie = ext_start - R.seq_start, il = lig_start - R.seq_start;
-            ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
-            lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
-        }
-        if ((int64_t)ext_copy * lig_copy > max_product || ext_copy > target || lig_copy > target) continue;          // :1628
-        if ((double)MIPGEN_REC_MASKED_N(m.record) / (double)(l + e) > thr) continue;                                  // :1629
-        const int snp = (int)MIPGEN_REC_SNP_COUNT(m.record);
-        if (best < 0 || snp < best_snp || (m.score > best_score && snp == best_snp)) { best = pi; best_snp = snp; best_score = m.score; }   // :1634-1645
+        const int q = 2 * (pi - p_lo) + s;
+        if (s_end[q] < j) continue;                                          // absent, filtered out, or its scan target ends before this base
+        const int snp = s_snp[q];
+        const double sc = s_score[q];
+        if (best < 0 || snp < best_snp || (sc > best_score && snp == best_snp)) { best = pi; best_snp = snp; best_score = sc; }   // :1634-1645
     }
     collapsed[region_base0[t.region] + 2 * (int64_t)j + s] = best;
 }
 
 extern "C" hipError_t mipgen_launch_collapse(hipStream_t stream, int n_tiles, const CollapseTile* tiles, const DevParams* P, const DevRegion* regions,
                                              const int64_t* region_pos0, const int64_t* region_base0, const mipgen_survivor* survivors,
-                                             const int32_t* copy, int64_t cand_base, int32_t* collapsed)
+                                             const int32_t* copy, int64_t cand_base, int32_t* collapsed, int max_scan_all)
 {
     if (n_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_collapse, dim3(n_tiles), dim3(256), 0, stream, n_tiles, tiles, P, regions, region_pos0, region_base0, survivors, copy, cand_base, collapsed);
+    // LDS: the survivors of the 128 bases' scan positions and of the max_scan - 1 positions before them, both strands, 16 bytes each
+    const size_t lds = (size_t)2 * (size_t)(128 + (max_scan_all > 0 ? max_scan_all : 0)) * 16;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_collapse, dim3(n_tiles), dim3(256), lds, stream, n_tiles, tiles, P, regions, region_pos0, region_base0, survivors, copy, cand_base, collapsed);
     return hipGetLastError();
 }
 
