@@ -218,6 +218,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense(
 // ---------------------------------------------------------------------------------------------------------
 #define REPLAY_ROWS 8
 
+template <bool WIDE>
 __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
     int total_pos, int lds_pitch, const DevParams* __restrict__ P, const DevRegion* __restrict__ regions,
     const int32_t* __restrict__ pos_region, const int32_t* __restrict__ pos_local, const double* __restrict__ scores,
@@ -259,11 +260,35 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
             if (lane < REPLAY_ROWS && k0 + lane < nK) emask[k0 + lane] = 0;
             continue;
         }
+        if constexpr (WIDE) {
+        // every load of the batch is issued before the first value is looked at (selects afterwards: with the loads predicated per lane and the flag
+        // tests next to them the compiler waits for each row's record before it issues the next row - eight dependent round trips; designs of few
+        // capture sizes run faster that way, hence the two forms)
+        {
+            const double* srow = scores + base;
+            const uint64_t* rrow = records + base;
+            const int la = min(lane, A - 1);
+#pragma unroll
+            for (int q = 0; q < REPLAY_ROWS; q++) {
+                bp[q] = 0.0; bm[q] = 0.0; br[q] = 0;
+                if (k0 + q < nK) {                                              // (wave-uniform: the rows behind the last capture size are not fetched)
+                    const int off = ((k0 + q) * 2) * A + la;
+                    bp[q] = srow[off]; bm[q] = srow[off + A]; br[q] = rrow[off];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < REPLAY_ROWS; q++) {
+                bp[q] = in ? bp[q] : 0.0; bm[q] = in ? bm[q] : 0.0; br[q] = in ? br[q] : 0;
+            }
+        }
+        } else {
 #pragma unroll
         for (int q = 0; q < REPLAY_ROWS; q++) {
             const bool on = in && k0 + q < nK;
             const int64_t idx = base + ((int64_t)(k0 + q) * 2) * A + lane;
             bp[q] = on ? scores[idx] : 0.0; bm[q] = on ? scores[idx + A] : 0.0; br[q] = on ? records[idx] : 0;
+        }
         }
 #pragma unroll
         for (int q = 0; q < REPLAY_ROWS; q++) {
@@ -335,12 +360,36 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
         for (int k0 = k_top; k0 >= 0 && !stop; k0 -= REPLAY_ROWS) {                  // newest first (push_front, :475,489)
             uint64_t em[REPLAY_ROWS], br[REPLAY_ROWS];
             double bs[REPLAY_ROWS];
+            if constexpr (WIDE) {
+            {
+                const double* srow = scores + base;
+                const uint64_t* rrow = records + base;
+                const int la = min(lane, A - 1);
+#pragma unroll
+                for (int q = 0; q < REPLAY_ROWS; q++) em[q] = k0 + q < nK ? emask[k0 + q] : 0;
+#pragma unroll
+                for (int q = 0; q < REPLAY_ROWS; q++) {
+                    br[q] = 0; bs[q] = 0.0;
+                    if (em[q]) {                                                 // (wave-uniform: a row nothing was emitted from is not fetched)
+                        const int off = ((k0 + q) * 2 + s) * A + la;
+                        br[q] = rrow[off]; bs[q] = srow[off];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < REPLAY_ROWS; q++) {
+                    const bool mine = (em[q] & lane_bit) != 0;
+                    br[q] = mine ? br[q] : 0; bs[q] = mine ? bs[q] : 0.0;
+                }
+            }
+            } else {
 #pragma unroll
             for (int q = 0; q < REPLAY_ROWS; q++) {
                 em[q] = k0 + q < nK ? emask[k0 + q] : 0;
                 const bool mine = (em[q] & lane_bit) != 0;
                 const int64_t idx = base + ((int64_t)(k0 + q) * 2 + s) * A + lane;
                 br[q] = mine ? records[idx] : 0; bs[q] = mine ? scores[idx] : 0.0;
+            }
             }
 #pragma unroll
             for (int q = REPLAY_ROWS - 1; q >= 0; q--) {
@@ -606,8 +655,12 @@ extern "C" hipError_t mipgen_launch_replay_condense(
         hipLaunchKernelGGL(k_replay_condense_carry<8>, grid, block, 0, stream, total_pos, P, regions, pos_region, pos_local, scores, records, copy, cand_base, emitted,
                            survivors, emitted_per_region);
     else if (n_chunks == 1)
-        hipLaunchKernelGGL(k_replay_condense_narrow, grid, block, lds, stream, total_pos, pitch, P, regions, pos_region, pos_local, scores, records, copy,
-                           cand_base, emitted, survivors, emitted_per_region);
+        if (n_sizes_max > 2 * REPLAY_ROWS)
+            hipLaunchKernelGGL(k_replay_condense_narrow<true>, grid, block, lds, stream, total_pos, pitch, P, regions, pos_region, pos_local, scores, records, copy,
+                               cand_base, emitted, survivors, emitted_per_region);
+        else
+            hipLaunchKernelGGL(k_replay_condense_narrow<false>, grid, block, lds, stream, total_pos, pitch, P, regions, pos_region, pos_local, scores, records, copy,
+                               cand_base, emitted, survivors, emitted_per_region);
     else
         hipLaunchKernelGGL(k_replay_condense, grid, block, lds, stream, total_pos, n_chunks, pitch, P, regions, pos_region, pos_local, scores, records,
                            copy, cand_base, emitted, survivors, emitted_per_region);
