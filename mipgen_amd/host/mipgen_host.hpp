@@ -108,6 +108,7 @@ struct Cand {
     int scan_size() const { return scan_stop - scan_start + 1; }
 };
 Cand make_cand(const Options& o, const Region& r, const mipgen_grid& g, int64_t local_index, double score, uint64_t record);
+Cand make_cand_at(const Options& o, const Region& r, const mipgen_grid& g, int scan_index, uint32_t index_in_position, double score, uint64_t record);
 
 struct Outputs {
     std::ofstream all, collapsed, picked, snp, progress, gaps, double_gaps, minus_gaps, double_minus_gaps;
