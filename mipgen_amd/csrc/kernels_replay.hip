@@ -746,7 +746,8 @@ extern "C" hipError_t mipgen_launch_collapse(hipStream_t stream, int n_tiles, co
     if (n_tiles <= 0) return hipSuccess;
     // LDS: the survivors of the 128 bases' scan positions and of the max_scan - 1 positions before them, both strands, 16 bytes each
     const size_t lds = (size_t)2 * (size_t)(128 + (max_scan_all > 0 ? max_scan_all : 0)) * 16;
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;                       // (scan targets beyond ~5,000 bases)
+    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)k_collapse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_collapse, dim3(n_tiles), dim3(256), lds, stream, n_tiles, tiles, P, regions, region_pos0, region_base0, survivors, copy, cand_base, collapsed);
     return hipGetLastError();
 }
