@@ -629,6 +629,30 @@ def test_collapse_on_device(name, genome):
     acc.close()
 
 
+@pytest.mark.parametrize("capture", [(300, 320), (1500, 1510)])
+def test_collapse_wide_scan_targets(capture):
+    """The collapse kernel parks the survivors a 128-base tile can see in LDS: wide capture sizes (scan targets of ~270 and ~1,470 bases: the
+    second needs more than the default 48 KB of dynamic LDS) against the plain restatement, over several tiles of a long region."""
+    g = synth.random_genome(12_000, 91, n_run_frac=0.001, n_run_len=6)
+    P = capi.make_params(capture[0], capture[1], score_method=capi.SCORE_LOGISTIC, capture_increment=10, arm_pairs=[(20, 20), (20, 24), (22, 22), (24, 20)])
+    from mipgen_amd import workloads
+    regions = [workloads.fast_region(g, synth.Interval("1", 4000, 4700, "a"), P), workloads.fast_region(g, synth.Interval("1", 8000, 8150, "b"), P)]
+    acc = capi.Accel(P)
+    grids = acc.upload(regions)
+    acc.score_condense_all(capi.SCORE_LOGISTIC)
+    e, surv, _ = acc.download_replay(want_mask=False)
+    col = acc.download_collapsed(-1)
+    off = pos = 0
+    for ri, gr in enumerate(grids):
+        fe, nb = acc.region_bases(ri)
+        exp = _collapse_py(P, gr, surv[2 * pos:2 * (pos + gr.n_pos)], P.target_arm_copy, P.max_arm_copy_product, P.masked_arm_threshold)
+        assert exp.shape[0] == nb
+        assert np.array_equal(col[off:off + 2 * nb].reshape(nb, 2), exp), (capture, ri)
+        assert (exp >= 0).any()
+        off += 2 * nb; pos += gr.n_pos
+    acc.close()
+
+
 def test_batched_candidate_rescoring(genome):
     """Lists of >= 256 candidates take the list path (k_features_batch: a wavefront per candidate, then k_svr_gemm: distances through the
     FP64 matrix cores): same features / records / scores as the one-workgroup-per-candidate kernel and as the oracle, incl. guard /
