@@ -37,10 +37,12 @@ hipError_t mipgen_launch_print_boundary_scan(hipStream_t, const DevParams*, cons
                                              double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap, int n_cu);
 hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t, const mipgen_candidate* cands, const double* scores, const uint64_t* records, int n, double tol_rel,
                                                   double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
-hipError_t mipgen_launch_scatter_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores);
+hipError_t mipgen_launch_dense_candidates(hipStream_t, const DevParams* P, const DevRegion* regions, int r0, int r1, int64_t c0, int n, mipgen_candidate* out);
+hipError_t mipgen_launch_dense_list_fix(hipStream_t, int n, const uint64_t* records, double rho, double s_guard, double* scores);
+hipError_t mipgen_launch_scatter_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores, unsigned int* over);
 hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t, const DevParams*, const DevRegion*, int r0, int r1, const mipgen_survivor* surv, int64_t n, int64_t cand0,
                                                   double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
-hipError_t mipgen_launch_scatter_surv_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv);
+hipError_t mipgen_launch_scatter_surv_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv, unsigned int* over);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
@@ -241,6 +243,7 @@ struct mipgen_accel {
     DevBuf<int64_t> pb_idx;
     DevBuf<double> pb_scores;
     DevBuf<unsigned int> pb_count;
+    unsigned int* pb_over = nullptr;         // host-mapped word: entries a re-score list could not hold (checked at the next download: pb_check)
     std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
     int n_sv_pad = 0;
@@ -401,6 +404,8 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
     hipError_t e1 = hipMalloc((void**)&h->dp, sizeof(DevParams));
     hipError_t e2 = hipMalloc((void**)&h->dconsts, sizeof(HostConsts));
     if (e1 != hipSuccess || e2 != hipSuccess) { mipgen_accel_destroy(h); return fail(MIPGEN_E_NOMEM, "hipMalloc failed"); }
+    if (hipHostMalloc((void**)&h->pb_over, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) { h->pb_over = nullptr; mipgen_accel_destroy(h); return fail(MIPGEN_E_NOMEM, "hipHostMalloc failed"); }
+    *h->pb_over = 0u;
     hipError_t e3 = hipMemcpy(h->dp, &D, sizeof D, hipMemcpyHostToDevice);
     if (e3 == hipSuccess) e3 = hipMemcpy(h->dconsts, &h->hconsts, sizeof(HostConsts), hipMemcpyHostToDevice);
     if (e3 != hipSuccess) { mipgen_accel_destroy(h); return fail(MIPGEN_E_HIP, "hipMemcpy of the run parameters: %s", hipGetErrorString(e3)); }
@@ -425,6 +430,7 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->pool.clear();
     if (h->dp) (void)hipFree(h->dp);
     if (h->dconsts) (void)hipFree(h->dconsts);
+    if (h->pb_over) (void)hipHostFree(h->pb_over);
     for (hipEvent_t e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1059,8 +1065,20 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
 
 static int ensure_tiles(mipgen_accel* h, int32_t method)
 {
-    if (method == MIPGEN_SCORE_SVR) return h->svr_geometry_error.empty() ? build_svr_tiles(h) : MIPGEN_OK;       // the caller reports the geometry error
+    // a parameter set the tiled SVR kernel cannot take still needs the record tiles: its dense grid goes through the list scorer (svr_window_via_list)
+    if (method == MIPGEN_SCORE_SVR) return h->svr_geometry_error.empty() ? build_svr_tiles(h) : build_record_tiles(h);
     return build_logistic_tiles(h);
+}
+
+// After a stream synchronisation: did a print-exact re-score list overflow since the last check?  The surplus entries keep the dense kernel's
+// value (still within 1e-5 - but their printed sixth digit is no longer guaranteed), so the download that would hand them out fails loudly.
+static int pb_check(mipgen_accel* h)
+{
+    if (!h->pb_over || *h->pb_over == 0u) return MIPGEN_OK;
+    const unsigned int v = *h->pb_over;
+    *h->pb_over = 0u;
+    return fail(MIPGEN_E_STATE, "print-exact re-score: %u scores on a 6-digit rounding boundary did not fit the re-score list "
+                                "(mipgen_accel_set_print_exact(h, 0) waives the guarantee)", v);
 }
 
 // SVR scores within the dense / list kernels' error of a midpoint between two 6-significant-digit numbers (what the front end prints,
@@ -1078,7 +1096,7 @@ static int fix_print_boundaries(mipgen_accel* h, int r0, int r1, const mipgen_ca
     else HIP_TRY(mipgen_launch_print_boundary_scan(h->stream, h->dp, h->regions.p, r0, r1, scores, records, n, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap, h->n_cu));
     HIP_TRY(mipgen_launch_candidates(h->stream, (int)cap, h->dp, h->regions.p, h->pb_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
                                      h->gamma, h->rho, MIPGEN_SCORE_SVR, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
-    HIP_TRY(mipgen_launch_scatter_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, scores));
+    HIP_TRY(mipgen_launch_scatter_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, scores, h->pb_over));
     return MIPGEN_OK;
 }
 
@@ -1097,16 +1115,37 @@ static int fix_print_boundaries_survivors(mipgen_accel* h, int w)
     HIP_TRY(mipgen_launch_print_boundary_scan_surv(h->stream, h->dp, h->regions.p, W.r0, W.r1, surv, n, W.cand0, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap));
     HIP_TRY(mipgen_launch_candidates(h->stream, (int)cap, h->dp, h->regions.p, h->pb_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
                                      h->gamma, h->rho, MIPGEN_SCORE_SVR, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
-    HIP_TRY(mipgen_launch_scatter_surv_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, surv));
+    HIP_TRY(mipgen_launch_scatter_surv_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, surv, h->pb_over));
+    return MIPGEN_OK;
+}
+
+// The dense grid of a window through the LIST scorer: the route of SVR parameter sets outside the tiled kernel's limits (scan size < 3,
+// > 240 arm pairs, a tile beyond 160 KiB of LDS; h->svr_geometry_error / svr_batch_error say which) - the reference completes every
+// -arm_lengths / -capture_increment / range it is given (mipgen.cpp:222-261, 427-444), so does this library, at the list scorer's rate
+// (k_features_batch builds all 192 features per candidate, k_svr_gemm contracts them with the model on the FP64 matrix cores).
+static int svr_window_via_list(mipgen_accel* h, const Window& W)
+{
+    const int64_t CH = (int64_t)1 << 19;                                  // candidates per chunk: 0.8 GB of features
+    const size_t n_max = (size_t)std::min<int64_t>(CH, std::max<int64_t>(W.n_cand, 1));
+    if (h->cand_in.reserve(n_max) || h->cand_records.reserve(n_max) || h->cand_feats.reserve(n_max * MIPGEN_N_FEATURES)) return MIPGEN_E_NOMEM;
+    for (int64_t c0 = 0; c0 < W.n_cand; c0 += CH) {
+        const int n = (int)std::min<int64_t>(CH, W.n_cand - c0);
+        HIP_TRY(mipgen_launch_dense_candidates(h->stream, h->dp, h->regions.p, W.r0, W.r1, c0, n, h->cand_in.p));
+        HIP_TRY(mipgen_launch_features_batch(h->stream, n, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->cand_records.p,
+                                             h->cand_feats.p));
+        HIP_TRY(mipgen_launch_svr_gemm(h->stream, n, h->cand_feats.p, h->cand_records.p, h->model_t.p, h->sv_norm.p, h->sv_coef.p, h->sv_center.p, h->n_sv_pad,
+                                       h->gamma, h->rho, h->scores.p + c0));
+        HIP_TRY(mipgen_launch_dense_list_fix(h->stream, n, h->records.p + c0, h->rho, h->s_guard, h->scores.p + c0));
+    }
     return MIPGEN_OK;
 }
 
 static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_dense = true)
 {
-    if (method == MIPGEN_SCORE_SVR && !h->svr_geometry_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_geometry_error.c_str());
     if (int rc = ensure_tiles(h, method)) return rc;
     const Window& W = h->windows[(size_t)w];
-    if (method == MIPGEN_SCORE_SVR && !h->svr_batch_error.empty()) return fail(MIPGEN_E_INVALID, "dense SVR scoring: %s", h->svr_batch_error.c_str());
+    const bool svr_via_list = method == MIPGEN_SCORE_SVR && (!h->svr_geometry_error.empty() || !h->svr_batch_error.empty());
+    if (svr_via_list && h->model_t.p == nullptr) return fail(MIPGEN_E_MODEL, "SVR scoring requested but no model is loaded");
     hipEvent_t* ev = nullptr;
     if (h->timing) { if (ensure_events(h)) return MIPGEN_E_HIP; ev = &h->ev[4 * (size_t)w]; }
     if (ev) HIP_TRY(hipEventRecord(ev[0], h->stream));
@@ -1118,7 +1157,10 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
         HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
                                                h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
     if (ev) HIP_TRY(hipEventRecord(ev[1], h->stream));
-    if (method == MIPGEN_SCORE_SVR) {
+    if (svr_via_list) {
+        if (int rc = svr_window_via_list(h, W)) return rc;
+        if (fix_dense) { if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand)) return rc; }
+    } else if (method == MIPGEN_SCORE_SVR) {
         const double gamma_l2e = h->gamma * 1.4426950408889634074;
         int split = h->sv_split > 0 ? h->sv_split : pick_sv_split(W.n_svr_tiles, h->n_sv, h->n_cu);
         split = std::max(1, std::min(split, (h->n_sv + SVR_GROUP - 1) / SVR_GROUP));
@@ -1223,6 +1265,7 @@ int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* rec
     if (scores) HIP_TRY(hipMemcpyAsync(scores, h->scores.p + off, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (records) HIP_TRY(hipMemcpyAsync(records, h->records.p + off, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc_pb = pb_check(h)) return rc_pb;
     return MIPGEN_OK;
 }
 
@@ -1281,6 +1324,7 @@ int mipgen_accel_score_candidates(mipgen_accel* h, const mipgen_candidate* cands
     if (features) HIP_TRY(hipMemcpyAsync(features, h->cand_feats.p, (size_t)n * MIPGEN_N_FEATURES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (ints) HIP_TRY(hipMemcpyAsync(ints, h->cand_ints.p, (size_t)n * sizeof(mipgen_candidate_ints), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc_pb = pb_check(h)) return rc_pb;
     if (time_list) {
         float a = 0.f, b = 0.f;
         if (hipEventElapsedTime(&a, le[0], le[1]) == hipSuccess && hipEventElapsedTime(&b, le[1], le[2]) == hipSuccess) { h->list_feat_ms = a; h->list_svr_ms = b; }
@@ -1356,6 +1400,7 @@ int mipgen_accel_download_replay(mipgen_accel* h, int64_t* emitted_per_region, m
     const Window& W = h->windows[(size_t)h->cur_window];
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc_pb = pb_check(h)) return rc_pb;
     if (emitted_per_region && W.r1 > W.r0)
         HIP_TRY(hipMemcpy(emitted_per_region, h->emitted_per_region.p + W.r0, (size_t)(W.r1 - W.r0) * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (survivors) {
@@ -1457,6 +1502,7 @@ int mipgen_accel_format_all_mips(mipgen_accel* h, const mipgen_record_names* nam
     HIP_TRY(hipMemcpyAsync(&totals[0], h->fmt_b.p + n_rb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(&totals[1], h->fmt_d.p + n_rb, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc_pb = pb_check(h)) return rc_pb;
     if (h->fmt_text.reserve((size_t)std::max<int64_t>(totals[1], 1))) return MIPGEN_E_NOMEM;
     HIP_TRY(mipgen_launch_fmt_records(h->stream, 1, n_rb, W.r0, &FC, h->fmt_regions.p, h->fmt_pool.p, h->dp, h->regions.p, h->letters.p, h->copy.p, h->scores.p,
                                       h->records.p, h->emitted.p, h->fmt_b.p, h->fmt_d.p, nullptr, h->fmt_text.p));
@@ -1484,6 +1530,7 @@ int mipgen_accel_download_survivors(mipgen_accel* h, int64_t* emitted_per_region
         if (!(h->win_state[w] & 1)) return fail(MIPGEN_E_STATE, "mipgen_accel_score_condense_all has not run on this batch (window %zu holds no current survivors)", w);
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc_pb = pb_check(h)) return rc_pb;
     if (emitted_per_region && h->n_regions)
         HIP_TRY(hipMemcpy(emitted_per_region, h->emitted_per_region.p, (size_t)h->n_regions * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (survivors) {

@@ -421,6 +421,61 @@ __global__ __launch_bounds__(FB_WAVES * 64) void k_features_batch(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The slow SVR route of the dense grid (parameter sets the tiled kernel of kernels_svr.hip cannot take: scan sizes below 3, more than
+// 240 arm pairs, a tile beyond 160 KiB of LDS - the reference accepts any -arm_lengths / -capture_increment / range, mipgen.cpp:222-261,
+// 427-444): the candidates of a chunk of the window's dense index range are written out as a LIST (k_dense_candidates) and go through the
+// list scorer (k_features_batch + k_svr_gemm); k_dense_list_fix then applies the constants of the dense kernel's own fix-ups from the
+// integer records, so that both routes hand out identical values for the flagged candidates.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_candidates(const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, int r0, int r1, int64_t c0, int n,
+                                                          mipgen_candidate* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t idx = c0 + i;                                    // window-relative dense index (DevRegion::out_off is window-relative too)
+    int lo = r0, hi = r1;                                          // the last region with out_off <= idx: empty regions share the offset of the
+    while (hi - lo > 1) {                                          // next non-empty one and come before it
+        const int mid = (lo + hi) >> 1;
+        if (regions[mid].out_off <= idx) lo = mid; else hi = mid;
+    }
+    const DevRegion& R = regions[lo];
+    const int64_t rel = idx - R.out_off;
+    const int A = P->n_pairs;
+    const int a = (int)(rel % A);
+    const int64_t row = rel / A;
+    const int strand = (int)(row & 1);
+    const int64_t rest = row >> 1;
+    const int k = (int)(rest % R.n_sizes), pi = (int)(rest / R.n_sizes);
+    mipgen_candidate c;
+    c.region = lo; c.scan_start = R.first_pos + pi; c.capture_size = P->max_capture - (R.k0 + k) * P->inc;
+    c.ext_len = P->arm_ext[a]; c.lig_len = P->arm_lig[a]; c.strand = strand;
+    out[i] = c;
+}
+__global__ __launch_bounds__(256) void k_dense_list_fix(int n, const uint64_t* __restrict__ records, double rho, double s_guard, double* __restrict__ scores)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t rec = records[i];
+    const uint32_t flags = MIPGEN_REC_FLAGS(rec);
+    if (!(flags & MIPGEN_FLAG_VALID)) scores[i] = 0.0;
+    else if (flags & MIPGEN_FLAG_GUARD) scores[i] = s_guard;           // all-zero feature vector (SVMipv4.cpp:63-68)
+    else if (MIPGEN_REC_EXT_COPY(rec) == 0 || MIPGEN_REC_LIG_COPY(rec) == 0) scores[i] = -rho;   // log10(0) = -inf: every kernel value is 0
+}
+extern "C" hipError_t mipgen_launch_dense_candidates(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, int64_t c0, int n,
+                                                     mipgen_candidate* out)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dense_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, regions, r0, r1, c0, n, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_dense_list_fix(hipStream_t stream, int n, const uint64_t* records, double rho, double s_guard, double* scores)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dense_list_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, records, rho, s_guard, scores);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mipgen_launch_features_batch(hipStream_t stream, int n, const DevParams* P, const DevRegion* regions, const mipgen_candidate* cands,
                                                    const uint8_t* bases, const int32_t* copy, const uint8_t* unmap, const HostConsts* HC, uint64_t* records,
                                                    double* features)
@@ -507,11 +562,13 @@ __global__ __launch_bounds__(256) void k_print_boundary_scan(const DevParams* __
     }
 }
 
+// `over` (host-mapped word, may be null): set when the scan listed more entries than the list holds - the surplus was not re-scored, the caller reports it
 __global__ __launch_bounds__(256) void k_scatter_scores(const double* __restrict__ src, const int64_t* __restrict__ idx, int cap, const unsigned int* __restrict__ n_dev,
-                                                        double* __restrict__ scores)
+                                                        double* __restrict__ scores, unsigned int* __restrict__ over)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap && (unsigned int)i < *n_dev) scores[idx[i]] = src[i];
+    if (i == 0 && over && *n_dev > (unsigned int)cap) *over = *n_dev - (unsigned int)cap;
 }
 
 // the same test over a candidate LIST (mixed designs: the survivors re-scored by the matrix-core scorer): entry i of the list
@@ -575,10 +632,11 @@ __global__ __launch_bounds__(256) void k_print_boundary_scan_surv(const DevParam
 }
 
 __global__ __launch_bounds__(256) void k_scatter_surv_scores(const double* __restrict__ src, const int64_t* __restrict__ idx, int cap, const unsigned int* __restrict__ n_dev,
-                                                             mipgen_survivor* __restrict__ surv)
+                                                             mipgen_survivor* __restrict__ surv, unsigned int* __restrict__ over)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap && (unsigned int)i < *n_dev) surv[idx[i]].score = src[i];
+    if (i == 0 && over && *n_dev > (unsigned int)cap) *over = *n_dev - (unsigned int)cap;
 }
 
 extern "C" hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, const mipgen_survivor* surv,
@@ -589,10 +647,10 @@ extern "C" hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t stream,
     hipLaunchKernelGGL(k_print_boundary_scan_surv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, regions, r0, r1, surv, n, cand0, tol_rel, tol_abs, out, out_idx, count, cap);
     return hipGetLastError();
 }
-extern "C" hipError_t mipgen_launch_scatter_surv_scores(hipStream_t stream, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv)
+extern "C" hipError_t mipgen_launch_scatter_surv_scores(hipStream_t stream, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv, unsigned int* over)
 {
     if (cap <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scatter_surv_scores, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src, idx, cap, n_dev, surv);
+    hipLaunchKernelGGL(k_scatter_surv_scores, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src, idx, cap, n_dev, surv, over);
     return hipGetLastError();
 }
 
@@ -603,10 +661,10 @@ extern "C" hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t stream,
     hipLaunchKernelGGL(k_print_boundary_scan_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cands, scores, records, n, tol_rel, tol_abs, out, out_idx, count, cap);
     return hipGetLastError();
 }
-extern "C" hipError_t mipgen_launch_scatter_scores(hipStream_t stream, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores)
+extern "C" hipError_t mipgen_launch_scatter_scores(hipStream_t stream, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores, unsigned int* over)
 {
     if (cap <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scatter_scores, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src, idx, cap, n_dev, scores);
+    hipLaunchKernelGGL(k_scatter_scores, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src, idx, cap, n_dev, scores, over);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@
 //   3. k_window_verify  second genome pass: a genome position whose k-mer is a seed with >= 2 loci is extended along its diagonal, for every
 //      region position of the seed, as the window's first seed (role 0) and as its second one (role 1, counted only when the first seed does
 //      NOT match there - so every (window, locus, strand) is counted once): the offsets of the first two mismatches decide the distance of
-//      every capture size at once;  X0 / X1 counters per (capture size, window start) by atomics (16 bits each in one word);
+//      every capture size at once;  X0 / X1 counters per (capture size, window start) by atomics (one word: a 31-bit X0 count + a sticky "some X1" bit);
 //   4. k_window_flags   flag = window contains a non-ACGT byte, or not (X0 prints with a leading '1' and X1 == 0) - the reference's substring
 //      tests (:852) accept X0 = 1, 10-19, 100-199, ...; seeds with ONE locus (the common case) are never extended: their windows have
 //      X0 = 1 through the first seed alone.
@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void k_window_verify(const char* __restrict__ 
         if (st < 0 || run < k) continue;
         const int gflip = fwd <= rc ? 0 : 1;
         const uint64_t key = gflip ? rc : fwd;
-        const uint32_t bi = filter_index(key, filter_bits);
+        // the same hash k_kmer_insert set the bit with (kernels_kmer.hip: 32-bit keys hash through filter_index32)
+        const uint32_t bi = k <= 16 ? filter_index32((uint32_t)key, filter_bits) : filter_index(key, filter_bits);
         if (!((filter[bi >> 5] >> (bi & 31)) & 1)) continue;
         const int64_t h = probe(keys, cap_mask, key);
         if (h < 0 || counts[h] < 2) continue;                          // not a seed, or a seed whose only locus this is
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_window_verify(const char* __restrict__ 
                         const int C = W.sizes[c];
                         const int d = (m1 < C) + (m2 < C);
                         if (d == 0) atomicAdd(&ctr[(int64_t)c * total + s], 1u);
-                        else if (d == 1) atomicAdd(&ctr[(int64_t)c * total + s], 1u << 16);
+                        else if (d == 1) atomicOr(&ctr[(int64_t)c * total + s], 1u << 31);   // X1 only matters as zero / non-zero (:852-868): a sticky bit cannot wrap
                     }
                 }
             }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_window_flags(const char* __restrict__ q
         else if (C > nb) f = 1;                                        // a non-ACGT byte: no exact self match
         else {
             const unsigned int w = ctr[(int64_t)c * total + s];
-            unsigned int x0 = (w & 0xFFFFu) + (seed_loci == 1 ? 1u : 0u), x1 = w >> 16;
+            unsigned int x0 = (w & 0x7FFFFFFFu) + (seed_loci == 1 ? 1u : 0u), x1 = w >> 31;   // X0: 31-bit count (cannot carry into the X1 bit: a genome has < 2^31 loci per strand pair here)
             unsigned int lead = x0;
             while (lead >= 10) lead /= 10;                             // "X0:i:1" is a substring test (:852): any count printed with a leading 1
             f = (lead == 1 && x1 == 0) ? 0 : 1;

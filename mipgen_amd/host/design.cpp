@@ -342,6 +342,8 @@ struct RecordOrder {
     std::vector<int64_t> total;                  // records worker k emits (valid once done[k])
     std::vector<char> done;
     bool abort = false;
+    int err_code = 0;                            // the first failure that stopped the run (a worker that only learns of the abort reports this one)
+    std::string err_msg;
     explicit RecordOrder(int n) : total((size_t)n, 0), done((size_t)n, 0) {}
     void publish(int k, int64_t n) { std::lock_guard<std::mutex> lk(m); total[(size_t)k] = n; done[(size_t)k] = 1; cv.notify_all(); }
     bool first_index(int k, int64_t* out)       // blocks until every worker before k has published; false when the run is aborting
@@ -354,7 +356,13 @@ struct RecordOrder {
         *out = s;
         return true;
     }
-    void stop() { std::lock_guard<std::mutex> lk(m); abort = true; cv.notify_all(); }
+    void stop(int code = 0, const std::string& msg = std::string())
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (code && !err_code) { err_code = code; err_msg = msg; }
+        abort = true; cv.notify_all();
+    }
+    void first_error(int* code, std::string* msg) { std::lock_guard<std::mutex> lk(m); *code = err_code; *msg = err_msg; }
 };
 
 struct Channel {                                 // worker -> consumer, at most two windows in flight per device
@@ -408,7 +416,7 @@ void worker(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel*
     catch (std::exception& e) {
         std::unique_ptr<WindowResult> r(new WindowResult());
         r->error = 19; r->msg = std::string("device worker: ") + e.what(); r->last = true;
-        order->stop();
+        order->stop(r->error, r->msg);
         ch->push(std::move(r));
     }
 }
@@ -419,7 +427,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     auto fail_out = [&](int code, const std::string& msg) {
         std::unique_ptr<WindowResult> r(new WindowResult());
         r->error = code; r->msg = msg; r->last = true;
-        order->stop();
+        order->stop(code, msg);
         ch->push(std::move(r));
     };
     const Options& o = d->o;
@@ -480,6 +488,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     // and waits for the totals of the workers before it; a worker whose shard is one window keeps that window's results for the second pass.
     const bool text = !o.silent;
     bool first_window_ready = false;
+    int64_t counted = -1, written = 0;           // records the counting pass saw / the formatting pass numbered (must agree)
     if (text && order->total.size() > 1) {
         int64_t mine = 0;
         std::vector<int64_t> em;
@@ -494,7 +503,18 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
         }
         first_window_ready = nw == 1;
         order->publish(k_worker, mine);
-        if (!order->first_index(k_worker, &all_before)) { mipgen_accel_destroy(h); return; }
+        if (!order->first_index(k_worker, &all_before)) {
+            // another worker failed (or the consumer stopped the run) while this one was counting.  The consumer may be blocked on THIS worker's
+            // channel (it drains the channels in worker order): it must get a terminal result - carrying the failure that stopped the run.
+            mipgen_accel_destroy(h);
+            std::unique_ptr<WindowResult> r(new WindowResult());
+            order->first_error(&r->error, &r->msg);
+            if (!r->error) { r->error = 19; r->msg = "device worker stopped: the run was aborted"; }
+            r->last = true;
+            ch->push(std::move(r));
+            return;
+        }
+        counted = mine;
         lap(3);
     }
     for (int w = 0; w < nw; w++) {
@@ -536,6 +556,13 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
             if (mipgen_accel_download_text(h, res->text.data(), n_bytes)) { bail(19); return; }
             res->has_text = true;
             all_before += n_rec;
+            written += n_rec;
+            if (counted >= 0 && (written > counted || (w == nw - 1 && written != counted))) {
+                // the design-wide record numbers of the workers behind this one were derived from `counted`
+                mipgen_accel_destroy(h);
+                fail_out(19, "all_mips numbering: the counting pass saw " + std::to_string(counted) + " records, the formatting pass " + std::to_string(written));
+                return;
+            }
         }
         lap(4);
         for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;

@@ -267,6 +267,12 @@ def test_window_uniqueness_vs_brute_force():
     got20 = acc.window_uniqueness([g1, g2], regions[:2], sizes, seed_len=20)
     for t30, t20 in zip(got, got20):
         assert np.array_equal(t30, t20)
+    # seeds of <= 16 bases are 32-bit keys: the Bloom bit is set and tested with the 32-bit hash (the verify pass once tested the 64-bit one:
+    # nearly every locus of a repeated seed was dropped, X0 = 0, every window flagged)
+    for k in (16, 12):
+        gotk = acc.window_uniqueness([g1, g2], regions[:2], sizes, seed_len=k)
+        for t30, tk in zip(got, gotk):
+            assert np.array_equal(t30, tk), k
     with pytest.raises(capi.AccelError):
         acc.window_uniqueness([g1], regions, [50], seed_len=30)                           # a window must hold two disjoint seeds
     acc.close()
