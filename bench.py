@@ -28,6 +28,16 @@ with ONE gather of the condensed survivors to rank 0 (RCCL over xGMI), where the
                                          the first 65,536 of its 200,000 exons (--regions 200000 for all of them: ~20 s per pass per GPU-share)
   --scaling weak (default for N = 1)     the BED grows with N: N practice62-sized instances / N x --regions
 
+The scaling curve (driver: `bench.py --gpus N` for N = 1, 2, 4, 8) is ONE workload family: N > 1 shards the first 65,536 exons of the exome BED
+(strong scaling); the N = 1 default line keeps the configs[1] headline and carries a top-level `scale_base` = the same 65,536-exon BED measured
+on the one GPU in the same run (`python bench.py --gpus 1 --config exome --regions 65536 --scaling strong` is that point as a line of its own).
+Every line names `rccl_ranks` (the world size torch.distributed reports after init_process_group; 1 without a process group) and the dense
+candidates of every rank.
+
+--measure-traffic   HBM bytes of the dominant kernel measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE - they do
+                    not share a pass) of the same workload, started before this process touches the GPU; `roofline.traffic` then comes from
+                    them (FETCH_SIZE doubled: the gfx950 correction of MI355X_MICROARCH.md, HBM section) instead of from profiles/.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -49,6 +59,7 @@ MODEL_RHO = -2.2
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 ALG_BYTES_PER_CAND = 16          # 8 B score + 8 B integer record written per candidate
+SCALE_REGIONS = 65536            # exons of the strong-scaling BED (--gpus N > 1) and of the N = 1 line's `scale_base`
 
 CONFIGS = {
     #             capture      method      default regions
@@ -79,6 +90,8 @@ def parse_args():
     ap.add_argument("--exome-regions", type=int, default=200000, help="exons of the exome200k line in `extra` (N = 1 default run; 0 = skip)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained run of the headline in `extra` (0 = skip)")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the in-run oracle check (profiling runs)")
+    ap.add_argument("--scale-base-regions", type=int, default=65536, help="exons of the `scale_base` line (N = 1 default run; 0 = skip): what --gpus N > 1 shards")
+    ap.add_argument("--measure-traffic", action="store_true", help="measure the dominant kernel's HBM bytes in this run (child rocprofv3 --pmc passes)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
     if a.config is None:
@@ -86,7 +99,7 @@ def parse_args():
     if a.scaling is None:
         a.scaling = "weak" if world == 1 else "strong"
     if not a.regions and a.config == "exome" and world > 1 and a.scaling == "strong":
-        a.regions = 65536
+        a.regions = SCALE_REGIONS
     return a
 
 
@@ -309,7 +322,7 @@ def cgroup_cpu_quota() -> float:
 
 def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
     """The reference CPU path (oracle/_ref: the real reference compiled from /root/reference by oracle/Makefile) timed on this box's host
-    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (its 8 shortest regions: seconds of CPU work each).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
+    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (8 regions at every 4th rank of its length-sorted BED: seconds to ~20 s of CPU work each).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
       leg A  one process per sample region, -O2, all_mips written: the emitted-candidate count of every sample region and the single-process
              rate; beside them ONE process of the binary AS SHIPPED (/root/reference/makefile:3-4: no -O flag) on the shortest region;
       leg B  C = all physical cores (capped by the container's cgroup CPU quota, if any) processes at once, -O2, -silent_mode on (no all_mips text): `value` = sum over the processes of
@@ -338,7 +351,10 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                 break
     except OSError:
         pass
-    pool = sorted(ivs, key=lambda v: (v.bed_end - v.bed_start))[:8]          # the 8 shortest regions: seconds of CPU work each
+    # 8 sample regions at every 4th rank of the length-sorted BED (ranks 0, 4, ... 28 of 62: 60 to ~150 bp, one to all nine capture sizes after
+    # the static skip of mipgen.cpp:429) - seconds to ~20 s of reference CPU work each, not only the shortest regions
+    by_len = sorted(ivs, key=lambda v: (v.bed_end - v.bed_start))
+    pool = [by_len[min(4 * i, len(by_len) - 1)] for i in range(8)]
     shortest = min(range(len(pool)), key=lambda i: pool[i].bed_end - pool[i].bed_start)
     work = tempfile.mkdtemp(prefix="mipgen_cpu_")          # not /dev/shm: it is mounted noexec on the GPU boxes (the binary is copied beside its model)
 
@@ -383,7 +399,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                    "scope": "reference binary, tile_regions only (enumeration + scoring + selection; from its 'bwa copy number analysis finished' line to exit), "
                             "-O2, -silent_mode on in the multi-process leg; end_to_end_value includes its input stage and the stand-in bwa / FASTQ I/O",
                    "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2, -silent_mode on), one region each from the "
-                             f"{len(pool)} shortest regions ({'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp), "
+                             f"{len(pool)} sample regions (every 4th of the length-sorted BED: {'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp), "
                              f"{n_all} emitted candidates, tile_regions {min(b['hot'] for b in B):.1f}-{max(b['hot'] for b in B):.1f} s per process, {wall:.1f} s wall; "
                              f"alone: {A[shortest]['len']}-bp region, {A[shortest]['n']} candidates, tile_regions {A[shortest]['hot']:.1f} s of {A[shortest]['seconds']:.1f} s"}
             if O0:
@@ -406,15 +422,64 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
         shutil.rmtree(work, ignore_errors=True)
 
 
+def measure_traffic(args, kernel: str):
+    """HBM bytes per launch of `kernel`, measured in this run: one child `rocprofv3 --kernel-trace --pmc <counter>` pass per counter
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with other trace domains) over the same workload at --steps 2 --warmup 1.
+    Must run BEFORE this process touches the GPU (the children are started as ordinary child processes, the program itself after `--`).
+    Counter unit: KiB.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM: gfx950 tallies 128-byte requests of coalesced reads at 64 bytes; the raw
+    value is kept beside it), WRITE_SIZE is taken as it reads.  Returns None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", args.config, "--scaling", args.scaling,
+            "--nsv", str(args.nsv), "--no-cpu-baseline", "--no-extras", "--no-parity-gate"]
+    if args.regions:
+        base += ["--regions", str(args.regions)]
+    if args.method:
+        base += ["--method", args.method]
+    if args.min_capture:
+        base += ["--min-capture", str(args.min_capture)]
+    if args.max_capture:
+        base += ["--max-capture", str(args.max_capture)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mipgen_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + base, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+            vals = []
+            for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None
+            got[ctr] = (sum(vals) / len(vals) * 1024.0, len(vals))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_corrected": 2.0 * fetch, "write_bytes": write,
+            "launches_averaged": min(got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]), "kernel": kernel,
+            "how": "child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this workload (--steps 2 --warmup 1), mean per launch, "
+                   "summed over the device; counter unit KiB; FETCH_SIZE x 2 = the gfx950 correction (MI355X_MICROARCH.md, HBM section)"}
+
+
 def newest_profile(pattern: str):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return files[-1] if files else None
 
 
 
-def exome_line(args, device: int, stream: int, model_path: str) -> dict:
+def exome_line(args, device: int, stream: int, model_path: str, n_regions: int = 0) -> dict:
     """The metric's own multi-GPU config on ONE GPU (BASELINE configs[3]: exome200k, capture 150-170, SVR): one warm-up pass over the first result
-    window, then one timed pass over all of it through score_condense_all (records + k_svr_dense + replay / condense per result window)."""
+    window, then one timed pass over all of it through score_condense_all (records + k_svr_dense + replay / condense per result window).
+    n_regions = SCALE_REGIONS gives the `scale_base` line: exactly the BED `--gpus N > 1` cuts N ways."""
     import torch
     from mipgen_amd import capi, workloads
     P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
@@ -422,7 +487,7 @@ def exome_line(args, device: int, stream: int, model_path: str) -> dict:
     acc.load_model_file(model_path)
     t0 = time.perf_counter()
     chrom_len, all_iv = workloads.exome_layout()
-    ivs = all_iv[:min(args.exome_regions, len(all_iv))]
+    ivs = all_iv[:min(n_regions or args.exome_regions, len(all_iv))]
     regions = workloads.build_exome(acc, chrom_len, ivs, P, with_lrc=True)
     grids = acc.upload(regions)
     t_build = time.perf_counter() - t0
@@ -456,6 +521,10 @@ def main() -> None:
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    traffic_run = None
+    if args.measure_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # child rocprofv3 passes, before this process initialises the GPU
+        traffic_run = measure_traffic(args, "k_svr_dense" if (args.method or CONFIGS[args.config][1]) == "svr" else "k_logistic_dense")
 
     import numpy as np
     import torch
@@ -541,11 +610,15 @@ def main() -> None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        tc = torch.tensor([n_cand], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
-        total_cand = int(tc.item())
+        per = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(per, torch.tensor([n_cand], dtype=torch.int64, device="cuda"))
+        cand_per_rank = [int(t.item()) for t in per]
+        total_cand = sum(cand_per_rank)
+        rccl_ranks = dist.get_world_size()                  # what the process group itself reports
     else:
         total_cand = n_cand
+        cand_per_rank = [n_cand]
+        rccl_ranks = 1
 
     if rank == 0:
         emitted, surv = acc.download_survivors()
@@ -562,7 +635,9 @@ def main() -> None:
         hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
         traffic, traffic_src = None, None
         tpath = newest_profile("r*_hbm_traffic.json")
-        if tpath and args.config == "practice62" and method == "svr" and not distributed:
+        if traffic_run:
+            traffic = traffic_run["bytes_per_launch"]
+        elif tpath and args.config == "practice62" and method == "svr" and not distributed:
             try:
                 traffic = json.load(open(tpath)).get("k_svr_dense_bytes_per_launch")
                 traffic_src = os.path.relpath(tpath, ROOT)
@@ -584,15 +659,18 @@ def main() -> None:
         else:
             roof = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
                     "kernel": kern, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
-        if traffic_src:
+        if traffic_run:
+            roof["traffic_measured_in_this_run"] = True
+            roof["traffic_detail"] = traffic_run
+        elif traffic_src:
             roof["traffic_from_profile"] = traffic_src
             roof["traffic_measured_in_this_run"] = False
         out = {
             "metric": f"candidate MIPs scored/sec ({'SVR' if method == 'svr' else 'logistic'})", "value": value, "unit": "candidates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "n_sv": n_sv, "regions_rank0": len(regions), "dense_candidates_rank0": n_cand,
-                       "dense_candidates_all_ranks": total_cand, "result_windows_rank0": acc.window_count(),
+                       "dense_candidates_all_ranks": total_cand, "dense_candidates_per_rank": cand_per_rank, "result_windows_rank0": acc.window_count(),
                        "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()),
                        # reference-equivalent rate: candidates the reference would have constructed, per second (rank 0's share)
                        "emitted_candidates_per_s_rank0": float(emitted.sum()) * args.steps / dt,
@@ -617,6 +695,13 @@ def main() -> None:
         # ---- extras (N = 1, default workload): throughput vs nSV, and the logistic scorer on the same batch -------------------------
         if not args.no_extras and not distributed and args.config == "practice62" and method == "svr":
             extra = []
+            if args.scale_base_regions > 0:
+                # the N = 1 point of the scaling curve: the BED that `--gpus N` (N > 1) cuts N ways, on this one GPU, in this run
+                sb = exome_line(args, local_rank, stream, model_path, n_regions=args.scale_base_regions)
+                out["scale_base"] = {"value": sb["value"], "unit": sb["unit"], "workload": sb["what"], "seconds": sb["seconds"],
+                                     "dense_candidates": sb["dense_candidates"], "regions": sb["regions"], "n_gpus": 1, "scaling": "strong",
+                                     "equivalent_command": f"python bench.py --gpus 1 --config exome --regions {args.scale_base_regions} --scaling strong",
+                                     "roofline": sb["roofline"]}
             if args.sustain_seconds > 0:
                 # the headline again, long enough for an outside observer (the driver's GPU-busy sampler) to see: same step, >= 2 s
                 reps = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)

@@ -49,6 +49,12 @@ def gen_models(genome: bytes) -> None:
     os.makedirs(os.path.join(HERE, "models"), exist_ok=True)
     synth.synthetic_svr_model(os.path.join(HERE, "models", "svr_syn_64.model"), genome, 64, seed=7)
     synth.synthetic_svr_model(os.path.join(HERE, "models", "svr_syn_200.model"), genome, 200, seed=8, drop_zero_frac=0.5)
+    gen_short_model(genome)
+
+
+def gen_short_model(genome: bytes) -> None:
+    # support vectors from SHORT captures (scan sizes 2..70): the model of the designs that leave the tiled SVR kernel's limits
+    synth.synthetic_svr_model(os.path.join(HERE, "models", "svr_syn_short_48.model"), genome, 48, seed=9, gamma=0.004, rho=1.535, capture=(47, 110))
 
 
 def gen_candidates(genome: bytes) -> None:
@@ -159,6 +165,10 @@ DESIGNS2 = [
     dict(name="limits_svr_parameter_file", method="svr", ivs=[("1", 77000, 77350, "s")], minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0", snps=False,
          trf=False, bwa="hashed", model="svr_syn_64.model", extra=[],
          params_file="# limits of the SVR design\n-svr_optimal_score 1.9\n-svr_priority_score 1.2\n-target_arm_copy 8\nnot an option line\n"),
+    # scan sizes from 2 and -capture_increment 1: outside the tiled SVR kernel's limits (the list route of the accelerator), inside what the
+    # reference accepts (mipgen.cpp:222-261, 427-444: any range / increment)
+    dict(name="svr_scan_size_2_increment_1", method="svr", ivs=[("1", 26000, 26045, "w")], minC=47, maxC=70, sums=[40, 41, 42, 43, 44, 45], flank=0,
+         tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_short_48.model", extra=["-capture_increment", "1"]),
 ]
 
 
@@ -244,6 +254,8 @@ def main() -> None:
                 gz.write(genome[i:i + 60] + b"\n")
         gen_models(genome)
         gen_candidates(genome)
+    elif not os.path.exists(os.path.join(HERE, "models", "svr_syn_short_48.model")):
+        gen_short_model(genome)
     for d in DESIGNS:
         if not only or d["name"] in only:
             gen_design(genome, d)

@@ -441,21 +441,61 @@ def test_long_range_batch(genome):
     acc.close()
 
 
-def test_logistic_designs_are_not_bound_by_svr_limits(genome):
-    """More than 240 arm pairs and scan sizes below 3 are limits of the dense SVR kernel only: logistic designs run, SVR requests on
-    such a handle fail with a message (the reference accepts both)."""
+def test_parameter_sets_outside_the_dense_svr_limits(genome, tmp_path):
+    """More than 240 arm pairs, scan sizes below 3 and -capture_increment 1 over a 100-base range are outside the tiled SVR kernel's limits;
+    the reference accepts any -arm_lengths / -capture_increment / range (mipgen.cpp:222-261, 427-444).  Logistic designs never were bound by
+    them; SVR requests on such a handle take the list route (every dense candidate through k_features_batch + k_svr_gemm) and must give the
+    oracle's dense grid: records bit-exact, scores within 1e-5, the replayed enumeration and the condensed survivors identical."""
+    from mipgen_amd import synth
+    # (a) 255 arm pairs: logistic as before, SVR through the list route
     pairs = [(e, l) for e in range(16, 31) for l in range(14, 31)]          # 255 pairs
     P = capi.make_params(150, 155, arm_pairs=pairs)
     acc = capi.Accel(P)
-    rd = capi.build_region(genome, "1", 9000, 9030, P, bwa_mode="hashed", label="many")
+    rd = capi.build_region(genome, "1", 9000, 9030, P, bwa_mode="hashed", label="many", lrc=np.full(44, 0.02))
     grids, scores, records = acc.score_regions([rd], capi.SCORE_LOGISTIC)
     _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_LOGISTIC, None)
     assert np.array_equal(records, or_)
     ok, mx = _close(scores, os_)
     assert ok.all(), mx
-    acc.load_model_file(os.path.join(H.GOLDEN, "models", "svr_syn_64.model"))
-    with pytest.raises(capi.AccelError, match="too many arm pairs"):
-        acc.score_window(0, capi.SCORE_SVR)
+    mp64 = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    acc.load_model_file(mp64)
+    om = po.Model(mp64)
+    acc.score_window(0, capi.SCORE_SVR)
+    s, r = acc.download()
+    _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+    assert np.array_equal(r, or_)
+    ok, mx = _close(s, os_)
+    assert ok.all(), mx
+    assert np.unique(np.round(s[np.isfinite(s)], 6)).size > 1000             # real kernel values, not one constant
+    acc.close()
+    # (b) arm sums 30..60 (195 pairs), capture 62-162 in steps of 1, scan sizes from 2: a model whose support vectors come from short captures
+    mp = str(tmp_path / "short.model")
+    synth.synthetic_svr_model(mp, genome, 48, seed=5, gamma=0.004, capture=(62, 120))
+    om = po.Model(mp)
+    pairs = synth.arm_pairs_from_sums(list(range(30, 61)))
+    assert len(pairs) == 195 and max(e + l for e, l in pairs) == 60
+    P = capi.make_params(62, 162, score_method=capi.SCORE_SVR, arm_pairs=pairs, capture_increment=1)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    rd = capi.build_region(genome, "1", 9000, 9056, P, bwa_mode="hashed", label="wide", lrc=np.linspace(0.01, 0.3, 44))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    og, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+    assert grids[0].count == og.count and og.n_sizes >= 20
+    assert np.array_equal(records, or_)
+    ok, mx = _close(scores, os_)
+    assert ok.all(), mx
+    fin = scores[np.isfinite(scores) & (capi.rec_flags(records) & capi.FLAG_VALID != 0)]
+    assert np.unique(np.round(fin, 6)).size > 1000
+    acc.replay_condense()
+    em, sv, mask = acc.download_replay()
+    n_emit, omask = po.replay_region(P, rd, scores, records)
+    assert int(em[0]) == n_emit and np.array_equal(mask, omask)
+    osurv = po.condense_region(P, rd, scores, records, omask)
+    assert np.array_equal(sv["cand_index"], osurv["cand_index"]) and np.array_equal(sv["record"], osurv["record"])
+    # the silent path (what the command line runs) takes the same route
+    acc.score_condense_all(capi.SCORE_SVR)
+    em2, sv2 = acc.download_survivors()
+    assert int(em2[0]) == n_emit and np.array_equal(sv2["cand_index"], osurv["cand_index"])
     acc.close()
 
 
