@@ -53,9 +53,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# rho of the synthetic SVR models: places ~10 % of the arm-sum lists' last pairs above the reference's upper score limit (2.2), so the replay of
-# the score-dependent early exits (mipgen.cpp:430,434) really skips candidates on the bench workloads (emitted < dense)
-MODEL_RHO = -2.2
+# rho of the synthetic SVR models (mipgen_amd/workloads.py: MODEL_RHO, per workload): places ~12 % of the arm-sum lists' last pairs above the
+# reference's upper score limit (2.2), so the replay of the score-dependent early exits (mipgen.cpp:430,434) really skips candidates on
+# every bench workload (emitted < dense), the exome included
+MODEL_RHO = -2.2                 # practice62 (the headline)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 ALG_BYTES_PER_CAND = 16          # 8 B score + 8 B integer record written per candidate
@@ -484,7 +485,8 @@ def exome_line(args, device: int, stream: int, model_path: str, n_regions: int =
     from mipgen_amd import capi, workloads
     P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
     acc = capi.Accel(P, device=device, stream=stream)
-    acc.load_model_file(model_path)
+    # the same support vectors as the headline's model, rho placed for the exome (workloads.MODEL_RHO): its replay takes early exits too
+    acc.load_model_file(workloads.svr_model_path(os.path.dirname(model_path), workloads.practice62()[0], args.nsv, rho=workloads.MODEL_RHO["exome"]))
     t0 = time.perf_counter()
     chrom_len, all_iv = workloads.exome_layout()
     ivs = all_iv[:min(n_regions or args.exome_regions, len(all_iv))]
@@ -551,7 +553,7 @@ def main() -> None:
     m = capi.SCORE_SVR if method == "svr" else capi.SCORE_LOGISTIC
     model_path = None
     if method == "svr":
-        model_path = workloads.svr_model_path(cache, model_genome, args.nsv, rho=MODEL_RHO)
+        model_path = workloads.svr_model_path(cache, model_genome, args.nsv, rho=workloads.MODEL_RHO[args.config])
         acc.load_model_file(model_path)
     regions = build(acc)
     if args.window_candidates:

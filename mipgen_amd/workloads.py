@@ -23,6 +23,12 @@ from . import capi, synth
 
 CHROMS_24 = [str(i) for i in range(1, 23)] + ["X", "Y"]
 
+# rho of the synthetic SVR model per workload, placed (rho_for_exit_rate below, measured on 800 exons of each config) so that ~12 % of the
+# arm-sum lists' last pairs score above the reference's upper limit (2.2): the replay of the early exits (mipgen.cpp:430,434) then really
+# removes candidates - practice62 / capture 140-180: 57 % of the dense grid, exome / 150-170: 19 %, exome + SNPs / 120-250: 56 %.  (With the
+# practice62 value the exome's last pairs - l = 18, the lowest-scoring arm of the synthetic model - never reach 2.2: emitted == dense.)
+MODEL_RHO = {"practice62": -2.2, "regions5k": -2.2, "exome": -4.568, "exome_snp": -1.645}
+
 
 def practice62(seed: int = 20140101, genome_len: int = 400_000, n_regions: int = 62) -> Tuple[bytes, List[synth.Interval]]:
     """`practice62`: one 400 kb chromosome "7", 62 exon-like intervals (EGFR/TERT/BRAF-like)."""
@@ -239,3 +245,23 @@ def dense_candidates(ivs: Sequence[synth.Interval], params: capi.Params, detail:
         npos[i] = max(0, ef - cur)
         nk[i] = K - k0
     return (out, npos, nk) if detail else out
+
+
+def rho_for_exit_rate(P: capi.Params, grids, scores: np.ndarray, rho_now: float, target: float = 0.12) -> float:
+    """The rho that puts `target` of the arm-sum lists' LAST pairs (max over the two strands: previous_best_score after the list,
+    /root/reference/mipgen.cpp:495) above the upper score limit, given dense scores computed with rho_now - rho is an additive constant of
+    the SVR score (svm.cpp:2515), so the early exits of mipgen.cpp:430,434 can be placed on any workload without re-scoring."""
+    A = P.n_arm_pairs
+    sums = [P.arm_ext[i] + P.arm_lig[i] for i in range(A)]
+    last = [i for i in range(A) if i == A - 1 or sums[i + 1] != sums[i]]
+    vals = []
+    for g in grids:
+        if g.count == 0:
+            continue
+        s = scores[g.offset:g.offset + g.count].reshape(g.n_pos, g.n_sizes, 2, A)[..., last]
+        with np.errstate(invalid="ignore"):
+            v = np.nanmax(s, axis=2).ravel()
+        vals.append(v[np.isfinite(v) & (v != 0.0)])
+    v = np.concatenate(vals)
+    q = float(np.quantile(v, 1.0 - target))
+    return round(q + rho_now - P.upper_score_limit, 3)

@@ -142,7 +142,7 @@ def _decode(P, g, idx):
 def exome_full():
     chrom_len, ivs = workloads.exome_layout()
     P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
-    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 1024, rho=-2.2)
+    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 1024, rho=workloads.MODEL_RHO["exome"])   # ~12 % of the lists exit early
     acc = capi.Accel(P)
     acc.load_model_file(mp)
     regions = workloads.build_exome(acc, chrom_len, ivs, P)
@@ -171,7 +171,11 @@ def test_full_exome_svr(exome_full):
     assert np.array_equal(rel[have] // per_pos[have], pos_in_region[have])
     assert np.array_equal((rel[have] // A) & 1, (slot & 1)[have])
     assert np.all(capi.rec_flags(surv["record"][have]) & capi.FLAG_VALID)
-    assert 0 < emitted.sum() <= sum(g.count for g in grids)
+    # the early exits of mipgen.cpp:430,434 are taken at exome scale (K = 1..5 capture sizes): a tenth to a half of the dense grid is never
+    # constructed, and that on at least a tenth of the exons
+    dense = np.array([g.count for g in grids], dtype=np.int64)
+    assert 0.5 * dense.sum() < emitted.sum() < 0.9 * dense.sum(), (int(emitted.sum()), int(dense.sum()))
+    assert (emitted < dense).mean() > 0.10
     # a shard alone
     lo, hi = 70_000, 72_000
     a = capi.Accel(P)
@@ -261,3 +265,72 @@ def test_full_exome_snps_full_sweep_logistic():
             assert np.array_equal(mine["record"], osurv["record"])
     a.close()
     acc.close()
+
+
+def test_full_exome_snps_full_sweep_svr():
+    """configs[4] at its full size WITH the SVR (1.35e11 dense candidates, 1,024 support vectors: ~70 s of k_svr_dense over ten-odd result
+    windows): the same invariants as the logistic sweep, early exits taken (rho placed for this workload), a shard alone on a second handle
+    gives the same survivors, and three exons go through the oracle (replay + condense of the exon's dense grid, and the oracle's own libsvm
+    arithmetic on sampled candidates)."""
+    chrom_len, ivs = workloads.exome_layout()
+    P = capi.make_params(120, 250, score_method=capi.SCORE_SVR)
+    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 1024, rho=workloads.MODEL_RHO["exome_snp"])
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    regions = workloads.build_exome(acc, chrom_len, ivs, P, snps=True)
+    grids = acc.upload(regions)
+    total = sum(g.count for g in grids)
+    assert total > 1.2e11 and acc.window_count() >= 8
+    acc.score_condense_all(capi.SCORE_SVR)
+    emitted, surv = acc.download_survivors()
+    emitted, surv = emitted.copy(), surv.copy()
+    acc.close()                                                               # its result windows hold most of the HBM
+    pos0 = np.concatenate([[0], np.cumsum([g.n_pos for g in grids])])
+    assert surv.shape[0] == 2 * pos0[-1]
+    dense = np.array([g.count for g in grids], dtype=np.int64)
+    assert 0.2 * total < emitted.sum() < 0.8 * total and (emitted < dense).mean() > 0.10      # the early exits are taken
+    have = surv["cand_index"] >= 0
+    rec = surv["record"][have]
+    assert np.all(capi.rec_flags(rec) & capi.FLAG_VALID)
+    assert (capi.rec_snp_count(rec) > 0).sum() > 100_000 and (capi.rec_snp_count(rec) == 0).mean() > 0.5
+    A = P.n_arm_pairs
+    rel = _relative(surv, grids, pos0)
+    slot = np.arange(surv.shape[0])
+    per_pos = np.repeat(np.array([g.n_sizes * 2 * A for g in grids]), 2 * np.diff(pos0))
+    pos_in_region = slot // 2 - np.repeat(pos0[:-1], 2 * np.diff(pos0))
+    assert np.array_equal(rel[have] // per_pos[have], pos_in_region[have])
+    assert np.array_equal((rel[have] // A) & 1, (slot & 1)[have])
+    # a shard alone (another handle = another rank), then three of its exons against the oracle
+    om = po.Model(mp)
+    rng = np.random.default_rng(4)
+    a = capi.Accel(P)
+    a.load_model_file(mp)
+    lo, hi = 150_000, 150_400
+    gs = a.upload(regions[lo:hi])
+    a.score_condense_all(capi.SCORE_SVR)
+    e, s = a.download_survivors()
+    p0 = np.concatenate([[0], np.cumsum([g.n_pos for g in gs])])
+    assert np.array_equal(e, emitted[lo:hi])
+    assert np.array_equal(_relative(s, gs, p0), rel[2 * pos0[lo]:2 * pos0[hi]])
+    ref = surv[2 * pos0[lo]:2 * pos0[hi]]
+    assert np.array_equal(s["record"], ref["record"])
+    assert np.nanmax(np.abs(s["score"] - ref["score"])) < 1e-9               # another SV split of the launch: sums in another order
+    sizes = np.array([g.count for g in gs])
+    for k in rng.choice(np.nonzero((sizes > 50_000) & (sizes < 1_500_000))[0], 3, replace=False).tolist():
+        ri = lo + int(k)
+        rd = regions[ri]
+        g1, scores, records = a.score_regions([rd], capi.SCORE_SVR)
+        n_emit, omask = po.replay_region(P, rd, scores, records)
+        osurv = po.condense_region(P, rd, scores, records, omask)
+        mine = surv[2 * pos0[ri]:2 * pos0[ri + 1]]
+        assert emitted[ri] == n_emit, ri
+        assert np.array_equal(np.where(mine["cand_index"] >= 0, mine["cand_index"] - grids[ri].offset, -1), osurv["cand_index"]), ri
+        assert np.array_equal(mine["record"], osurv["record"])
+        valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
+        lrc = np.array(rd.c.long_range_content[:])
+        for idx in rng.choice(valid, size=min(40, valid.size), replace=False):
+            sk, dsg = po.design(P, rd, _decode(P, g1[0], int(idx)))
+            assert not sk
+            so, _, oints = po.score_designed(dsg, capi.SCORE_SVR, lrc, om)
+            assert abs(scores[idx] - so) <= TOL or (np.isnan(scores[idx]) and np.isnan(so)), (ri, int(idx), scores[idx], so)
+    a.close()

@@ -103,6 +103,28 @@ def test_bench_two_ranks_strong_scaling_child_process():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "exome200k" in line["config"]["workload"]
     assert line["parity_checked"] is True and line["value"] > 0
     assert line["config"]["survivors_gathered_per_step"] > 0
+    # the process group itself reports two ranks, and both hold a share of the BED (cost-model shards: within a factor of 1.5 of each other)
+    assert line["rccl_ranks"] == 2
+    per = line["config"]["dense_candidates_per_rank"]
+    assert len(per) == 2 and min(per) > 0 and sum(per) == line["config"]["dense_candidates_all_ranks"] and max(per) < 1.5 * min(per)
+
+
+def test_bench_scale_base_line_is_the_sharded_workload():
+    """The N = 1 point of the scaling curve: `bench.py --gpus 1 --config exome --regions R --scaling strong` runs, on one GPU, exactly the BED
+    that `--gpus N` cuts N ways (same describe string, same dense-candidate total as the sum over the ranks of an N-rank run), and names one
+    RCCL-free rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "exome", "--regions", "2048", "--scaling", "strong",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["scaling"] == "strong"
+    assert "exome200k" in line["config"]["workload"] and "first 2048" in line["config"]["workload"]
+    assert line["config"]["dense_candidates_per_rank"] == [line["config"]["dense_candidates_all_ranks"]]
+    assert line["parity_checked"] is True and line["roofline"]["frac"] > 0
 
 
 def test_region_cost_weights_balance_the_svr_shards():

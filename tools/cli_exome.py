@@ -45,7 +45,7 @@ def main() -> None:
     synth.write_bed(os.path.join(work, "exome.bed"), ivs)
     exe = os.path.join(work, "mipgen")
     os.symlink(os.path.join(ROOT, "mipgen_amd", "mipgen"), exe)
-    model = workloads.svr_model_path(os.path.join(work, "cache"), workloads.practice62()[0], 1024, rho=-2.2)
+    model = workloads.svr_model_path(os.path.join(work, "cache"), workloads.practice62()[0], 1024, rho=workloads.MODEL_RHO["regions5k" if config == "regions5k" else "exome"])
     shutil.copy(model, os.path.join(work, "mipgen_svr.model"))
     print(f"inputs: {len(ivs)} intervals on {len(chroms)} chromosomes written in {time.time() - t0:.1f} s", flush=True)
     argv = [exe, "-regions_to_scan", os.path.join(work, "exome.bed"), "-project_name", "out", "-min_capture_size", capture[0], "-max_capture_size", capture[1],
