@@ -65,6 +65,10 @@ struct mipgen_design {
     int n_devices = 0;                           // device workers of mipgen_design_run (0 = every visible device)
     int64_t window_candidates = 0;               // cap on the candidates of one result window (0 = the default policy)
     bool timing = false;                         // stage timings on stderr
+    // the per-region "[mipgen] feature #N" lines of stderr (mipgen.cpp:417): the same bytes in the same order, written a few KB at a time -
+    // one write() per region was 200,000 system calls on the critical path of an exome design
+    std::string err_lines;
+    void flush_err() { if (!err_lines.empty()) { std::cerr.write(err_lines.data(), (std::streamsize)err_lines.size()); err_lines.clear(); } }
 };
 
 extern "C" {
@@ -148,6 +152,7 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         d->selector.reset(new Selector(d->o, d->tables, d->out));
         clk.lap("per-region tables");
     } catch (int e) {
+        d->flush_err();
         char msg[96];
         snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);                             // mipgen.cpp:2029-2032
         return fail(e == 1 ? MIPGEN_HOST_E_USAGE : MIPGEN_HOST_E_INPUT, e, msg);
@@ -162,6 +167,7 @@ int mipgen_design_close(mipgen_design* d)
 {
     if (!d) return 0;
     if (!d->closed) {
+        d->flush_err();
         Outputs& out = d->out;
         const Options& o = d->o;
         out.all.close(); out.collapsed.close(); out.picked.close(); out.snp.close();
@@ -243,7 +249,8 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
         {
             char line[48];
             const int n = snprintf(line, sizeof line, "[mipgen] feature #%d\n", i + 1);
-            std::cerr.write(line, n);                                                // unbuffered stream: one write, not three
+            d->err_lines.append(line, (size_t)n);
+            if (d->err_lines.size() >= 4096) d->flush_err();
         }
         if (!o.silent && scores && records && emitted_mask) {
             // the reference's generation order: position, size, pair, plus then minus (mipgen.cpp:421-491)
@@ -262,23 +269,25 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
             out.all << buf;
         } else out.all_counter += emitted;
         out.progress << "condensing feature #" << i + 1 << "\ncollapsing feature #" << i + 1 << '\n';
-        std::vector<mipgen_survivor> rs(survivors, survivors + 2 * (size_t)grid->n_pos);
-        for (auto& s : rs) if (s.cand_index >= 0) s.cand_index -= grid->offset;       // region-local for make_cand
         const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;   // mixed scans with logistic (:467)
         const double lower = method == MIPGEN_SCORE_SVR ? o.svr_priority : o.logistic_priority;
         const double upper = method == MIPGEN_SCORE_SVR ? o.svr_optimal : o.logistic_optimal;
         FnRescorer rs_fn;
         rs_fn.fn = rescore; rs_fn.ctx = ctx; rs_fn.region = i;
         if (o.score_method == MIPGEN_SCORE_MIXED && !rescore) return fail(MIPGEN_HOST_E_USAGE, 0, "a mixed design needs the SVR re-score hook");
-        d->selector->run_region(r, *grid, rs, o.score_method == MIPGEN_SCORE_MIXED ? &rs_fn : nullptr, lower, upper, collapsed, n_bases);
+        // the survivor and collapse arrays ARE the selection stage's tables (cand_index - grid->offset = the region-local dense index)
+        d->selector->run_region(r, *grid, survivors, grid->offset, o.score_method == MIPGEN_SCORE_MIXED ? &rs_fn : nullptr, lower, upper, collapsed, n_bases);
     } catch (int e) {
+        d->flush_err();
         char msg[96];
         snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);
         return fail(MIPGEN_HOST_E_INPUT, e, msg);
     } catch (std::exception& e) {
+        d->flush_err();
         return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
     }
     d->next_region = i + 1;
+    if (d->next_region == (int)d->regions.size()) d->flush_err();
     return 0;
 }
 
@@ -678,7 +687,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
             const auto tw1 = std::chrono::steady_clock::now();
             t_wait += std::chrono::duration<double>(tw1 - tw0).count();
-            if (w->error) { rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
+            if (w->error) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
             if (w->has_text) d->out.all.write(w->text.data(), (std::streamsize)w->text.size());     // numbered by the device from this window's first index
             int64_t pos0 = 0;
             for (int bi = 0; bi < w->r1 - w->r0 && rc == 0; bi++) {
@@ -699,6 +708,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             if (w->last || rc) break;
         }
     }
+    d->flush_err();
     if (clk.on) std::cerr << "[mipgen timing] tile_regions: waiting for the device workers " << t_wait << " s, selection stage " << t_select << " s\n";
     if (clk.on && d->selector) std::cerr << "[mipgen timing] selection stage: tables " << d->selector->stage_seconds[0] << " s, collapsed output " << d->selector->stage_seconds[1]
                                           << " s, pick " << d->selector->stage_seconds[2] << " s, clean-up " << d->selector->stage_seconds[3] << " s\n";

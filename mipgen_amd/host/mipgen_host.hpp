@@ -206,54 +206,95 @@ private:
 };
 
 // scan_strand_best_mip / pos_strand_best_mip of the region in hand (mipgen.cpp:1616-1746, 1748-1908): [position][strand] -> candidate.
-// The reference nests two std::map; the positions of a region are one dense run, so this is a flat table from the first position with
-// an "exists" flag per position - operator[] on the reference's map CREATES the position (:1869) and later find() calls see it, which
-// the flag reproduces.  Iterate ascending with lo() / hi() + find().
-class PosTable {
-public:
-    struct Slot { bool exists = false; Cand* m[2] = {nullptr, nullptr}; };      // candidates live in the Selector's per-region arena
-    void reset(int first, int count) { first_ = first; slots_.clear(); slots_.resize((size_t)std::max(count, 0)); }
-    int lo() const { return first_; }
-    int hi() const { return first_ + (int)slots_.size(); }
-    Slot* find(int pos)
-    {
-        if (pos < first_ || pos >= hi()) return nullptr;
-        Slot& s = slots_[(size_t)(pos - first_)];
-        return s.exists ? &s : nullptr;
-    }
-    Slot& touch(int pos)                            // the reference's operator[]
-    {
-        if (slots_.empty()) { first_ = pos; slots_.resize(1); }
-        else if (pos < first_) { slots_.insert(slots_.begin(), (size_t)(first_ - pos), Slot()); first_ = pos; }
-        else if (pos >= hi()) slots_.resize((size_t)(pos - first_ + 1));
-        Slot& s = slots_[(size_t)(pos - first_)];
-        s.exists = true;
-        return s;
-    }
-private:
-    int first_ = 0;
-    std::vector<Slot> slots_;
-};
-
+// The reference nests two std::map and fills them with heap objects; here NOTHING is built per region: the accelerator's two arrays ARE
+// the tables.  scan_strand_best_mip[p][s] is slot 2 * (p - first_pos) + s of the survivor array (present iff its cand_index >= 0),
+// pos_strand_best_mip[b][s] is entry 2 * (b - first_pos) + s of the collapse array (the scan-start index of the survivor the fold kept, or
+// -1), and a candidate is a pointer into the survivor array: its geometry follows from the slot (scan start, strand) and from a per-design
+// table over the index inside the position (capture size, arm lengths) by a few additions whenever a field is read - the pick stage reads
+// a handful of fields of a few hundred candidates per region, whereas materialising every survivor (80 bytes each, 10^8 of them per exome
+// design) was half of the selection stage's time.  operator[] on the reference's map CREATES a position (:1869) and later find() calls
+// see it: a per-region bitmap of touched scan positions reproduces that (a std::set for the positions outside the region's grid).
 class Selector {
 public:
-    Selector(const Options& o, const Tables& t, Outputs& out) : o_(o), t_(t), out_(out) {}
-    // survivors: 2 per scan position ('+','-'); cand_index is region-local or -1.  scores/records: region-local dense arrays
-    // (only needed for the survivors; pass the values stored in the survivor records)
+    Selector(const Options& o, const Tables& t, Outputs& out);
+    // survivors: 2 per scan position ('+','-'); cand_index - index_base is the region-local dense index, cand_index < 0 = no survivor.
     // collapsed: optional result of the accelerator's collapse (2 entries per base from g.first_pos on: scan-start index of the
     // winning survivor per strand, or -1; n_bases of them); nullptr = collapse on the host
-    void run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& survivors, Rescorer* rescorer,
+    void run_region(const Region& r, const mipgen_grid& g, const mipgen_survivor* survivors, int64_t index_base, Rescorer* rescorer,
                     double lower, double upper, const int32_t* collapsed = nullptr, int32_t n_bases = 0);
-    double stage_seconds[4] = {0, 0, 0, 0};      // diagnostics ($MIPGEN_TIMING): survivor + collapse tables, collapsed output, pick, clean-up
+    double stage_seconds[4] = {0, 0, 0, 0};      // diagnostics (-gpu_timing on): table set-up (+ host collapse), collapsed output, pick, clean-up
 private:
-    using CandPtr = Cand*;                                                 // into arena_: valid until the next region
-    std::vector<Cand> arena_;                                              // the survivors of the region in hand (<= 2 per scan position)
+    using CandPtr = const mipgen_survivor*;                                // into sv_: valid until the next region
+    struct Geo { int scan_start, scan_stop, ext_start, ext_stop, lig_start, lig_stop, ext_len, lig_len, strand; };
+    struct Within { uint16_t size_index; uint8_t ext_len, lig_len, strand; };   // per index inside a position: (capture size index * 2 + strand) * pairs + pair
     const Options& o_; const Tables& t_; Outputs& out_;
+    std::vector<Within> within_;                                           // n_sizes_all * 2 * pairs entries (a few KB: stays in L1)
     std::map<std::string, std::array<UsedBases, 2>> used_;                 // chr_strand_pos_used_arm_bases (persists across regions)
     std::array<UsedBases, 2>* used_cur_ = nullptr;                         // ... of the chromosome of the region in hand
-    PosTable scan_best_, pos_best_;                                        // [position][strand 0/1]
-    const Region* r_ = nullptr; Rescorer* rs_ = nullptr; double lower_ = 0, upper_ = 0;
+    // the region in hand
+    const Region* r_ = nullptr; const mipgen_grid* g_ = nullptr; Rescorer* rs_ = nullptr; double lower_ = 0, upper_ = 0;
+    const mipgen_survivor* sv_ = nullptr;                                  // 2 * n_pos slots
+    std::vector<mipgen_survivor> sv_copy_;                                 // mixed designs re-score in place (:1873-1877): their own copy
+    int64_t base_ = 0, per_pos_ = 0;
+    int first_pos_ = 0, n_pos_ = 0, cap0_ = 0;                             // cap0_: capture size of size index 0 of this region
+    const int32_t* col_ = nullptr; int32_t n_bases_ = 0;                   // pos_strand_best_mip as scan-start indices
+    std::vector<int32_t> col_own_;                                         // ... when the collapse runs here
+    std::vector<uint8_t> touched_;                                         // scan positions created by operator[] (:1869)
+    std::set<int> touched_outside_;
     GlibcRand rand_;
+    // table views
+    CandPtr scan_m(int pos, int s) const
+    {
+        const long pi = (long)pos - first_pos_;
+        if (pi < 0 || pi >= n_pos_) return nullptr;
+        const mipgen_survivor* m = sv_ + 2 * pi + s;
+        return m->cand_index >= 0 ? m : nullptr;
+    }
+    bool scan_exists(int pos) const
+    {
+        const long pi = (long)pos - first_pos_;
+        if (pi < 0 || pi >= n_pos_) return !touched_outside_.empty() && touched_outside_.count(pos) != 0;
+        return sv_[2 * pi].cand_index >= 0 || sv_[2 * pi + 1].cand_index >= 0 || touched_[(size_t)pi] != 0;
+    }
+    void scan_touch(int pos)
+    {
+        const long pi = (long)pos - first_pos_;
+        if (pi < 0 || pi >= n_pos_) touched_outside_.insert(pos); else touched_[(size_t)pi] = 1;
+    }
+    CandPtr pos_m(int pos, int s) const
+    {
+        const long j = (long)pos - first_pos_;
+        if (j < 0 || j >= n_bases_) return nullptr;
+        const int32_t pi = col_[2 * j + s];
+        return pi >= 0 ? sv_ + 2 * (long)pi + s : nullptr;
+    }
+    // candidate views
+    int slot_of(CandPtr m) const { return (int)(m - sv_); }
+    Geo geo(CandPtr m) const
+    {
+        const int slot = slot_of(m), pi = slot >> 1;
+        const Within& w = within_[(size_t)(m->cand_index - base_ - (int64_t)pi * per_pos_)];
+        Geo x;
+        x.ext_len = w.ext_len; x.lig_len = w.lig_len; x.strand = w.strand;
+        const int capture = cap0_ - (int)w.size_index * o_.capture_increment;
+        x.scan_start = first_pos_ + pi;
+        x.scan_stop = x.scan_start + capture - x.ext_len - x.lig_len - 1;          // mipgen.cpp:449
+        if (x.strand == 0) {                                                       // PlusSVMipv4.cpp:9-12
+            x.ext_start = x.scan_start - x.ext_len; x.ext_stop = x.scan_start - 1;
+            x.lig_start = x.scan_stop + 1; x.lig_stop = x.scan_stop + x.lig_len;
+        } else {                                                                   // MinusSVMipv4.cpp:32-35
+            x.ext_start = x.scan_stop + 1; x.ext_stop = x.scan_stop + x.ext_len;
+            x.lig_start = x.scan_start - x.lig_len; x.lig_stop = x.scan_start - 1;
+        }
+        return x;
+    }
+    static int snp_count(CandPtr m) { return (int)MIPGEN_REC_SNP_COUNT(m->record); }
+    double masked(CandPtr m, const Geo& x) const { return (double)MIPGEN_REC_MASKED_N(m->record) / (double)(x.lig_len + x.ext_len); }   // mipgen.cpp:610
+    int ext_copy(CandPtr m, const Geo& x) const { const int c = (int)MIPGEN_REC_EXT_COPY(m->record); return c == 65535 ? true_copy(x.ext_start, x.ext_len) : c; }
+    int lig_copy(CandPtr m, const Geo& x) const { const int c = (int)MIPGEN_REC_LIG_COPY(m->record); return c == 65535 ? true_copy(x.lig_start, x.lig_len) : c; }
+    int true_copy(int start, int len) const;
+    Cand cand_of(CandPtr m) const;                                         // the materialised record (printing, the SVR re-score hook)
+    double rescore(CandPtr m);                                             // mixed designs: SVR score, stored in place
     void collapse();
     void output_collapsed();
     void pick();
@@ -262,7 +303,7 @@ private:
     void manage_picked(CandPtr m, PosSet& positions);
     void print_gaps(std::ofstream& f, const std::string& ext, const std::string& note, PosSet& positions);
     void create_gap(std::ofstream& f, const std::string& ext, const std::string& note, PosSet& positions);
-    bool arm_used(const Cand& c, int strand) const;
+    bool arm_used(const Geo& x, int strand) const;
 };
 
 }  // namespace mipgen

@@ -188,39 +188,67 @@ int GlibcRand::next()
 
 // ---- selection ---------------------------------------------------------------------------------------------
 
-bool Selector::arm_used(const Cand& c, int strand) const
+Selector::Selector(const Options& o, const Tables& t, Outputs& out) : o_(o), t_(t), out_(out)
 {
-    const UsedBases& u = (*used_cur_)[(size_t)strand];
-    return u.any(c.ext_start, c.ext_stop) || u.any(c.lig_start, c.lig_stop);
+    // index inside a scan position -> (capture size index, strand, arm lengths): within = (size index * 2 + strand) * pairs + pair
+    const size_t A = o.arm_pairs.size();
+    const int K = o.capture_increment > 0 ? (o.max_capture - o.min_capture) / o.capture_increment + 1 : 1;
+    within_.resize((size_t)std::max(K, 1) * 2 * A);
+    for (size_t w = 0; w < within_.size(); w++) {
+        const size_t row = w / A, a = w - row * A;
+        within_[w] = Within{(uint16_t)(row >> 1), (uint8_t)o.arm_pairs[a].first, (uint8_t)o.arm_pairs[a].second, (uint8_t)(row & 1)};
+    }
 }
 
-void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vector<mipgen_survivor>& surv, Rescorer* rs,
+// the record's 16-bit copy fields saturate; bwa's X0 count does not (mipgen.cpp:586-587): a saturated field is read from the region's own
+// copy table (or the handle's list of counts >= 65535), so printed and compared copies are the reference's
+int Selector::true_copy(int start, int len) const
+{
+    const Region& r = *r_;
+    if (r.copy_resident) {
+        auto it = r.big_copy.find({len, (int)((long)start - r.seq_start)});
+        return it != r.big_copy.end() ? it->second : 0;
+    }
+    if ((size_t)len >= r.copy_ptr.size() || !r.copy_ptr[(size_t)len]) return 65535;
+    const long rel = (long)start - r.seq_start;
+    return rel >= 0 && rel < (long)r.seq.size() ? r.copy_ptr[(size_t)len][rel] : 0;
+}
+
+Cand Selector::cand_of(CandPtr m) const
+{
+    const int pi = slot_of(m) >> 1;
+    return make_cand_at(o_, *r_, *g_, pi, (uint32_t)(m->cand_index - base_ - (int64_t)pi * per_pos_), m->score, m->record);
+}
+
+double Selector::rescore(CandPtr m)                          // test_mip->score = predict_value(...), in place (mipgen.cpp:1523-1527, 1873-1877)
+{
+    const double s = rs_->svr(cand_of(m));
+    sv_copy_[(size_t)slot_of(m)].score = s;                  // mixed designs run on the selector's own copy of the survivors
+    return s;
+}
+
+bool Selector::arm_used(const Geo& x, int strand) const
+{
+    const UsedBases& u = (*used_cur_)[(size_t)strand];
+    return u.any(x.ext_start, x.ext_stop) || u.any(x.lig_start, x.lig_stop);
+}
+
+void Selector::run_region(const Region& r, const mipgen_grid& g, const mipgen_survivor* surv, int64_t index_base, Rescorer* rs,
                           double lower, double upper, const int32_t* collapsed, int32_t n_bases)
 {
-    r_ = &r; rs_ = rs; lower_ = lower; upper_ = upper;
+    r_ = &r; g_ = &g; rs_ = rs; lower_ = lower; upper_ = upper;
     used_cur_ = &used_[r.chr];
     const auto t0 = std::chrono::steady_clock::now();
-    scan_best_.reset(g.first_pos, g.n_pos); pos_best_.reset(g.first_pos, collapsed ? n_bases : g.n_pos);
-    arena_.clear(); arena_.reserve((size_t)2 * (size_t)std::max(g.n_pos, 0));                 // never reallocates below: the pointers stay valid
-    const int64_t per_pos = (int64_t)g.n_sizes * 2 * (int64_t)o_.arm_pairs.size();
-    for (int pi = 0; pi < g.n_pos; pi++)
-        for (int s = 0; s < 2; s++) {
-            const mipgen_survivor& sv = surv[(size_t)(2 * pi + s)];
-            if (sv.cand_index < 0) continue;
-            arena_.push_back(make_cand_at(o_, r, g, pi, (uint32_t)(sv.cand_index - (int64_t)pi * per_pos), sv.score, sv.record));
-            scan_best_.touch(g.first_pos + pi).m[s] = &arena_.back();
-        }
-    if (collapsed) {
-        // collapse_mips ran on the accelerator: per base and strand the scan-start index of the survivor the fold keeps
-        for (int32_t j = 0; j < n_bases; j++)
-            for (int s = 0; s < 2; s++) {
-                const int32_t pi = collapsed[2 * (size_t)j + s];
-                if (pi < 0) continue;
-                PosTable::Slot* it = scan_best_.find(g.first_pos + pi);
-                if (!it || !it->m[s]) throw 21;
-                pos_best_.touch(g.first_pos + j).m[s] = it->m[s];
-            }
-    } else collapse();
+    first_pos_ = g.first_pos; n_pos_ = std::max(g.n_pos, 0);
+    base_ = index_base; per_pos_ = (int64_t)g.n_sizes * 2 * (int64_t)o_.arm_pairs.size();
+    cap0_ = o_.max_capture - g.first_size_index * o_.capture_increment;
+    if ((size_t)per_pos_ > within_.size()) throw 21;
+    if (rs) { sv_copy_.assign(surv, surv + 2 * (size_t)n_pos_); sv_ = sv_copy_.data(); }     // re-scored in place
+    else sv_ = surv;
+    touched_.assign((size_t)n_pos_, 0);
+    touched_outside_.clear();
+    if (collapsed) { col_ = collapsed; n_bases_ = n_bases; }                                  // collapse_mips ran on the accelerator
+    else collapse();
     const auto t1 = std::chrono::steady_clock::now();
     if (!o_.silent) output_collapsed();
     out_.progress << "mips collapsed! picking mips...\n";
@@ -228,64 +256,81 @@ void Selector::run_region(const Region& r, const mipgen_grid& g, const std::vect
     const auto t2 = std::chrono::steady_clock::now();
     pick();
     const auto t3 = std::chrono::steady_clock::now();
-    scan_best_.reset(0, 0); pos_best_.reset(0, 0);
+    sv_ = nullptr; col_ = nullptr; n_bases_ = 0;
     const auto t4 = std::chrono::steady_clock::now();
     auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     stage_seconds[0] += sec(t0, t1); stage_seconds[1] += sec(t1, t2); stage_seconds[2] += sec(t2, t3); stage_seconds[3] += sec(t3, t4);
 }
 
-// collapse_mips, mipgen.cpp:1616-1649
+// collapse_mips, mipgen.cpp:1616-1649 (only when the accelerator's collapse result is not handed in)
 void Selector::collapse()
 {
-    for (int sp = scan_best_.lo(); sp < scan_best_.hi(); sp++) {
-        PosTable::Slot* ps = scan_best_.find(sp);
-        if (!ps) continue;
+    const int max_scan = std::max(o_.max_capture - o_.min_arm_sum, 1);
+    n_bases_ = n_pos_ + max_scan;                            // the furthest scan target ends max_scan - 1 bases behind the last scan start
+    col_own_.assign(2 * (size_t)n_bases_, -1);
+    for (int pi = 0; pi < n_pos_; pi++) {
         for (int strand = 0; strand < 2; strand++) {
-            const CandPtr m = ps->m[strand];
+            const CandPtr m = sv_[2 * pi + strand].cand_index >= 0 ? sv_ + 2 * pi + strand : nullptr;
             if (!m) continue;
-            if ((long)m->ext_copy * m->lig_copy > o_.max_arm_copy || m->ext_copy > o_.target_arm_copy || m->lig_copy > o_.target_arm_copy) continue;
-            if (m->masked > o_.masked_arm_threshold) continue;
-            for (int pos = m->scan_start; pos <= m->scan_stop; pos++) {
-                CandPtr& cur = pos_best_.touch(pos).m[strand];
-                if (!cur) cur = m;
-                else if (m->snp_count < cur->snp_count) cur = m;
-                else if (m->score > cur->score && m->snp_count == cur->snp_count) cur = m;
+            const Geo x = geo(m);
+            const int ec = ext_copy(m, x), lc = lig_copy(m, x);
+            if ((long)ec * lc > o_.max_arm_copy || ec > o_.target_arm_copy || lc > o_.target_arm_copy) continue;
+            if (masked(m, x) > o_.masked_arm_threshold) continue;
+            for (int pos = x.scan_start; pos <= x.scan_stop; pos++) {
+                const long j = (long)pos - first_pos_;
+                if (j < 0 || j >= n_bases_) throw 21;
+                int32_t& cur = col_own_[2 * (size_t)j + strand];
+                if (cur < 0) { cur = pi; continue; }
+                const CandPtr c = sv_ + 2 * (long)cur + strand;
+                if (snp_count(m) < snp_count(c)) cur = pi;
+                else if (m->score > c->score && snp_count(m) == snp_count(c)) cur = pi;
             }
         }
     }
+    col_ = col_own_.data();
 }
 
 // output_collapsed_mips, mipgen.cpp:1651-1668
 void Selector::output_collapsed()
 {
-    for (int p = pos_best_.lo(); p < pos_best_.hi(); p++) {
-        PosTable::Slot* ps = pos_best_.find(p);
-        if (!ps) continue;
+    for (int32_t j = 0; j < n_bases_; j++)
         for (int strand = 0; strand < 2; strand++) {
-            if (!ps->m[strand]) continue;
+            const CandPtr m = pos_m(first_pos_ + j, strand);
+            if (!m) continue;
+            if (m->cand_index < 0) throw 21;
             out_.collapsed_counter++;
-            out_.collapsed << format_record(o_, *r_, t_, *ps->m[strand], out_.collapsed_counter, false);
+            out_.collapsed << format_record(o_, *r_, t_, cand_of(m), out_.collapsed_counter, false);
         }
-    }
 }
 
 // optimize_worst_in_region, mipgen.cpp:1748-1820
 Selector::CandPtr Selector::optimize_worst(PosSet& positions, int strand_to_use)
 {
     CandPtr worst = nullptr;
+    // a survivor is the best of ~100 consecutive bases: its arm test is repeated for every one of them by the reference, with the same
+    // answer - the used-arm sets do not change inside this function - so the last answer per strand is kept
+    CandPtr last[2] = {nullptr, nullptr};
+    bool last_free[2] = {false, false};
+    auto arm_free = [&](CandPtr m, int strand) -> bool {
+        if (m != last[strand]) {
+            if (m->cand_index < 0) throw 21;
+            last[strand] = m; last_free[strand] = !arm_used(geo(m), strand);
+        }
+        return last_free[strand];
+    };
     positions.for_each([&](int pos) {
-        PosTable::Slot* pit = pos_best_.find(pos);
-        if (!pit) return;
+        const CandPtr m0 = pos_m(pos, 0), m1 = pos_m(pos, 1);
+        if (!m0 && !m1) return;
         CandPtr cur = nullptr, plus = nullptr, minus = nullptr;
         bool plus_set = false, minus_set = false;
-        if (pit->m[0] && strand_to_use != 1) {
-            plus = pit->m[0];
-            plus_set = !arm_used(*plus, 0);
+        if (m0 && strand_to_use != 1) {
+            plus = m0;
+            plus_set = arm_free(plus, 0);
             if (plus_set) cur = plus;
         }
-        if (pit->m[1] && strand_to_use != 0) {
-            minus = pit->m[1];
-            minus_set = !arm_used(*minus, 1);
+        if (m1 && strand_to_use != 0) {
+            minus = m1;
+            minus_set = arm_free(minus, 1);
             if (minus_set) cur = plus_set ? (plus->score > minus->score ? plus : minus) : minus;
         }
         if ((plus_set || minus_set) && (!worst || cur->score < worst->score)) worst = cur;
@@ -303,39 +348,44 @@ Selector::CandPtr Selector::translocate(PosSet& positions, int strand_to_use)
     int earliest, prelim, dir;
     if (to_end < min_scan - 10 - o_.starting_mip_overlap) {
         earliest = r_->stop_fl - min_scan + 1; prelim = earliest; dir = 1;
-        while (!scan_best_.find(prelim) && prelim <= latest) prelim++;
+        while (!scan_exists(prelim) && prelim <= latest) prelim++;
     } else {
         earliest = latest - o_.max_mip_overlap; prelim = latest - o_.starting_mip_overlap; dir = -1;
-        while (!scan_best_.find(prelim) && prelim >= earliest) prelim--;
+        while (!scan_exists(prelim) && prelim >= earliest) prelim--;
     }
-    if (!scan_best_.find(prelim)) return nullptr;
+    if (!scan_exists(prelim)) return nullptr;
     CandPtr next = nullptr;
+    Geo next_x{};
+    int next_snp = 0;
     int prev_extent = latest + 1;
     for (int chosen = prelim;
          (!next && prev_extent > latest && chosen < r_->stop_fl && chosen > r_->start_fl - o_.min_capture) ||
-         (next && ((next->score < upper_ || next->snp_count > 0) && chosen >= earliest && chosen <= latest - o_.starting_mip_overlap &&
-                   (dir == -1 || chosen + next->scan_size() > positions.back())));
+         (next && ((next->score < upper_ || next_snp > 0) && chosen >= earliest && chosen <= latest - o_.starting_mip_overlap &&
+                   (dir == -1 || chosen + (next_x.scan_stop - next_x.scan_start + 1) > positions.back())));
          chosen += dir) {
         int strand_index, iterations;
         if (strand_to_use != -1) { strand_index = 1 - strand_to_use; iterations = 1; }
         else { strand_index = rand_.next() % 2; iterations = 2; }                 // the reference's libc rand(), never seeded (:1863)
         for (int i = 0; i < iterations; i++) {
             strand_index = 1 - strand_index;
-            PosTable::Slot& slot = scan_best_.touch(chosen);                      // operator[]: creates the position, as the reference does (:1869)
-            if (!slot.m[strand_index]) continue;
-            CandPtr test = slot.m[strand_index];
-            if (o_.score_method == MIPGEN_SCORE_MIXED && rs_) test->score = rs_->svr(*test);      // in place (:1873-1877)
-            prev_extent = test->scan_stop;
-            if (!next || test->score > next->score || test->snp_count < next->snp_count) {
-                const int test_copy = std::max(test->ext_copy, test->lig_copy);
+            scan_touch(chosen);                                                   // operator[]: creates the position, as the reference does (:1869)
+            const CandPtr test = scan_m(chosen, strand_index);
+            if (!test) continue;
+            if (o_.score_method == MIPGEN_SCORE_MIXED && rs_) rescore(test);      // in place (:1873-1877)
+            const Geo x = geo(test);
+            prev_extent = x.scan_stop;
+            const int test_snp = snp_count(test);
+            if (!next || test->score > next->score || test_snp < next_snp) {
+                const int test_copy = std::max(ext_copy(test, x), lig_copy(test, x));
                 if (test_copy > o_.target_arm_copy && next) {
-                    if (test_copy > std::max(next->ext_copy, next->lig_copy)) continue;
+                    if (test_copy > std::max(ext_copy(next, next_x), lig_copy(next, next_x))) continue;
                 }
-                if (test->masked > o_.masked_arm_threshold && next) {
-                    if (test->masked > next->masked) continue;
+                const double test_masked = masked(test, x);
+                if (test_masked > o_.masked_arm_threshold && next) {
+                    if (test_masked > masked(next, next_x)) continue;
                 }
-                if (arm_used(*test, strand_index)) continue;
-                next = test;
+                if (arm_used(x, strand_index)) continue;
+                next = test; next_x = x; next_snp = test_snp;
             }
         }
     }
@@ -343,8 +393,10 @@ Selector::CandPtr Selector::translocate(PosSet& positions, int strand_to_use)
 }
 
 // manage_picked_mip, mipgen.cpp:1910-1939
-void Selector::manage_picked(CandPtr m, PosSet& positions)
+void Selector::manage_picked(CandPtr mp, PosSet& positions)
 {
+    const Cand c = cand_of(mp);
+    const Cand* m = &c;
     out_.picked_counter++;
     out_.picked << format_record(o_, *r_, t_, *m, out_.picked_counter, false);
     if (m->snp_count == 1 && m->snp_failed == '0') out_.snp << format_record(o_, *r_, t_, *m, out_.picked_counter, true);
@@ -405,18 +457,18 @@ void Selector::pick()
     if (o_.double_tile && o_.double_tile_strands_separately) minus_again.fill(r_->start_fl, r_->stop_fl);
     const bool mixed = o_.score_method == MIPGEN_SCORE_MIXED && rs_;
     CandPtr picked = optimize_worst(pos, strand_to_use);
-    if (mixed && picked) picked->score = rs_->svr(*picked);
+    if (mixed && picked) rescore(picked);
     while (!pos.empty() && picked && picked->score < lower_) {
         manage_picked(picked, pos);
         picked = optimize_worst(pos, strand_to_use);
-        if (mixed && picked) picked->score = rs_->svr(*picked);
+        if (mixed && picked) rescore(picked);
     }
     if (o_.double_tile_strands_separately) {
         picked = optimize_worst(minus, 1);                                         // not re-scored here in the reference (:1541)
         while (!minus.empty() && picked && picked->score < lower_) {
             manage_picked(picked, minus);
             picked = optimize_worst(minus, 1);
-            if (mixed && picked) picked->score = rs_->svr(*picked);
+            if (mixed && picked) rescore(picked);
         }
     }
     bool extended;
