@@ -715,6 +715,20 @@ def main() -> None:
                 d1 = time.perf_counter() - t1
                 extra.append({"what": f"sustained: the headline step {reps} times back to back", "value": n_cand * reps / d1, "unit": "candidates/s",
                               "ms_per_step": d1 / reps * 1e3, "seconds": d1})
+            # the same batch handed over as HOST buffers (the C ABI's mipgen_accel_score_regions): H2D of the region batch, dense scoring of every
+            # candidate, D2H of 16 B per candidate - the PCIe-inclusive rate of the boundary (never the headline: inputs are resident there)
+            acc.score_regions(regions, m)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                acc.score_regions(regions, m)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            extra.append({"what": "PCIe-inclusive: mipgen_accel_score_regions from host buffers (upload of the region batch, dense scoring, download of "
+                                  "score + record of every candidate)", "value": n_cand * reps / d1, "unit": "candidates/s", "ms_per_step": d1 / reps * 1e3,
+                          "bytes_down_per_step": 16 * n_cand})
+            acc.upload(regions)                               # back to the resident-batch state of the other lines
             if args.exome_regions > 0:
                 extra.append(exome_line(args, local_rank, stream, model_path))
             for nsv in (256, 4096):

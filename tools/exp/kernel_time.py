@@ -1,0 +1,30 @@
+import os, sys, numpy as np
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R)
+from mipgen_amd import capi, workloads
+lib_path = sys.argv[2] if len(sys.argv) > 2 else None
+if lib_path:
+    capi.LIB_PATH = os.path.join(R, lib_path); capi._lib = capi.load_library(capi.LIB_PATH)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "practice62"
+if cfg == "practice62":
+    genome, ivs = workloads.practice62()
+    P = capi.make_params(140, 180, score_method=capi.SCORE_SVR)
+    acc = capi.Accel(P)
+    acc.load_model_file(workloads.svr_model_path("gpurun_out/bench_cache", genome, 1024))
+    regions = workloads.build_regions(acc, genome, ivs, P)
+else:
+    chrom_len, all_iv = workloads.exome_layout()
+    P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
+    acc = capi.Accel(P)
+    acc.load_model_file(workloads.svr_model_path("gpurun_out/bench_cache", workloads.practice62()[0], 1024))
+    regions = workloads.build_exome(acc, chrom_len, all_iv[:2048], P)
+acc.upload(regions)
+acc.set_timing(True)
+ts = []
+for _ in range(12):
+    acc.score_window(0, capi.SCORE_SVR); ts.append(acc.last_kernel_ms(0))
+ts = np.array(ts[2:])
+sc, rec = acc.download()
+import hashlib
+chk = hashlib.md5(np.ascontiguousarray(sc).tobytes()).hexdigest()[:12] + " sum=%r" % float(np.nansum(sc))
+print(f"{cfg} {lib_path or 'product'}: kernel ms min {ts.min():.3f} median {np.median(ts):.3f}  checksum {chk!r}")
