@@ -1,5 +1,6 @@
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+[ -x $R/tools/microbench/pmc_calib ] || hipcc --offload-arch=gfx950 -O2 -o $R/tools/microbench/pmc_calib $R/tools/microbench/pmc_calib.hip
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/cal_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/cal_$c -o p -- $R/tools/microbench/pmc_calib > /dev/null 2>&1
