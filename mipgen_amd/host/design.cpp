@@ -680,6 +680,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     }
     int rc = 0;
     StageClock clk(d->timing);
+    if (d->selector) d->selector->fine_timing = d->timing;
     double t_wait = 0.0, t_select = 0.0;
     for (int k = 0; k < n_devices && rc == 0; k++) {
         for (;;) {
@@ -711,7 +712,10 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     d->flush_err();
     if (clk.on) std::cerr << "[mipgen timing] tile_regions: waiting for the device workers " << t_wait << " s, selection stage " << t_select << " s\n";
     if (clk.on && d->selector) std::cerr << "[mipgen timing] selection stage: tables " << d->selector->stage_seconds[0] << " s, collapsed output " << d->selector->stage_seconds[1]
-                                          << " s, pick " << d->selector->stage_seconds[2] << " s, clean-up " << d->selector->stage_seconds[3] << " s\n";
+                                          << " s, pick " << d->selector->stage_seconds[2] << " s, clean-up " << d->selector->stage_seconds[3] << " s\n"
+                                          << "[mipgen timing] pick stage: position sets " << d->selector->pick_seconds[0] << " s, optimize_worst " << d->selector->pick_seconds[1]
+                                          << " s, translocate " << d->selector->pick_seconds[2] << " s, manage_picked " << d->selector->pick_seconds[3]
+                                          << " s, print_gaps " << d->selector->pick_seconds[4] << " s\n";
     for (auto& c : chans) c->stop();
     if (rc) order.stop();
     if (rc) for (auto& c : chans) { std::lock_guard<std::mutex> lk(c->m); c->q.clear(); }

@@ -145,6 +145,18 @@ public:
         if (w >= bits_.size()) bits_.resize(std::max(w + 1, bits_.size() * 2), 0);
         bits_[w] |= 1ull << (p & 63);
     }
+    void insert_range(int lo, int hi)               // every base of [lo, hi] (an arm of a picked MIP, mipgen.cpp:1928-1937), a word at a time
+    {
+        if (lo < 0) lo = 0;
+        if (hi < lo) return;
+        const size_t w0 = (size_t)lo >> 6, w1 = (size_t)hi >> 6;
+        if (w1 >= bits_.size()) bits_.resize(std::max(w1 + 1, bits_.size() * 2), 0);
+        const uint64_t first = ~0ull << (lo & 63), last = ~0ull >> (63 - (hi & 63));
+        if (w0 == w1) { bits_[w0] |= first & last; return; }
+        bits_[w0] |= first;
+        for (size_t w = w0 + 1; w < w1; w++) bits_[w] = ~0ull;
+        bits_[w1] |= last;
+    }
     bool any(int lo, int hi) const                  // any used base in [lo, hi]
     {
         if (lo < 0) lo = 0;
@@ -194,6 +206,23 @@ public:
         const uint64_t bit = 1ull << (rel & 63);
         if (w & bit) { w &= ~bit; count_--; }
     }
+    void erase_range(int lo, int hi)                // every position of [lo, hi] (the scan target of a picked MIP, mipgen.cpp:1938)
+    {
+        long a = (long)lo - first_, b = (long)hi - first_;
+        const long n = (long)bits_.size() * 64;
+        if (a < 0) a = 0;
+        if (b >= n) b = n - 1;
+        if (b < a) return;
+        const size_t w0 = (size_t)a >> 6, w1 = (size_t)b >> 6;
+        const uint64_t first = ~0ull << (a & 63), last = ~0ull >> (63 - (b & 63));
+        for (size_t w = w0; w <= w1; w++) {
+            uint64_t m = ~0ull;
+            if (w == w0) m &= first;
+            if (w == w1) m &= last;
+            const uint64_t hit = bits_[w] & m;
+            if (hit) { bits_[w] &= ~m; count_ -= __builtin_popcountll(hit); }
+        }
+    }
     template <class F> void for_each(F f) const     // ascending
     {
         for (size_t w = lo_; w < bits_.size(); w++)
@@ -223,6 +252,8 @@ public:
     void run_region(const Region& r, const mipgen_grid& g, const mipgen_survivor* survivors, int64_t index_base, Rescorer* rescorer,
                     double lower, double upper, const int32_t* collapsed = nullptr, int32_t n_bases = 0);
     double stage_seconds[4] = {0, 0, 0, 0};      // diagnostics (-gpu_timing on): table set-up (+ host collapse), collapsed output, pick, clean-up
+    bool fine_timing = false;                    // -gpu_timing on: the pick stage by function (a clock read per call)
+    double pick_seconds[5] = {0, 0, 0, 0, 0};    // position sets, optimize_worst, translocate, manage_picked (+ gaps), print_gaps
 private:
     using CandPtr = const mipgen_survivor*;                                // into sv_: valid until the next region
     struct Geo { int scan_start, scan_stop, ext_start, ext_stop, lig_start, lig_stop, ext_len, lig_len, strand; };

@@ -420,15 +420,15 @@ void Selector::manage_picked(CandPtr mp, PosSet& positions)
     const int other = 1 - m->strand;
     auto& used = *used_cur_;
     if (o_.seal_both) {
-        for (int p = m->ext_start; p <= m->ext_stop; p++) used[other].insert(p);
-        for (int p = m->lig_start; p <= m->lig_stop; p++) used[other].insert(p);
+        used[other].insert_range(m->ext_start, m->ext_stop);
+        used[other].insert_range(m->lig_start, m->lig_stop);
     } else if (o_.half_seal_both) {
         used[other].insert((m->ext_stop + m->ext_start) / 2);
         used[other].insert((m->lig_start + m->lig_stop) / 2);
     }
-    for (int p = m->ext_start; p <= m->ext_stop; p++) used[m->strand].insert(p);
-    for (int p = m->lig_start; p <= m->lig_stop; p++) used[m->strand].insert(p);
-    for (int p = m->scan_start; p <= m->scan_stop; p++) positions.erase(p);
+    used[m->strand].insert_range(m->ext_start, m->ext_stop);
+    used[m->strand].insert_range(m->lig_start, m->lig_stop);
+    positions.erase_range(m->scan_start, m->scan_stop);
 }
 
 // print_gaps, mipgen.cpp:1231-1259
@@ -465,6 +465,12 @@ void Selector::create_gap(std::ofstream& f, const std::string& ext, const std::s
 // pick_mips, mipgen.cpp:1506-1614
 void Selector::pick()
 {
+    using clk = std::chrono::steady_clock;
+    clk::time_point tq = fine_timing ? clk::now() : clk::time_point();
+    auto lap = [&](int k) { if (fine_timing) { const auto n = clk::now(); pick_seconds[k] += std::chrono::duration<double>(n - tq).count(); tq = n; } };
+    auto OW = [&](PosSet& ps, int st) { lap(0); CandPtr m = optimize_worst(ps, st); lap(1); return m; };
+    auto TL = [&](PosSet& ps, int st) { lap(0); CandPtr m = translocate(ps, st); lap(2); return m; };
+    auto MP = [&](CandPtr m, PosSet& ps) { lap(0); manage_picked(m, ps); lap(3); };
     PosSet pos, again, minus, minus_again;
     const int strand_to_use = o_.double_tile_strands_separately ? 0 : -1;
     pos.fill(r_->start_fl, r_->stop_fl);
@@ -472,60 +478,62 @@ void Selector::pick()
     if (o_.double_tile_strands_separately) minus.fill(r_->start_fl, r_->stop_fl);
     if (o_.double_tile && o_.double_tile_strands_separately) minus_again.fill(r_->start_fl, r_->stop_fl);
     const bool mixed = o_.score_method == MIPGEN_SCORE_MIXED && rs_;
-    CandPtr picked = optimize_worst(pos, strand_to_use);
+    CandPtr picked = OW(pos, strand_to_use);
     if (mixed && picked) rescore(picked);
     while (!pos.empty() && picked && picked->score < lower_) {
-        manage_picked(picked, pos);
-        picked = optimize_worst(pos, strand_to_use);
+        MP(picked, pos);
+        picked = OW(pos, strand_to_use);
         if (mixed && picked) rescore(picked);
     }
     if (o_.double_tile_strands_separately) {
-        picked = optimize_worst(minus, 1);                                         // not re-scored here in the reference (:1541)
+        picked = OW(minus, 1);                                         // not re-scored here in the reference (:1541)
         while (!minus.empty() && picked && picked->score < lower_) {
-            manage_picked(picked, minus);
-            picked = optimize_worst(minus, 1);
+            MP(picked, minus);
+            picked = OW(minus, 1);
             if (mixed && picked) rescore(picked);
         }
     }
     bool extended;
     if (!pos.empty()) {
         do {
-            picked = translocate(pos, strand_to_use);
+            picked = TL(pos, strand_to_use);
             extended = pos.back() - pos.front() > o_.max_capture;
             if (!picked && extended) create_gap(out_.gaps, ".coverage_failed.bed", "GAP INTRODUCED ON CHROMOSOME ", pos);
-            if (picked) manage_picked(picked, pos);
+            if (picked) MP(picked, pos);
         } while (!pos.empty() && (picked || extended));
     }
     if (!minus.empty()) {
         do {
-            picked = translocate(minus, 1);
+            picked = TL(minus, 1);
             extended = minus.back() - minus.front() > o_.max_capture;
             if (!picked && extended) create_gap(out_.minus_gaps, ".minus_strand_failed.bed", "GAP INTRODUCED ON MINUS STRAND OF CHROMOSOME ", minus);
-            if (picked) manage_picked(picked, minus);
+            if (picked) MP(picked, minus);
         } while (!minus.empty() && (picked || extended));
     }
     if (o_.double_tile) {
         do {
-            picked = translocate(again, strand_to_use);
+            picked = TL(again, strand_to_use);
             extended = !again.empty() && again.back() - again.front() > o_.max_capture;
             if (!picked && extended) create_gap(out_.double_gaps, ".double_tile_failed.bed", "GAP INTRODUCED ON DOUBLE TILING OF CHROMOSOME ", again);
-            if (picked) manage_picked(picked, again);
+            if (picked) MP(picked, again);
         } while (!again.empty() && (picked || extended));
         if (o_.double_tile_strands_separately) {
             // the reference walks positions_to_scan_again here but manages / terminates on positions_to_scan_minus_again (:1597-1607)
             do {
-                picked = translocate(again, 1);
+                picked = TL(again, 1);
                 extended = !again.empty() && again.back() - again.front() > o_.max_capture;
                 if (!picked && extended && !minus_again.empty())
                     create_gap(out_.double_gaps, ".minus_strand_double_tile_failed.bed", "GAP INTRODUCED ON MINUS STRAND OF DOUBLE TILING OF CHROMOSOME ", minus_again);
-                if (picked) manage_picked(picked, minus_again);
+                if (picked) MP(picked, minus_again);
             } while (!minus_again.empty() && (picked || extended));
         }
     }
+    lap(0);
     print_gaps(out_.gaps, ".coverage_failed.bed", "BASES NOT COVERED ON CHROMOSOME ", pos);
     print_gaps(out_.double_gaps, ".double_tile_failed.bed", "BASES NOT DOUBLE TILED ON CHROMOSOME ", again);
     print_gaps(out_.minus_gaps, ".minus_strand_failed.bed", "BASES NOT COVERED ON MINUS STRAND OF CHROMOSOME ", minus);
     print_gaps(out_.double_minus_gaps, ".minus_strand_double_tile_failed.bed", "BASES NOT DOUBLE TILED ON MINUS STRAND OF CHROMOSOME ", minus_again);
+    lap(4);
 }
 
 }  // namespace mipgen
