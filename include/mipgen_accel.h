@@ -239,7 +239,11 @@ int mipgen_accel_window_info(const mipgen_accel* h, int32_t w, int32_t* first_re
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* Scores the resident batch's dense grid with `method` (MIPGEN_SCORE_LOGISTIC or MIPGEN_SCORE_SVR) into
  * library-owned device arrays (double scores[], uint64 records[], both batch_candidates long).
- * Asynchronous on the handle's stream. */
+ * Asynchronous on the handle's stream.
+ * Every parameter set the reference accepts is scored (mipgen.cpp:222-261, 427-444: any -arm_lengths / -capture_increment / range): SVR
+ * requests outside the tiled kernel's limits (scan sizes below 3, more than 240 arm pairs, a tile beyond 160 KiB of LDS) take the
+ * list scorer over the window's dense index range - same results, a lower rate.  The one limit left: that route refuses scan sizes above 1,024 bases
+ * (MIPGEN_E_INVALID). */
 int mipgen_accel_score_resident(mipgen_accel* h, int32_t method);       /* single-window batches; else MIPGEN_E_STATE */
 /* the same for result window w of a larger batch; the window's results replace the previous window's */
 int mipgen_accel_score_window(mipgen_accel* h, int32_t w, int32_t method);
@@ -360,7 +364,9 @@ int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
 /* SVR scores that sit within the device kernels' error (~1e-12) of a midpoint between two 6-significant-digit numbers - the precision the
  * front end prints scores with (mipgen.cpp:774) - are re-scored in the reference's own operation order (svm.cpp:329-368, 2511-2515: index-order
  * sums, every operation rounded on its own) and overwritten, so that the printed digit is the reference's.  On by default; 0 switches it off
- * (measurements, tests of the mechanism).  Dense windows and candidate lists (mixed designs) alike. */
+ * (measurements, tests of the mechanism).  Dense windows and candidate lists (mixed designs) alike.  Should a window hold more such scores
+ * than the re-score list (1/1024 of its candidates + 4096), the next download of its results fails with MIPGEN_E_STATE instead of handing
+ * out digits that are not guaranteed. */
 int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on);
 /* The dense logistic kernel gives a workgroup `n` consecutive runs of scan positions (it stages the bases once and slides its downstream-arm
  * table from run to run).  0 = chosen from the batch size (1 for small batches, which need every workgroup they can get; 2 or 3 for large ones),
