@@ -344,6 +344,19 @@ int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char*
                                    int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens,
                                    int32_t n_sizes, const int32_t* sizes, int32_t seed_len, uint8_t* const* unmap_out);
 
+/* The same test for a caller that wants exactly mipgen_region.unmappable: `bounds` gives, per region, the coordinates the reference's lookup is limited
+ * by (mipgen.cpp:808-813: a window start is written only for current_mip_start in [start_flanked - C, stop_flanked), > 0, with the window inside the
+ * region string [seq_start, seq_stop]); the flags of every other start are cleared ON THE DEVICE, the flag image stays in the handle, and any_out[r]
+ * (one byte per region) says whether region r has a flagged start at all.  Only those regions need mipgen_accel_window_flags_region (out: uint8
+ * [n_sizes][region_lens[r]]); mipgen_accel_window_uniqueness_end releases the image (so do the next _begin and mipgen_accel_destroy).  An exome design
+ * has a flagged start in a few percent of its regions: 560 MB of flags stay where they were computed. */
+typedef struct mipgen_window_bounds { int32_t start_flanked, stop_flanked, seq_start, seq_stop; } mipgen_window_bounds;
+int mipgen_accel_window_uniqueness_begin(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens,
+                                         int32_t n_regions, const char* const* region_seqs, const int32_t* region_lens, const mipgen_window_bounds* bounds,
+                                         int32_t n_sizes, const int32_t* sizes, int32_t seed_len, uint8_t* any_out);
+int mipgen_accel_window_flags_region(mipgen_accel* h, int32_t region, uint8_t* out);
+int mipgen_accel_window_uniqueness_end(mipgen_accel* h);
+
 /* The same counts, kept in the handle's device memory in the layout the scoring kernels read (288 GB of HBM: the tables of a whole exome
  * are 6.7 GB and would otherwise cross PCIe twice).  The oligo lengths are the ones the handle's arm pairs use.  The next
  * mipgen_accel_upload_regions must pass the SAME regions (count, order, seq_len) with copy = MIPGEN_COPY_RESIDENT in every one of them;

@@ -311,6 +311,10 @@ def load_library(path: Optional[str] = None):
                                                              C.POINTER(C.POINTER(BigCopy))]
     lib.mipgen_accel_window_uniqueness.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, C.c_int32, i32p, C.c_int32,
                                                    C.POINTER(C.POINTER(C.c_uint8))]
+    lib.mipgen_accel_window_uniqueness_begin.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i64p, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, C.c_int32, i32p,
+                                                         C.c_int32, C.POINTER(C.c_uint8)]
+    lib.mipgen_accel_window_flags_region.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint8)]
+    lib.mipgen_accel_window_uniqueness_end.argtypes = [vp]
     lib.mipgen_accel_format_all_mips.argtypes = [vp, C.POINTER(RecordNames), C.c_char_p, C.c_int64, i64p, i64p]
     lib.mipgen_accel_download_text.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
@@ -318,7 +322,8 @@ def load_library(path: Optional[str] = None):
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
-                 "set_sv_split", "set_print_exact", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "format_all_mips", "download_text"):
+                 "set_sv_split", "set_print_exact", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "window_uniqueness_begin", "window_flags_region", "window_uniqueness_end",
+                 "format_all_mips", "download_text"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -336,7 +341,8 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
-    "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_set_print_exact", "mipgen_accel_set_logistic_subruns",
+    "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_window_uniqueness_begin", "mipgen_accel_window_flags_region",
+    "mipgen_accel_window_uniqueness_end", "mipgen_accel_set_print_exact", "mipgen_accel_set_logistic_subruns",
 ]
 
 
@@ -457,6 +463,34 @@ class Accel:
         self._check(self.lib.mipgen_accel_window_uniqueness(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra,
                                                             rl.ctypes.data_as(C.POINTER(C.c_int32)), ns, sz.ctypes.data_as(C.POINTER(C.c_int32)), seed_len, op))
         return outs
+
+    def window_uniqueness_bounded(self, chroms: Sequence[bytes], region_seqs: Sequence[bytes], bounds: Sequence[Tuple[int, int, int, int]],
+                                  sizes: Sequence[int], seed_len: int = 30) -> Tuple[np.ndarray, List[Optional[np.ndarray]]]:
+        """mipgen_accel_window_uniqueness_begin / _flags_region / _end: the same flags restricted on the device to the window starts the reference
+        looks up (bounds = (start_flanked, stop_flanked, seq_start, seq_stop) per region); returns the per-region any flags and the image of
+        every region that has a flagged start (None for the others)."""
+        nc, nr, ns = len(chroms), len(region_seqs), len(sizes)
+        ca = (C.c_char_p * max(nc, 1))(*chroms)
+        cl = np.array([len(c) for c in chroms], dtype=np.int64)
+        ra = (C.c_char_p * max(nr, 1))(*region_seqs)
+        rl = np.array([len(r) for r in region_seqs], dtype=np.int32)
+        sz = np.array(list(sizes), dtype=np.int32)
+        bd = np.ascontiguousarray(np.array(bounds, dtype=np.int32).reshape(nr, 4))
+        any_ = np.zeros(max(nr, 1), dtype=np.uint8)
+        i32 = C.POINTER(C.c_int32)
+        self._check(self.lib.mipgen_accel_window_uniqueness_begin(self.h, nc, ca, cl.ctypes.data_as(C.POINTER(C.c_int64)), nr, ra, rl.ctypes.data_as(i32),
+                                                                  bd.ctypes.data_as(i32), ns, sz.ctypes.data_as(i32), seed_len,
+                                                                  any_.ctypes.data_as(C.POINTER(C.c_uint8))))
+        outs: List[Optional[np.ndarray]] = []
+        for r in range(nr):
+            if not any_[r]:
+                outs.append(None)
+                continue
+            o = np.zeros((ns, len(region_seqs[r])), dtype=np.uint8)
+            self._check(self.lib.mipgen_accel_window_flags_region(self.h, r, o.ctypes.data_as(C.POINTER(C.c_uint8))))
+            outs.append(o)
+        self._check(self.lib.mipgen_accel_window_uniqueness_end(self.h))
+        return any_[:nr], outs
 
     def count_oligo_copies_resident(self, chroms: Sequence[bytes], region_seqs: Sequence[bytes]) -> List[Tuple[int, int, int, int]]:
         """The same counts for the handle's own oligo lengths, left on the device for an upload of the same regions with copy=COPY_RESIDENT;

@@ -243,6 +243,12 @@ struct mipgen_accel {
     DevBuf<int64_t> pb_idx;
     DevBuf<double> pb_scores;
     DevBuf<unsigned int> pb_count;
+    // flag image of the last mipgen_accel_window_uniqueness_begin: uint8 [win_sizes][win_total], region r at column win_roff[r]
+    DevBuf<uint8_t> win_img;
+    std::vector<int64_t> win_roff;
+    std::vector<int32_t> win_lens;
+    int win_sizes = 0;
+    int64_t win_total = 0;
     unsigned int* pb_over = nullptr;         // host-mapped word: entries a re-score list could not hold (checked at the next download: pb_check)
     std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
@@ -426,6 +432,7 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->fmt_a.release(); h->fmt_b.release(); h->fmt_c.release(); h->fmt_d.release();
     h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
+    h->win_img.release();
     h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();
     h->pool.clear();
     if (h->dp) (void)hipFree(h->dp);
@@ -1732,14 +1739,17 @@ extern "C" hipError_t mipgen_launch_window_verify(hipStream_t st, const char* G,
                                                   const unsigned int* rmult, const unsigned int* rstart, const uint32_t* rlist, const uint16_t* dist_start, unsigned int* ctr);
 extern "C" hipError_t mipgen_launch_window_flags(hipStream_t st, const char* q, int64_t total, const int32_t* sizes, int n_sizes, int k, const uint64_t* keys,
                                                  uint64_t cap_mask, const unsigned int* counts, const uint16_t* dist_bad, const uint16_t* dist_end, const unsigned int* ctr,
-                                                 uint8_t* unmap);
+                                                 uint8_t* unmap, const int64_t* roff, int n_regions, const int32_t* bounds, uint8_t* any);
 
-int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
-                                   const char* const* region_seqs, const int32_t* region_lens, int32_t n_sizes, const int32_t* sizes, int32_t seed_len,
-                                   uint8_t* const* unmap_out)
+// bounds == nullptr: the full flag image goes to unmap_out (mipgen_accel_window_uniqueness).  bounds != nullptr: the flags are restricted to the
+// window starts the reference looks up on the device, the image stays in the handle (h->win_img) and any_out gets one byte per region
+// (mipgen_accel_window_uniqueness_begin)
+static int window_uniqueness_impl(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                  const char* const* region_seqs, const int32_t* region_lens, int32_t n_sizes, const int32_t* sizes, int32_t seed_len,
+                                  uint8_t* const* unmap_out, const mipgen_window_bounds* bounds, uint8_t* any_out)
 {
     if (!h || n_chrom < 0 || n_regions < 0 || n_sizes < 1 || n_sizes > 64 || !sizes || (n_chrom && (!chrom_seqs || !chrom_lens)) ||
-        (n_regions && (!region_seqs || !region_lens || !unmap_out)))
+        (n_regions && (!region_seqs || !region_lens || (!bounds && !unmap_out) || (bounds && !any_out))))
         return fail(MIPGEN_E_INVALID, "bad arguments");
     if (seed_len < 12 || seed_len > 31) return fail(MIPGEN_E_INVALID, "seed length %d: must be in [12, 31] (exact 2-bit keys)", seed_len);
     int max_size = 0;
@@ -1760,10 +1770,19 @@ int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char*
     DevBuf<uint32_t> rlist;
     DevBuf<uint16_t> dbad, dend, dstart;
     DevBuf<int64_t> droff;
-    DevBuf<uint8_t> dun;
+    DevBuf<uint8_t> dun, dany;
+    DevBuf<int32_t> dbounds;
+    h->win_img.release(); h->win_roff.clear(); h->win_lens.clear(); h->win_sizes = 0; h->win_total = 0;
     struct Free { std::vector<std::function<void()>> f; ~Free() { for (auto& g : f) g(); } } fr;     // DevBuf has no destructor: release on every exit
     fr.f = {[&] { rmult.release(); }, [&] { rstart.release(); }, [&] { rfill.release(); }, [&] { alloc.release(); }, [&] { ctr.release(); }, [&] { rlist.release(); },
-            [&] { dbad.release(); }, [&] { dend.release(); }, [&] { dstart.release(); }, [&] { droff.release(); }, [&] { dun.release(); }};
+            [&] { dbad.release(); }, [&] { dend.release(); }, [&] { dstart.release(); }, [&] { droff.release(); }, [&] { dun.release(); }, [&] { dany.release(); },
+            [&] { dbounds.release(); }};
+    if (bounds) {
+        if (dany.reserve((size_t)n_regions) || dbounds.reserve(4 * (size_t)n_regions)) return MIPGEN_E_NOMEM;
+        static_assert(sizeof(mipgen_window_bounds) == 16, "four int32");
+        HIP_TRY(hipMemcpyAsync(dbounds.p, bounds, (size_t)n_regions * sizeof(mipgen_window_bounds), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(dany.p, 0, (size_t)n_regions, h->stream));
+    }
     if (rmult.reserve(cap) || rstart.reserve(cap) || rfill.reserve(cap) || alloc.reserve(1) || ctr.reserve((size_t)n_sizes * (size_t)total) || rlist.reserve((size_t)total) ||
         dbad.reserve((size_t)total) || dend.reserve((size_t)total) || dstart.reserve((size_t)total) || droff.reserve(K.roff.size()) ||
         dun.reserve((size_t)n_sizes * (size_t)total))
@@ -1783,7 +1802,16 @@ int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char*
                                             K.dfilter.p, K.KP.filter_bits, rmult.p, rstart.p, rlist.p, dstart.p, ctr.p));
         HIP_TRY(hipStreamSynchronize(h->stream));                      // the next chromosome overwrites the genome buffer
     }
-    HIP_TRY(mipgen_launch_window_flags(h->stream, K.dq.p, total, sizes, n_sizes, seed_len, K.dkeys.p, K.KP.cap_mask, K.dcounts.p, dbad.p, dend.p, ctr.p, dun.p));
+    HIP_TRY(mipgen_launch_window_flags(h->stream, K.dq.p, total, sizes, n_sizes, seed_len, K.dkeys.p, K.KP.cap_mask, K.dcounts.p, dbad.p, dend.p, ctr.p, dun.p,
+                                       droff.p, n_regions, bounds ? dbounds.p : nullptr, bounds ? dany.p : nullptr));
+    if (bounds) {
+        // the image stays on the device: the caller fetches the few regions that have a flagged start (mipgen_accel_window_flags_region)
+        HIP_TRY(hipMemcpyAsync(any_out, dany.p, (size_t)n_regions, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->win_img = dun; dun = DevBuf<uint8_t>();                     // ownership moves to the handle (released by _end / the next call / destroy)
+        h->win_roff = K.roff; h->win_lens.assign(region_lens, region_lens + n_regions); h->win_sizes = n_sizes; h->win_total = total;
+        return MIPGEN_OK;
+    }
     std::vector<uint8_t> img((size_t)n_sizes * (size_t)total);
     HIP_TRY(hipMemcpyAsync(img.data(), dun.p, img.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1792,6 +1820,40 @@ int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char*
         const int len = region_lens[r];
         for (int c = 0; c < n_sizes; c++) memcpy(unmap_out[r] + (size_t)c * (size_t)len, &img[(size_t)c * (size_t)total + (size_t)K.roff[(size_t)r]], (size_t)len);
     }
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_window_uniqueness(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                   const char* const* region_seqs, const int32_t* region_lens, int32_t n_sizes, const int32_t* sizes, int32_t seed_len,
+                                   uint8_t* const* unmap_out)
+{
+    return window_uniqueness_impl(h, n_chrom, chrom_seqs, chrom_lens, n_regions, region_seqs, region_lens, n_sizes, sizes, seed_len, unmap_out, nullptr, nullptr);
+}
+
+int mipgen_accel_window_uniqueness_begin(mipgen_accel* h, int32_t n_chrom, const char* const* chrom_seqs, const int64_t* chrom_lens, int32_t n_regions,
+                                         const char* const* region_seqs, const int32_t* region_lens, const mipgen_window_bounds* bounds,
+                                         int32_t n_sizes, const int32_t* sizes, int32_t seed_len, uint8_t* any_out)
+{
+    if (!bounds || !any_out) return fail(MIPGEN_E_INVALID, "bad arguments");
+    return window_uniqueness_impl(h, n_chrom, chrom_seqs, chrom_lens, n_regions, region_seqs, region_lens, n_sizes, sizes, seed_len, nullptr, bounds, any_out);
+}
+
+int mipgen_accel_window_flags_region(mipgen_accel* h, int32_t region, uint8_t* out)
+{
+    if (!h || !out) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (!h->win_img.p || region < 0 || (size_t)region >= h->win_lens.size()) return fail(MIPGEN_E_STATE, "no window-uniqueness image in the handle for region %d", region);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t len = (size_t)h->win_lens[(size_t)region];
+    if (len == 0) return MIPGEN_OK;
+    HIP_TRY(hipMemcpy2DAsync(out, len, h->win_img.p + h->win_roff[(size_t)region], (size_t)h->win_total, len, (size_t)h->win_sizes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_window_uniqueness_end(mipgen_accel* h)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    h->win_img.release(); h->win_roff.clear(); h->win_lens.clear(); h->win_sizes = 0; h->win_total = 0;
     return MIPGEN_OK;
 }
 

@@ -182,10 +182,23 @@ __global__ __launch_bounds__(256) void k_window_verify(const char* __restrict__ 
 // unmap[c][s] for every capture size c and window start s of the region concatenation
 __global__ __launch_bounds__(256) void k_window_flags(const char* __restrict__ q, int64_t total, WinParams W, const uint64_t* __restrict__ keys, uint64_t cap_mask,
                                                       const unsigned int* __restrict__ counts, const uint16_t* __restrict__ dist_bad,
-                                                      const uint16_t* __restrict__ dist_end, const unsigned int* __restrict__ ctr, uint8_t* __restrict__ unmap)
+                                                      const uint16_t* __restrict__ dist_end, const unsigned int* __restrict__ ctr, uint8_t* __restrict__ unmap,
+                                                      const int64_t* __restrict__ roff, int n_regions, const int4* __restrict__ bounds, uint8_t* __restrict__ any)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= total) return;
+    // bounds (optional): per region {start_flanked, stop_flanked, seq_start, seq_stop} - only the window starts the reference looks up keep their
+    // flag (mipgen.cpp:808-813: current_mip_start in [start_flanked - C, stop_flanked), > 0, the window inside the region string), and
+    // any[r] says whether region r has a flagged start at all
+    int reg = -1;
+    long pos = 0;
+    int4 B = make_int4(0, 0, 0, 0);
+    if (bounds) {
+        int lo = 0, hi = n_regions;                                    // the region whose [roff[r], roff[r + 1]) holds s
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= s) lo = mid; else hi = mid; }
+        reg = lo; B = bounds[reg];
+        pos = (long)B.z + (long)(s - roff[reg]);
+    }
     uint64_t key; int flip;
     unsigned int seed_loci = 0;
     if (seed_at(q, s, total, W.k, key, flip)) { const int64_t h = probe(keys, cap_mask, key); if (h >= 0) seed_loci = counts[h]; }
@@ -201,6 +214,10 @@ __global__ __launch_bounds__(256) void k_window_flags(const char* __restrict__ q
             unsigned int lead = x0;
             while (lead >= 10) lead /= 10;                             // "X0:i:1" is a substring test (:852): any count printed with a leading 1
             f = (lead == 1 && x1 == 0) ? 0 : 1;
+        }
+        if (f && bounds) {
+            if (!(pos >= (long)B.x - C && pos < (long)B.y && pos > 0 && pos + C - 1 <= (long)B.w)) f = 0;
+            else any[reg] = 1;
         }
         unmap[(int64_t)c * total + s] = f;
     }
@@ -237,12 +254,13 @@ extern "C" hipError_t mipgen_launch_window_verify(hipStream_t st, const char* G,
 }
 extern "C" hipError_t mipgen_launch_window_flags(hipStream_t st, const char* q, int64_t total, const int32_t* sizes, int n_sizes, int k, const uint64_t* keys,
                                                  uint64_t cap_mask, const unsigned int* counts, const uint16_t* dist_bad, const uint16_t* dist_end, const unsigned int* ctr,
-                                                 uint8_t* unmap)
+                                                 uint8_t* unmap, const int64_t* roff, int n_regions, const int32_t* bounds, uint8_t* any)
 {
     if (total <= 0) return hipSuccess;
     WinParams W;
     W.n_sizes = n_sizes; W.k = k; W.max_size = 0;
     for (int i = 0; i < n_sizes; i++) { W.sizes[i] = sizes[i]; W.max_size = std::max(W.max_size, sizes[i]); }
-    hipLaunchKernelGGL(k_window_flags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, total, W, keys, cap_mask, counts, dist_bad, dist_end, ctr, unmap);
+    hipLaunchKernelGGL(k_window_flags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q, total, W, keys, cap_mask, counts, dist_bad, dist_end, ctr, unmap,
+                       roff, n_regions, (const int4*)bounds, any);
     return hipGetLastError();
 }

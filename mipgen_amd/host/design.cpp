@@ -441,7 +441,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     };
     const Options& o = d->o;
     const bool timing = d->timing;               // seconds per stage of this worker
-    double t_stage[7] = {0, 0, 0, 0, 0, 0, 0};   // create + model, long-range content, upload, score + replay + collapse (+ downloads), text, mixed re-scores, copy numbers
+    double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // create + model, long-range content, upload, score + replay + collapse (+ downloads), text, mixed re-scores, copy numbers
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](int k) { const auto n_ = std::chrono::steady_clock::now(); t_stage[k] += std::chrono::duration<double>(n_ - t_prev).count(); t_prev = n_; };
     mipgen_accel* h = nullptr;
@@ -479,8 +479,10 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
         if (mipgen_accel_count_oligo_copies_resident(h, (int32_t)cs.size(), cs.data(), cl.data(), n, rs.data(), rl.data(), &n_big, &big)) { bail(11); return; }
         for (int i = 0; i < n; i++) { Region& r = d->regions[(size_t)(r0 + i)]; r.copy_resident = true; r.big_copy.clear(); }
         for (int64_t k = 0; k < n_big; k++) d->regions[(size_t)(r0 + big[k].region)].big_copy[{big[k].length, big[k].start}] = big[k].copies;
+        lap(6);
         // the capture-window half of check_copy_numbers (mapping_failed, mipgen.cpp:615-625, 841-868) for the same shard
         try { gpu_window_flags(o, h, d->genome, d->regions, r0, r1); } catch (int) { bail(11); return; }
+        lap(7);
     }
     lap(6);
     std::vector<mipgen_region> batch((size_t)n);
@@ -604,7 +606,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     if (timing) {
         std::ostringstream line;                                     // one write: the selection thread prints to stderr too
         line << "[mipgen timing] device " << device << " worker: create + model " << t_stage[0] << " s, long-range content " << t_stage[1]
-             << " s, arm copy numbers (resident) " << t_stage[6] << " s, upload "
+             << " s, arm copy numbers (resident) " << t_stage[6] << " s, capture-window uniqueness " << t_stage[7] << " s, upload "
              << t_stage[2] << " s, score + replay + collapse + downloads " << t_stage[3] << " s, record text " << t_stage[4] << " s, mixed re-scores "
              << t_stage[5] << " s\n";
         std::cerr << line.str();

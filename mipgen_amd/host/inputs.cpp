@@ -463,32 +463,31 @@ void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::
     }
     std::vector<const char*> cs; std::vector<int64_t> cl;
     for (const std::string& c : chroms) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
-    std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<uint8_t*> outp;
+    // The restriction to the window starts the reference looks up (current_mip_start of mipgen.cpp:808-813) happens on the device, and only the
+    // regions that have a flagged start at all (a few percent) get a table: the K x 112 M bytes of an exome's flag image stay in HBM
+    std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<mipgen_window_bounds> bounds;
     for (int i = r0; i < r1; i++) {
         Region& r = regs[(size_t)i];
         rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size());
-        r.unmappable.assign((size_t)K * r.seq.size(), 0);
-        outp.push_back(r.unmappable.data());
+        bounds.push_back(mipgen_window_bounds{r.start_fl, r.stop_fl, r.seq_start, r.seq_stop});
+        r.unmappable.clear();
     }
-    if (mipgen_accel_window_uniqueness(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(), K, sizes.data(), seed, outp.data())) {
+    std::vector<uint8_t> any((size_t)(r1 - r0), 0);
+    if (mipgen_accel_window_uniqueness_begin(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(), bounds.data(), K, sizes.data(), seed, any.data())) {
         std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
         throw 11;
     }
     for (int i = r0; i < r1; i++) {
+        if (!any[(size_t)(i - r0)]) continue;
         Region& r = regs[(size_t)i];
-        const size_t n = r.seq.size();
-        bool any = false;
-        for (int k = 0; k < K; k++) {
-            const int C = sizes[(size_t)k];
-            uint8_t* row = r.unmappable.data() + (size_t)k * n;
-            for (size_t j = 0; j < n; j++) {
-                const long pos = (long)r.seq_start + (long)j;                 // current_mip_start of mipgen.cpp:808-813
-                if (row[j] && !(pos >= (long)r.start_fl - C && pos < r.stop_fl && pos > 0 && pos + C - 1 <= r.seq_stop)) row[j] = 0;
-                any |= row[j] != 0;
-            }
+        r.unmappable.assign((size_t)K * r.seq.size(), 0);
+        if (mipgen_accel_window_flags_region(h, i - r0, r.unmappable.data())) {
+            std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
+            (void)mipgen_accel_window_uniqueness_end(h);
+            throw 11;
         }
-        if (!any) r.unmappable.clear();
     }
+    (void)mipgen_accel_window_uniqueness_end(h);
 }
 
 // the counts as host tables (Region::copy_flat): for callers that score through their own accelerator handle

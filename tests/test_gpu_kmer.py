@@ -275,6 +275,25 @@ def test_window_uniqueness_vs_brute_force():
             assert np.array_equal(t30, tk), k
     with pytest.raises(capi.AccelError):
         acc.window_uniqueness([g1], regions, [50], seed_len=30)                           # a window must hold two disjoint seeds
+    # the bounded form (what the front end uses): the restriction to the window starts the reference looks up (mipgen.cpp:808-813) happens on
+    # the device, and only the regions with a flagged start hand out an image
+    bounds = [(200 + 180, len(regions[0]) - 400, 1, len(regions[0])),                   # a region string that starts at chromosome coordinate 1
+              (1_000_000, 1_000_000 + 60, 1_000_000 - 180, 1_000_000 - 180 + len(regions[1]) - 1),
+              (50, 60, 1, len(regions[2])), (10, 20, 1, len(regions[3]))]
+    any_, imgs = acc.window_uniqueness_bounded([g1, g2], regions, bounds, sizes, seed_len=30)
+    for r, (seq, full) in enumerate(zip(regions, got)):
+        sf, ef, s0, s1 = bounds[r]
+        exp = full.copy()
+        pos = s0 + np.arange(len(seq))
+        for c, size in enumerate(sizes):
+            keep = (pos >= sf - size) & (pos < ef) & (pos > 0) & (pos + size - 1 <= s1)
+            exp[c][~keep] = 0
+        assert bool(any_[r]) == bool(exp.any()), r
+        if exp.any():
+            assert np.array_equal(imgs[r], exp), r
+        else:
+            assert imgs[r] is None
+    assert any_.sum() >= 2
     acc.close()
 
 

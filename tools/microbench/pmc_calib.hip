@@ -19,6 +19,19 @@ __global__ void w8_rows(double* o, size_t n_rows)
         o[(2 * r) * 57 + a] = (double)e;
     }
 }
+// k_svr_dense's epilogue exactly: a workgroup of 1024 threads owns 27 positions x 9 capture sizes of ONE strand (243 rows of 57 doubles inside a
+// 27 x 8,208-byte block whose other rows belong to the other strand's tile), element e = (size * 27 + position) * 57 + pair, thread t takes
+// e = t, t + 1024, ... four at a time: consecutive lanes on consecutive doubles of a row, consecutive rows of a wave 8,208 bytes apart
+__global__ void w8_tile(double* o, int n_tiles, int strand)
+{
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t base = (size_t)tile * 27 * 9 * 2 * 57;
+        for (int e = threadIdx.x; e < 243 * 57; e += 1024) {
+            const int it = e / 57, a = e - it * 57, kc = it / 27, pl = it - kc * 27;
+            o[base + ((size_t)(pl * 9 + kc) * 2 + strand) * 57 + a] = (double)e;
+        }
+    }
+}
 __global__ void r8(const double* in, size_t n, double* sink)
 {
     double s = 0;
@@ -42,6 +55,8 @@ int main()
         hipLaunchKernelGGL(w8, dim3(4096), dim3(256), 0, 0, b, N);
         hipLaunchKernelGGL(w16, dim3(4096), dim3(256), 0, 0, (double2*)b, N / 2);
         hipLaunchKernelGGL(w8_rows, dim3(4096), dim3(256), 0, 0, a, N / 57);
+        hipLaunchKernelGGL(w8_tile, dim3(1254), dim3(1024), 0, 0, a, (int)(N / (27 * 9 * 57)), 0);      // '+' tiles: N * 8 bytes again (half of the rows of a 2 N block)
+        hipLaunchKernelGGL(w8_tile, dim3(1254), dim3(1024), 0, 0, a, (int)(N / (27 * 9 * 57)), 1);      // '-' tiles
         hipLaunchKernelGGL(r8, dim3(4096), dim3(256), 0, 0, b, N, sink);
         hipLaunchKernelGGL(r16, dim3(4096), dim3(256), 0, 0, (const double2*)b, N / 2, sink);
     }
