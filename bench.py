@@ -664,6 +664,10 @@ def main() -> None:
         if traffic_run:
             roof["traffic_measured_in_this_run"] = True
             roof["traffic_detail"] = traffic_run
+            roof["traffic_note"] = ("k_svr_dense under --pmc carries a per-launch constant of ~0.16 GB in each direction that does not scale with the batch "
+                                    "(exome, 2.6e8 candidates: WRITE_SIZE 2.19 GB for 2.08 GB of scores = 1.05x; this batch: +0.16 GB on 0.12 GB) - the size of one "
+                                    "wave-context save / restore of the fully occupied chip (256 CUs x (16 x 128 VGPRs x 256 B + 146 KB LDS) = 0.17 GB), not "
+                                    "traffic of the algorithm; tools/exp/wr_probe*.sh, DESIGN.md section 5")
         elif traffic_src:
             roof["traffic_from_profile"] = traffic_src
             roof["traffic_measured_in_this_run"] = False
