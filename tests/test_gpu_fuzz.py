@@ -76,6 +76,58 @@ def test_random_configuration(cfg):
         acc.close()
 
 
+def _list_route_configs():
+    """Parameter sets on and across the limits of the tiled SVR kernel (scan sizes 1..5, 230..256 arm pairs, increments 1..3): the same handle
+    takes the tiled kernel or the list route (accel.hip: svr_window_via_list) depending on which side of a limit it falls."""
+    rng = np.random.default_rng(20260101)
+    out = []
+    for i in range(int(os.environ.get("MIPGEN_FUZZ_LIST_N", "6"))):
+        if i % 2 == 0:                                # short captures: the smallest scan size is 1..5
+            sums = sorted(rng.choice(np.arange(36, 47), size=int(rng.integers(1, 4)), replace=False).tolist(), reverse=True)
+            pairs = [(e, s - e) for s in sums for e in range(16, 31) if 18 <= s - e <= 30][:int(rng.integers(3, 30))]
+            lo = max(e + l for e, l in pairs) + int(rng.integers(1, 6))
+            hi = lo + int(rng.integers(0, 9)) * (inc := int(rng.choice([1, 2, 3])))
+        else:                                         # many pairs: 230..256 of them, around the tiled kernel's 240
+            n = int(rng.integers(230, 257))
+            grid = [(e, l) for e in range(14, 31) for l in range(14, 31)]
+            idx = sorted(rng.permutation(len(grid))[:n].tolist(), key=lambda j: (-(grid[j][0] + grid[j][1]), grid[j][0]))
+            pairs = [grid[j] for j in idx]
+            inc = int(rng.choice([1, 5]))
+            lo = int(rng.integers(100, 140)); hi = lo + inc * int(rng.integers(0, 3))
+        out.append((i, lo, hi, inc, pairs, int(rng.integers(3000, 16000)), int(rng.choice([1, 9, 30]))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _list_route_configs(), ids=lambda c: f"list{c[0]}_C{c[1]}-{c[2]}x{c[3]}_A{len(c[4])}_L{c[6]}")
+def test_random_configuration_around_the_tiled_kernels_limits(cfg):
+    i, lo, hi, inc, pairs, start, length = cfg
+    genome = H.golden_genome()
+    mp = os.path.join(H.GOLDEN, "models", "svr_syn_short_48.model" if i % 2 == 0 else "svr_syn_64.model")
+    om = po.Model(mp)
+    P = capi.make_params(lo, hi, score_method=capi.SCORE_SVR, capture_increment=inc, arm_pairs=pairs)
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    rd = capi.build_region(genome, "1", start, start + length, P, bwa_mode="hashed", label=f"l{i}", lrc=np.full(44, 0.02 * (i + 1)))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    g = grids[0]
+    assert g.count <= 1_500_000
+    og, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+    assert (g.first_pos, g.n_pos, g.first_size_index, g.n_sizes, g.count) == (og.first_pos, og.n_pos, og.first_size_index, og.n_sizes, og.count)
+    assert np.array_equal(records[:g.count], or_), cfg[:4]
+    a, b = np.asarray(scores[:g.count]), np.asarray(os_)
+    both_nan = np.isnan(a) & np.isnan(b)
+    with np.errstate(invalid="ignore"):
+        d = np.where(both_nan | (np.isinf(a) & (a == b)), 0.0, np.abs(a - b))
+    assert np.nanmax(d) <= TOL and not np.isnan(d).any(), (cfg[:4], int(np.nanargmax(d)), float(np.nanmax(d)))
+    acc.replay_condense()
+    emitted, surv, mask = acc.download_replay()
+    n_emit, omask = po.replay_region(P, rd, scores, records)
+    assert emitted[0] == n_emit and np.array_equal(mask, omask), cfg[:4]
+    osurv = po.condense_region(P, rd, scores, records, omask)
+    assert np.array_equal(surv["cand_index"], osurv["cand_index"]) and np.array_equal(surv["record"], osurv["record"])
+    acc.close()
+
+
 def _pair_lists():
     """Arm-pair lists of many shapes: one pair, one list, lists of unequal length, exactly 63 / 64 pairs (the single-wavefront replay,
     kernels_replay.hip: k_replay_condense_narrow) and 65 / 100 pairs (the chunked kernel), grouped by arm sum as the reference walks them."""
