@@ -93,6 +93,9 @@ def parse_args():
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the in-run oracle check (profiling runs)")
     ap.add_argument("--scale-base-regions", type=int, default=65536, help="exons of the `scale_base` line (N = 1 default run; 0 = skip): what --gpus N > 1 shards")
     ap.add_argument("--measure-traffic", action="store_true", help="measure the dominant kernel's HBM bytes in this run (child rocprofv3 --pmc passes)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the N > 1 run: nccl = RCCL over xGMI (the measured "
+                    "path); gloo = the same exchange through host memory (tests of the N > 1 logic on boxes without a second GPU)")
+    ap.add_argument("--share-gpus", action="store_true", help="tests only: ranks beyond the visible devices share them (rank r on GPU r mod devices; gloo only)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
     if a.config is None:
@@ -539,12 +542,18 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this node shows {torch.cuda.device_count()} device(s): one process per GPU")
+        if not (args.share_gpus and args.backend == "gloo"):
+            raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this node shows {torch.cuda.device_count()} device(s): one process per GPU")
+        local_rank %= torch.cuda.device_count()             # tests of the N > 1 logic on a one-GPU box (never a measurement: `shared_gpus` in the line)
     torch.cuda.set_device(local_rank)
     distributed = world > 1
+    xdev = "cuda" if args.backend == "nccl" else "cpu"      # where the tensors of the collectives live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     P, method, model_genome, build, desc, global_dense = assemble(args, rank, world)
     cache = os.path.join(ROOT, "gpurun_out", "bench_cache") + ("" if rank == 0 else f"_r{rank}")
@@ -571,13 +580,13 @@ def main() -> None:
     send = torch.as_tensor(_DevView(surv_ptr, max(n_surv, 1) * 24), device=f"cuda:{local_rank}") if distributed else None
     recv = None
     if distributed:
-        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_surv * 24], dtype=torch.int64, device="cuda"))
+        sizes = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([n_surv * 24], dtype=torch.int64, device=xdev))
         sizes = [int(s.item()) for s in sizes]
         mx = max(max(sizes), 24)
-        pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+        pad = torch.zeros(mx, dtype=torch.uint8, device=xdev)
         if rank == 0:
-            recv = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
+            recv = [torch.zeros(mx, dtype=torch.uint8, device=xdev) for _ in range(world)]
 
     def step() -> None:
         acc.score_condense_all(m)
@@ -609,11 +618,11 @@ def main() -> None:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        per = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(per, torch.tensor([n_cand], dtype=torch.int64, device="cuda"))
+        per = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([n_cand], dtype=torch.int64, device=xdev))
         cand_per_rank = [int(t.item()) for t in per]
         total_cand = sum(cand_per_rank)
         rccl_ranks = dist.get_world_size()                  # what the process group itself reports
@@ -673,7 +682,8 @@ def main() -> None:
             roof["traffic_measured_in_this_run"] = False
         out = {
             "metric": f"candidate MIPs scored/sec ({'SVR' if method == 'svr' else 'logistic'})", "value": value, "unit": "candidates/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "backend": args.backend if distributed else None, "shared_gpus": bool(args.share_gpus and distributed),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "n_sv": n_sv, "regions_rank0": len(regions), "dense_candidates_rank0": n_cand,
                        "dense_candidates_all_ranks": total_cand, "dense_candidates_per_rank": cand_per_rank, "result_windows_rank0": acc.window_count(),

@@ -109,6 +109,33 @@ def test_bench_two_ranks_strong_scaling_child_process():
     assert len(per) == 2 and min(per) > 0 and sum(per) == line["config"]["dense_candidates_all_ranks"] and max(per) < 1.5 * min(per)
 
 
+def test_bench_two_ranks_logic_through_gloo_on_one_gpu():
+    """The N > 1 path of bench.py on a box with ONE GPU: two ranks share the device and exchange through host memory (`--backend gloo --share-gpus`,
+    tests only - never a measurement).  Everything but RCCL itself is the code the driver's SCALE run executes: the launcher, the cost-model shards,
+    the size exchange, the per-step gather of the condensed survivors to rank 0, the max-over-ranks clock, the per-rank candidate counts."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpus", "--steps", "2", "--warmup", "1",
+                        "--regions", "1024", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["shared_gpus"] is True
+    assert line["scaling"] == "strong" and "exome200k" in line["config"]["workload"] and "first 1024" in line["config"]["workload"]
+    per = line["config"]["dense_candidates_per_rank"]
+    assert len(per) == 2 and min(per) > 0 and sum(per) == line["config"]["dense_candidates_all_ranks"] and max(per) < 1.5 * min(per)
+    assert line["config"]["survivors_gathered_per_step"] > line["config"]["survivors_rank0"] > 0      # rank 1's survivors arrived too
+    assert line["parity_checked"] is True and line["value"] > 0
+    # the same BED on one rank: the same dense-candidate total
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "exome", "--regions", "1024", "--scaling", "strong", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-parity-gate"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert q.returncode == 0, q.stderr.decode()[-2000:]
+    one = json.loads(q.stdout.decode().strip().splitlines()[-1])
+    assert one["config"]["dense_candidates_all_ranks"] == line["config"]["dense_candidates_all_ranks"]
+    assert one["config"]["emitted_candidates_rank0"] >= line["config"]["emitted_candidates_rank0"] > 0          # rank 0 of two holds a part of it
+
+
 def test_bench_scale_base_line_is_the_sharded_workload():
     """The N = 1 point of the scaling curve: `bench.py --gpus 1 --config exome --regions R --scaling strong` runs, on one GPU, exactly the BED
     that `--gpus N` cuts N ways (same describe string, same dense-candidate total as the sum over the ranks of an N-rank run), and names one
