@@ -381,6 +381,15 @@ int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
  * than the re-score list (1/1024 of its candidates + 4096), the next download of its results fails with MIPGEN_E_STATE instead of handing
  * out digits that are not guaranteed. */
 int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on);
+/* The reference stops constructing candidates at a scan position for good once a capture size starts with previous_best_score above the upper
+ * score limit (mipgen.cpp:430).  A region of more than nine capture sizes is scored in runs of <= 9 sizes; with this switch on the runs are scored in
+ * order and a tile of a later run is left out when every one of its positions has stopped before it - exactly the candidates the reference never
+ * constructs.  Emitted masks, emitted counts, survivors, collapse results and all_mips records are unchanged (the replay never consults the rows
+ * behind a position's exit); the DENSE scores of skipped tiles read NaN, which is why the switch is off by default for callers that fetch the dense
+ * grid.  SVR scoring through the tiled kernel only.  How much it saves is a property of the model (how early the arm-sum lists' last pairs score above
+ * the limit); mipgen_accel_skipped_candidates returns - and resets - the dense candidates left out since the last call. */
+int mipgen_accel_set_dynamic_skip(mipgen_accel* h, int32_t on);
+int mipgen_accel_skipped_candidates(mipgen_accel* h, int64_t* n);
 /* The dense logistic kernel gives a workgroup `n` consecutive runs of scan positions (it stages the bases once and slides its downstream-arm
  * table from run to run).  0 = chosen from the batch size (1 for small batches, which need every workgroup they can get; 2 or 3 for large ones),
  * 1..8 forced.  Results do not depend on it. */

@@ -37,6 +37,12 @@ hipError_t mipgen_launch_print_boundary_scan(hipStream_t, const DevParams*, cons
                                              double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap, int n_cu);
 hipError_t mipgen_launch_print_boundary_scan_list(hipStream_t, const mipgen_candidate* cands, const double* scores, const uint64_t* records, int n, double tol_rel,
                                                   double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
+hipError_t mipgen_launch_svr_run_state(hipStream_t s, int64_t n_pos, const DevParams* P, const DevRegion* regions, const int32_t* pos_region, const int32_t* pos_local,
+                                       const uint32_t* run_bounds, int max_levels, int level, double margin, const double* scores, const uint64_t* records, double* pbs,
+                                       uint8_t* state);
+hipError_t mipgen_launch_svr_tile_keep(hipStream_t s, int n_tiles, const SvrTile* tiles, const int64_t* region_pos0, int64_t win_pos0, const uint8_t* state, int64_t* keep);
+hipError_t mipgen_launch_svr_tile_compact(hipStream_t s, int n_tiles, const SvrTile* tiles, const int64_t* keep, const int64_t* offs, SvrTile* out, const DevParams* P,
+                                          const DevRegion* regions, double* scores, unsigned long long* skipped);
 hipError_t mipgen_launch_dense_candidates(hipStream_t, const DevParams* P, const DevRegion* regions, int r0, int r1, int64_t c0, int n, mipgen_candidate* out);
 hipError_t mipgen_launch_dense_list_fix(hipStream_t, int n, const uint64_t* records, double rho, double s_guard, double* scores);
 hipError_t mipgen_launch_scatter_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, double* scores, unsigned int* over);
@@ -99,6 +105,7 @@ struct Window {
     int64_t cand0 = 0, n_cand = 0;   // batch-wide candidate index of the first candidate; candidates
     int64_t pos0 = 0, n_pos = 0;     // batch-wide scan-position index; positions
     int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0, col_tile0 = 0, n_col_tiles = 0, ld_tile0 = 0, n_ld_tiles = 0;
+    std::vector<int> lvl_tile0;      // dense SVR tiles by capture-size run: run l = svr_tiles_lvl[lvl_tile0[l], lvl_tile0[l + 1])
     int64_t base0 = 0, n_base_entries = 0;   // collapsed entries (2 per base) of the window inside the batch-wide array
 };
 
@@ -249,6 +256,17 @@ struct mipgen_accel {
     std::vector<int32_t> win_lens;
     int win_sizes = 0;
     int64_t win_total = 0;
+    // dynamic skip between capture-size runs (kernels_skip.hip; mipgen_accel_set_dynamic_skip)
+    bool dyn_skip = false;
+    int svr_levels = 1;                      // capture-size runs of the region with the most of them (1: nothing to skip between)
+    DevBuf<SvrTile> svr_tiles_lvl, svr_tiles_kept;
+    DevBuf<uint32_t> run_bounds;             // [region][level]: first size index | sizes << 16
+    DevBuf<double> run_pbs;                  // per scan position of the window: previous_best_score after the runs scored so far
+    DevBuf<uint8_t> run_state;               // 0 still constructing, 1 stopped (mipgen.cpp:430), 2 too close to the limit to call
+    DevBuf<int64_t> run_keep, run_offs;
+    DevBuf<unsigned long long> skip_count;   // dense candidates of the tiles skipped since the last read
+    unsigned long long skipped_total = 0;
+    bool skip_count_valid = false;
     unsigned int* pb_over = nullptr;         // host-mapped word: entries a re-score list could not hold (checked at the next download: pb_check)
     std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
@@ -433,6 +451,8 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
     h->win_img.release();
+    h->svr_tiles_lvl.release(); h->svr_tiles_kept.release(); h->run_bounds.release(); h->run_pbs.release(); h->run_state.release(); h->run_keep.release();
+    h->run_offs.release(); h->skip_count.release();
     h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();
     h->pool.clear();
     if (h->dp) (void)hipFree(h->dp);
@@ -944,7 +964,7 @@ static int build_logistic_tiles(mipgen_accel* h)        // k_logistic_dense: a r
             if (np < 1 || ssmin_all < 1) { ld_ok = false; break; }
             ld_lds = std::max(ld_lds, b);
             // the sub-run length travels in the tile's strand field (these tiles hold both strands)
-            for (int p0 = 0; p0 < d.n_pos; p0 += subs * np) { SvrTile t = {i, np, p0, std::min(subs * np, d.n_pos - p0), 0, d.n_sizes}; ldt.push_back(t); }
+            for (int p0 = 0; p0 < d.n_pos; p0 += subs * np) { SvrTile t = {i, np, p0, std::min(subs * np, d.n_pos - p0), 0, d.n_sizes, 0, 0}; ldt.push_back(t); }
         }
         w.n_ld_tiles = (int)ldt.size() - w.ld_tile0;
     }
@@ -969,9 +989,10 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
     const int Lmax = std::max(D.e_max, D.l_max);
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
     const int lanes = 64 * h->geom.wpc;
-    std::vector<SvrTile> st;
+    std::vector<SvrTile> st, st_lvl;
     std::vector<double> st_cost;
     size_t svr_lds = 0;
+    int max_levels = 1;                                  // capture-size runs of the region with the most of them
     // SVR tiles: capture sizes in nearly equal runs of <= 9, positions in runs as long as the tile's LDS allows (more positions per tile =
     // fewer factor-table entries per candidate and fewer idle candidate lanes).  Every split of the sizes is priced with the kernel's
     // instruction budget - ~47 VALU per (table entry, SV) against ~2.7 per (candidate, SV) at full lanes - and the cheapest one is laid
@@ -1032,7 +1053,9 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
             if (shape.runs.empty()) { svr_lds = (size_t)1 << 30; continue; }
             svr_lds = std::max(svr_lds, shape.lds);
             const int Cmax = D.max_capture - d.k0 * D.inc;
-            for (const Run& r : shape.runs)
+            for (size_t lvl = 0; lvl < shape.runs.size(); lvl++) {
+                const Run& r = shape.runs[lvl];
+                max_levels = std::max(max_levels, (int)lvl + 1);
                 for (int p0 = 0; p0 < d.n_pos; p0 += r.np) {
                     const int npt = std::min(r.np, d.n_pos - p0);
                     // run time of the tile in wavefront-cycles per SV group (measured shares of the three stages): table entries, scan span,
@@ -1040,8 +1063,9 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
                     const int Cmax_t = Cmax - r.ki0 * D.inc, ssmax = Cmax_t - D.min_sum, ssr = (r.kc - 1) * D.inc + D.max_sum - D.min_sum + 1;
                     const double ent = (npt + (npt + ssr - 1)) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)npt * ssr;
                     const double cost = 19.0 * ent + 100.0 * (npt + ssmax + 2 * Lmax) + 75000.0;
-                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc}; st.push_back(t); st_cost.push_back(cost); }
+                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc, (int)lvl, 0}; st.push_back(t); st_cost.push_back(cost); }
                 }
+            }
         }
         // longest tiles first: workgroups are dispatched in index order as compute units free up, so the short tiles fill the end of the
         // launch (k_svr_dense takes tile blockIdx / n_split: consecutive tiles already land on different XCDs)
@@ -1055,6 +1079,17 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
             std::copy(sorted.begin(), sorted.end(), st.begin() + (ptrdiff_t)t0);
         }
         w.n_svr_tiles = (int)st.size() - w.svr_tile0;
+        // the same tiles grouped by capture-size run (run 0 first, longest first inside a run): the launch order of the dynamic skip (kernels_skip.hip)
+        {
+            const size_t t0 = (size_t)w.svr_tile0, n = (size_t)w.n_svr_tiles;
+            int wl = 0;
+            for (size_t k = 0; k < n; k++) wl = std::max(wl, st[t0 + k].level + 1);
+            w.lvl_tile0.assign(1, (int)st_lvl.size());
+            for (int lvl = 0; lvl < wl; lvl++) {
+                for (size_t k = 0; k < n; k++) if (st[t0 + k].level == lvl) st_lvl.push_back(st[t0 + k]);
+                w.lvl_tile0.push_back((int)st_lvl.size());
+            }
+        }
     }
     h->svr_batch_error.clear();
     if (svr_lds > 160 * 1024) {
@@ -1065,6 +1100,16 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
     }
     if (h->svr_tiles.reserve(std::max<size_t>(st.size(), 1))) return MIPGEN_E_NOMEM;
     if (!st.empty()) HIP_TRY(hipMemcpy(h->svr_tiles.p, st.data(), st.size() * sizeof(SvrTile), hipMemcpyHostToDevice));
+    // the run-ordered copy of the tile list and the runs of every region, for the dynamic skip between capture-size runs (only regions of more
+    // than nine capture sizes have a second run)
+    h->svr_levels = st.empty() ? 1 : max_levels;
+    if (h->svr_levels > 1) {
+        std::vector<uint32_t> rb((size_t)h->n_regions * (size_t)max_levels, 0u);
+        for (const SvrTile& t : st) rb[(size_t)t.region * (size_t)max_levels + (size_t)t.level] = (uint32_t)t.ki0 | ((uint32_t)t.kc << 16);
+        if (h->svr_tiles_lvl.reserve(st_lvl.size()) || h->run_bounds.reserve(rb.size())) return MIPGEN_E_NOMEM;
+        HIP_TRY(hipMemcpy(h->svr_tiles_lvl.p, st_lvl.data(), st_lvl.size() * sizeof(SvrTile), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->run_bounds.p, rb.data(), rb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     h->svr_lds = svr_lds;
     h->svr_tiles_ready = true;
     return MIPGEN_OK;
@@ -1176,6 +1221,45 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
         int split = h->sv_split > 0 ? h->sv_split : pick_sv_split(W.n_svr_tiles, h->n_sv, h->n_cu);
         split = std::max(1, std::min(split, (h->n_sv + SVR_GROUP - 1) / SVR_GROUP));
         if (split > 1 && h->partials.reserve((size_t)(split - 1) * (size_t)std::max<int64_t>(W.n_cand, 1))) return MIPGEN_E_NOMEM;
+        const int levels = (int)W.lvl_tile0.size() - 1;
+        if (h->dyn_skip && h->svr_levels > 1 && levels > 1) {
+            // The runs of capture sizes in order, largest first; between two runs the enumeration state of every scan position (mipgen.cpp:426-497)
+            // is advanced over the run just scored, and the tiles of the next run whose positions have all stopped (:430) are left out
+            // (kernels_skip.hip).  One launch per run (no split along the SV list: these are large batches), one small synchronisation per run
+            // for the number of tiles that are left.
+            int max_run = 0;
+            for (int l = 0; l < levels; l++) max_run = std::max(max_run, W.lvl_tile0[(size_t)l + 1] - W.lvl_tile0[(size_t)l]);
+            if (h->run_pbs.reserve((size_t)W.n_pos) || h->run_state.reserve((size_t)W.n_pos) || h->run_keep.reserve((size_t)max_run + 1) ||
+                h->run_offs.reserve((size_t)max_run + 1) || h->svr_tiles_kept.reserve((size_t)max_run) || h->skip_count.reserve(1))
+                return MIPGEN_E_NOMEM;
+            HIP_TRY(hipMemsetAsync(h->run_pbs.p, 0, (size_t)W.n_pos * sizeof(double), h->stream));
+            HIP_TRY(hipMemsetAsync(h->run_state.p, 0, (size_t)W.n_pos, h->stream));
+            if (!h->skip_count_valid) { HIP_TRY(hipMemsetAsync(h->skip_count.p, 0, sizeof(unsigned long long), h->stream)); h->skip_count_valid = true; }
+            // a score this close to the limit could land on the other side after the print-exact re-score: such a position is never marked as stopped
+            const double margin = 1e-6 * std::max(1.0, fabs(h->hp.upper)) + 1e-12 * std::max(1.0, h->sum_abs_coef);
+            for (int l = 0; l < levels; l++) {
+                const SvrTile* tl = h->svr_tiles_lvl.p + W.lvl_tile0[(size_t)l];
+                int nt = W.lvl_tile0[(size_t)l + 1] - W.lvl_tile0[(size_t)l];
+                if (l > 0 && nt > 0) {
+                    HIP_TRY(mipgen_launch_svr_run_state(h->stream, W.n_pos, h->dp, h->regions.p, h->pos_region.p + W.pos0, h->pos_local.p + W.pos0, h->run_bounds.p,
+                                                        h->svr_levels, l - 1, margin, h->scores.p, h->records.p, h->run_pbs.p, h->run_state.p));
+                    HIP_TRY(mipgen_launch_svr_tile_keep(h->stream, nt, tl, h->region_pos0.p, W.pos0, h->run_state.p, h->run_keep.p));
+                    size_t temp_bytes = 0;
+                    HIP_TRY(mipgen_scan_i64(h->stream, nullptr, &temp_bytes, h->run_keep.p, h->run_offs.p, (int64_t)nt + 1));
+                    if (h->fmt_temp.reserve(temp_bytes + 16)) return MIPGEN_E_NOMEM;
+                    HIP_TRY(mipgen_scan_i64(h->stream, h->fmt_temp.p, &temp_bytes, h->run_keep.p, h->run_offs.p, (int64_t)nt + 1));
+                    HIP_TRY(mipgen_launch_svr_tile_compact(h->stream, nt, tl, h->run_keep.p, h->run_offs.p, h->svr_tiles_kept.p, h->dp, h->regions.p, h->scores.p,
+                                                           h->skip_count.p));
+                    int64_t kept = 0;
+                    HIP_TRY(hipMemcpyAsync(&kept, h->run_offs.p + nt, sizeof kept, hipMemcpyDeviceToHost, h->stream));
+                    HIP_TRY(hipStreamSynchronize(h->stream));
+                    tl = h->svr_tiles_kept.p; nt = (int)kept;
+                }
+                HIP_TRY(mipgen_launch_svr_dense(h->stream, nt, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, tl, h->bases.p, h->copy.p,
+                                                (const double*)h->dconsts, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, 1,
+                                                nullptr));
+            }
+        } else
         HIP_TRY(mipgen_launch_svr_dense(h->stream, W.n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p,
                                         h->svr_tiles.p + W.svr_tile0, h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */,
                                         h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, split, h->partials.p));
@@ -1252,6 +1336,27 @@ int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
         if (method == MIPGEN_SCORE_SVR) { if (int rc = fix_print_boundaries_survivors(h, w)) return rc; }
         if (int rc = collapse_window_impl(h)) return rc;
     }
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_set_dynamic_skip(mipgen_accel* h, int32_t on)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    h->dyn_skip = on != 0;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_skipped_candidates(mipgen_accel* h, int64_t* n)
+{
+    if (!h || !n) return fail(MIPGEN_E_INVALID, "bad arguments");
+    *n = 0;
+    if (!h->skip_count_valid) return MIPGEN_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, h->skip_count.p, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemsetAsync(h->skip_count.p, 0, sizeof v, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *n = (int64_t)v;
     return MIPGEN_OK;
 }
 

@@ -1,0 +1,80 @@
+"""GPU: the reference's dynamic skip between capture sizes (mipgen.cpp:430) applied between the capture-size RUNS of the dense SVR scorer
+(mipgen_accel_set_dynamic_skip; kernels_skip.hip).  A tile of a later run is left out when every one of its positions has stopped constructing
+candidates before it.  Whatever the model does - every position stops inside the first run, inside the second, or none at all - the replayed
+emitted mask, the emitted counts, the condensed survivors and the collapse result must be IDENTICAL to the ones of the full dense grid, the dense
+scores must be identical wherever a candidate is emitted, and the replay + condense of the oracle over the full grid must agree."""
+import numpy as np
+import pytest
+
+from mipgen_amd import capi, workloads
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+CACHE = "/tmp/mipgen_test_cache"
+
+
+def _batch(acc, P):
+    genome = workloads.regions5k_genome()
+    ivs = [iv for iv in workloads.regions5k_intervals(3)]
+    # 3 x 5 kb would be 48 M candidates: cut the intervals down to 260 / 90 / 400 bases (27, 1..n and 27 capture sizes after the static skip)
+    from mipgen_amd import synth
+    cut = [synth.Interval(iv.chrom, iv.bed_start + 100, iv.bed_start + 100 + n, iv.label) for iv, n in zip(ivs, (260, 90, 400))]
+    return workloads.build_regions5k(acc, genome, cut, P)
+
+
+@pytest.mark.parametrize("rho,expect", [(-2.2, "first_run"), (-2.1, "later"), (-1.0, "never")])
+def test_dynamic_skip_changes_nothing_but_the_work(rho, expect):
+    P = capi.make_params(120, 250, score_method=capi.SCORE_SVR)
+    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 256, rho=rho)
+    out = {}
+    for on in (False, True):
+        acc = capi.Accel(P)
+        acc.load_model_file(mp)
+        acc.set_sv_split(1)                                   # the skipping launch never splits along the SV list: same summation order in both runs
+        acc.set_dynamic_skip(on)
+        regions = _batch(acc, P)
+        grids = acc.upload(regions)
+        assert max(g.n_sizes for g in grids) == 27
+        acc.score_window(0, capi.SCORE_SVR)
+        scores, records = acc.download()
+        acc.replay_condense()
+        em, surv, mask = acc.download_replay()
+        acc.collapse()
+        col = acc.download_collapsed()
+        skipped = acc.skipped_candidates()
+        # the silent path takes the same route
+        acc.score_condense_all(capi.SCORE_SVR)
+        em2, surv2 = acc.download_survivors()
+        out[on] = dict(scores=scores, records=records, em=em.copy(), surv=surv.copy(), mask=mask.copy(), col=col.copy(), skipped=skipped, em2=em2.copy(),
+                       surv2=surv2.copy(), grids=grids, regions=regions)
+        acc.close()
+    a, b = out[False], out[True]
+    assert a["skipped"] == 0
+    assert np.array_equal(a["records"], b["records"])
+    assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["em"], b["em"])
+    assert a["surv"].tobytes() == b["surv"].tobytes() and np.array_equal(a["col"], b["col"])
+    assert np.array_equal(a["em2"], b["em2"])
+    assert np.array_equal(a["surv2"]["cand_index"], b["surv2"]["cand_index"]) and np.array_equal(a["surv2"]["record"], b["surv2"]["record"])
+    assert np.array_equal(a["surv2"]["score"], b["surv2"]["score"], equal_nan=True)
+    emitted = a["mask"] != 0
+    assert np.array_equal(a["scores"][emitted], b["scores"][emitted], equal_nan=True)       # every constructed candidate carries the same score
+    left_out = np.isnan(b["scores"]) & ~np.isnan(a["scores"])
+    assert not (left_out & emitted).any() and int(left_out.sum()) == b["skipped"]
+    dense = sum(g.count for g in a["grids"])
+    if expect == "first_run":
+        assert b["skipped"] > 0.5 * dense                     # two of three runs of the 27-size regions
+    elif expect == "later":
+        assert 0 < b["skipped"] < 0.5 * dense
+    else:
+        assert b["skipped"] == 0
+    # the oracle's replay + condense over the FULL grid agrees with the survivors of the skipping run
+    pos0 = 0
+    for rd, g in zip(a["regions"], a["grids"]):
+        s = a["scores"][g.offset:g.offset + g.count]
+        r = a["records"][g.offset:g.offset + g.count]
+        n_emit, omask = po.replay_region(P, rd, s, r)
+        osurv = po.condense_region(P, rd, s, r, omask)
+        mine = b["surv"][2 * pos0:2 * (pos0 + g.n_pos)]
+        assert int(b["em"][a["grids"].index(g)]) == n_emit
+        assert np.array_equal(np.where(mine["cand_index"] >= 0, mine["cand_index"] - g.offset, -1), osurv["cand_index"])
+        pos0 += g.n_pos
