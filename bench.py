@@ -93,6 +93,8 @@ def parse_args():
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the in-run oracle check (profiling runs)")
     ap.add_argument("--scale-base-regions", type=int, default=65536, help="exons of the `scale_base` line (N = 1 default run; 0 = skip): what --gpus N > 1 shards")
     ap.add_argument("--measure-traffic", action="store_true", help="measure the dominant kernel's HBM bytes in this run (child rocprofv3 --pmc passes)")
+    ap.add_argument("--dynamic-skip", action="store_true", help="mipgen.cpp:430 between the capture-size runs of the dense SVR scorer (regions of more than nine "
+                    "capture sizes): tiles whose positions have all stopped are not scored; `value` then counts the candidates that WERE scored")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the N > 1 run: nccl = RCCL over xGMI (the measured "
                     "path); gloo = the same exchange through host memory (tests of the N > 1 logic on boxes without a second GPU)")
     ap.add_argument("--share-gpus", action="store_true", help="tests only: ranks beyond the visible devices share them (rank r on GPU r mod devices; gloo only)")
@@ -569,6 +571,8 @@ def main() -> None:
         acc.set_window_candidates(args.window_candidates)
     if args.sv_split:
         acc.set_sv_split(args.sv_split)
+    if args.dynamic_skip:
+        acc.set_dynamic_skip(True)
     grids = acc.upload(regions)                            # inputs resident in HBM before the timed region
     n_cand = acc.batch_candidates()
     acc.set_timing(True)
@@ -606,6 +610,8 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms, records_ms, replay_ms = [], [], []
+    if args.dynamic_skip:
+        acc.skipped_candidates()                            # reset: count the timed steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -617,6 +623,7 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    skipped_per_step = acc.skipped_candidates() // max(args.steps, 1) if args.dynamic_skip else 0       # (the counter was reset before the timed steps)
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -638,7 +645,9 @@ def main() -> None:
             survivors_gathered = sum(sizes) // 24
             head = recv[0][:sizes[0]].cpu().numpy().view(capi.SURVIVOR_DTYPE)
             assert np.array_equal(head["cand_index"], surv["cand_index"]), "rank 0's own slice of the gather differs from its survivors"
-        value = total_cand * args.steps / dt
+        # with --dynamic-skip only the candidates that were scored count (rank 0's skipped share is known here; N > 1: every rank skips alike on the
+        # sharded exome, the line says what it counted)
+        value = (total_cand - skipped_per_step) * args.steps / dt
         k_ms = float(np.mean(kernel_ms))
         n_sv = acc.model_info()[0] if method == "svr" else 0
         alg_bytes = ALG_BYTES_PER_CAND * n_cand
@@ -660,6 +669,8 @@ def main() -> None:
             # FP64 operations the window-separable algorithm needs per support vector: 3 per candidate (multiply + FMA on table factors)
             # + ~45 per distinct table entry (window-sum arithmetic and one full-precision exp2)
             flops = float(n_sv) * (3.0 * n_cand + 45.0 * ent)
+            if args.dynamic_skip and n_cand:
+                flops *= float(n_cand - skipped_per_step) / float(n_cand)      # tiles that were left out did no work: neither candidates nor table entries
             ach = flops / (k_ms * 1e-3) / 1e12
             roof = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
                     "traffic": traffic, "kernel": kern, "kernel_ms": k_ms,
@@ -690,7 +701,9 @@ def main() -> None:
                        "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()),
                        # reference-equivalent rate: candidates the reference would have constructed, per second (rank 0's share)
                        "emitted_candidates_per_s_rank0": float(emitted.sum()) * args.steps / dt,
-                       "survivors_gathered_per_step": survivors_gathered},
+                       "survivors_gathered_per_step": survivors_gathered,
+                       "dynamic_skip": bool(args.dynamic_skip), "skipped_candidates_per_step_rank0": int(skipped_per_step),
+                       "dense_candidates_covered_per_s": total_cand * args.steps / dt},
             "roofline": roof,
             "parity_checked": bool(gate), "parity_gate": gate,
             "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},

@@ -450,6 +450,9 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     if (mipgen_accel_create(&ap, device, nullptr, &h)) { fail_out(17, mipgen_accel_last_error()); return; }
     auto bail = [&](int code) { std::string m = mipgen_accel_last_error(); mipgen_accel_destroy(h); fail_out(code, m); };
     if (o.score_method != MIPGEN_SCORE_LOGISTIC && mipgen_accel_load_model_file(h, d->model_path.c_str())) { bail(18); return; }
+    // svr designs: mipgen.cpp:430 between the capture-size runs of the dense scorer - the tiles of a later run whose positions have all stopped are
+    // never scored, exactly as the reference never constructs those candidates (nothing this front end reads lies behind a position's exit)
+    if (o.score_method == MIPGEN_SCORE_SVR) (void)mipgen_accel_set_dynamic_skip(h, 1);
     const int n = r1 - r0;
     lap(0);
     if (o.score_method != MIPGEN_SCORE_LOGISTIC) {                                                                   // mipgen.cpp:1171,1224
