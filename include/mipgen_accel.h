@@ -390,6 +390,9 @@ int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on);
  * the limit); mipgen_accel_skipped_candidates returns - and resets - the dense candidates left out since the last call. */
 int mipgen_accel_set_dynamic_skip(mipgen_accel* h, int32_t on);
 int mipgen_accel_skipped_candidates(mipgen_accel* h, int64_t* n);
+/* inspection: per scan position of the window scored last with the switch on, the state after its last-but-one run (0 still constructing, 1 stopped,
+ * 2 too close to the limit to call) and previous_best_score there; either output may be NULL */
+int mipgen_accel_skip_state(mipgen_accel* h, uint8_t* state, double* previous_best, int64_t capacity);
 /* The dense logistic kernel gives a workgroup `n` consecutive runs of scan positions (it stages the bases once and slides its downstream-arm
  * table from run to run).  0 = chosen from the batch size (1 for small batches, which need every workgroup they can get; 2 or 3 for large ones),
  * 1..8 forced.  Results do not depend on it. */

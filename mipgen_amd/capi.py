@@ -317,6 +317,7 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_window_uniqueness_end.argtypes = [vp]
     lib.mipgen_accel_set_dynamic_skip.argtypes = [vp, C.c_int32]
     lib.mipgen_accel_skipped_candidates.argtypes = [vp, i64p]
+    lib.mipgen_accel_skip_state.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_int64]
     lib.mipgen_accel_format_all_mips.argtypes = [vp, C.POINTER(RecordNames), C.c_char_p, C.c_int64, i64p, i64p]
     lib.mipgen_accel_download_text.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
@@ -325,7 +326,7 @@ def load_library(path: Optional[str] = None):
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
                  "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
                  "set_sv_split", "set_print_exact", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "window_uniqueness_begin", "window_flags_region", "window_uniqueness_end",
-                 "format_all_mips", "download_text", "set_dynamic_skip", "skipped_candidates"):
+                 "format_all_mips", "download_text", "set_dynamic_skip", "skipped_candidates", "skip_state"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -344,7 +345,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
     "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_window_uniqueness_begin", "mipgen_accel_window_flags_region",
-    "mipgen_accel_window_uniqueness_end", "mipgen_accel_set_dynamic_skip", "mipgen_accel_skipped_candidates", "mipgen_accel_set_print_exact", "mipgen_accel_set_logistic_subruns",
+    "mipgen_accel_window_uniqueness_end", "mipgen_accel_set_dynamic_skip", "mipgen_accel_skipped_candidates", "mipgen_accel_skip_state", "mipgen_accel_set_print_exact", "mipgen_accel_set_logistic_subruns",
 ]
 
 
@@ -469,6 +470,11 @@ class Accel:
     def set_dynamic_skip(self, on: bool) -> None:
         """mipgen.cpp:430 applied between the capture-size runs of the dense SVR scorer (the dense scores of skipped tiles read NaN)."""
         self._check(self.lib.mipgen_accel_set_dynamic_skip(self.h, int(bool(on))))
+
+    def skip_state(self, n_pos: int) -> Tuple[np.ndarray, np.ndarray]:
+        st = np.zeros(n_pos, dtype=np.uint8); pb = np.zeros(n_pos, dtype=np.float64)
+        self._check(self.lib.mipgen_accel_skip_state(self.h, st.ctypes.data_as(C.POINTER(C.c_uint8)), pb.ctypes.data_as(C.POINTER(C.c_double)), n_pos))
+        return st, pb
 
     def skipped_candidates(self) -> int:
         n = C.c_int64(0)

@@ -1346,6 +1346,19 @@ int mipgen_accel_set_dynamic_skip(mipgen_accel* h, int32_t on)
     return MIPGEN_OK;
 }
 
+int mipgen_accel_skip_state(mipgen_accel* h, uint8_t* state, double* previous_best, int64_t capacity)
+{
+    if (!h || capacity < 0) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if (h->cur_window < 0 || !h->run_state.p) return fail(MIPGEN_E_STATE, "no window scored with the dynamic skip");
+    const Window& W = h->windows[(size_t)h->cur_window];
+    if (capacity < W.n_pos) return fail(MIPGEN_E_INVALID, "capacity %lld < %lld scan positions", (long long)capacity, (long long)W.n_pos);
+    HIP_TRY(hipSetDevice(h->device));
+    if (state) HIP_TRY(hipMemcpyAsync(state, h->run_state.p, (size_t)W.n_pos, hipMemcpyDeviceToHost, h->stream));
+    if (previous_best) HIP_TRY(hipMemcpyAsync(previous_best, h->run_pbs.p, (size_t)W.n_pos * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MIPGEN_OK;
+}
+
 int mipgen_accel_skipped_candidates(mipgen_accel* h, int64_t* n)
 {
     if (!h || !n) return fail(MIPGEN_E_INVALID, "bad arguments");

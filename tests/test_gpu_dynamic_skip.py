@@ -22,7 +22,7 @@ def _batch(acc, P):
     return workloads.build_regions5k(acc, genome, cut, P)
 
 
-@pytest.mark.parametrize("rho,expect", [(-2.2, "first_run"), (-2.1, "later"), (-1.0, "never")])
+@pytest.mark.parametrize("rho,expect", [(-2.3, "first_run"), (-2.1, "later"), (-1.0, "never")])
 def test_dynamic_skip_changes_nothing_but_the_work(rho, expect):
     P = capi.make_params(120, 250, score_method=capi.SCORE_SVR)
     mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 1024, rho=rho)
