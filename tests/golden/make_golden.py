@@ -167,6 +167,10 @@ DESIGNS2 = [
          params_file="# limits of the SVR design\n-svr_optimal_score 1.9\n-svr_priority_score 1.2\n-target_arm_copy 8\nnot an option line\n"),
     # scan sizes from 2 and -capture_increment 1: outside the tiled SVR kernel's limits (the list route of the accelerator), inside what the
     # reference accepts (mipgen.cpp:222-261, 427-444: any range / increment)
+    # seventeen capture sizes = two runs of the dense SVR scorer: the front end's dynamic skip between the runs (mipgen.cpp:430; kernels_skip.hip) must
+    # not change a byte - with this optimal score every position of the long region stops at the fourth capture size (some lists of it still constructed): the whole second run is skipped
+    dict(name="svr_two_size_runs", method="svr", ivs=[("1", 30000, 30150, "t"), ("1", 31000, 31060, "u")], minC=120, maxC=200, sums=[42, 43, 44, 45], flank=0,
+         tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_64.model", extra=["-svr_optimal_score", "2.8", "-svr_priority_score", "1.2"]),
     dict(name="svr_scan_size_2_increment_1", method="svr", ivs=[("1", 26000, 26045, "w")], minC=47, maxC=70, sums=[40, 41, 42, 43, 44, 45], flank=0,
          tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_short_48.model", extra=["-capture_increment", "1"]),
 ]
