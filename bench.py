@@ -34,6 +34,9 @@ on the one GPU in the same run (`python bench.py --gpus 1 --config exome --regio
 Every line names `rccl_ranks` (the world size torch.distributed reports after init_process_group; 1 without a process group) and the dense
 candidates of every rank.
 
+--dynamic-skip      mipgen.cpp:430 between the capture-size runs of the dense SVR scorer (configs of more than nine capture sizes: regions5k --method svr,
+                    exome_snp): tiles whose positions have all stopped are not scored.  `value` then counts the candidates that WERE scored
+                    (`config.dense_candidates_covered_per_s` is the covered rate); the headline config (nine sizes: one run) is not affected.
 --measure-traffic   HBM bytes of the dominant kernel measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE - they do
                     not share a pass) of the same workload, started before this process touches the GPU; `roofline.traffic` then comes from
                     them (FETCH_SIZE doubled: the gfx950 correction of MI355X_MICROARCH.md, HBM section) instead of from profiles/.
