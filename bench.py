@@ -38,7 +38,8 @@ candidates of every rank.
                     exome_snp): tiles whose positions have all stopped are not scored.  `value` then counts the candidates that WERE scored
                     (`config.dense_candidates_covered_per_s` is the covered rate); the headline config (nine sizes: one run) is not affected.
 --measure-traffic   HBM bytes of the dominant kernel measured in THIS run: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE - they do
-                    not share a pass) of the same workload, started before this process touches the GPU; `roofline.traffic` then comes from
+                    not share a pass) of the same workload, started before this process touches the GPU (the default N = 1 line does this by
+                    itself: ~40 s; --no-measure-traffic switches it off); `roofline.traffic` then comes from
                     them (FETCH_SIZE doubled: the gfx950 correction of MI355X_MICROARCH.md, HBM section) instead of from profiles/.
 
 Prints ONE JSON line on rank 0.
@@ -95,7 +96,9 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained run of the headline in `extra` (0 = skip)")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the in-run oracle check (profiling runs)")
     ap.add_argument("--scale-base-regions", type=int, default=65536, help="exons of the `scale_base` line (N = 1 default run; 0 = skip): what --gpus N > 1 shards")
-    ap.add_argument("--measure-traffic", action="store_true", help="measure the dominant kernel's HBM bytes in this run (child rocprofv3 --pmc passes)")
+    ap.add_argument("--measure-traffic", action="store_true", help="measure the dominant kernel's HBM bytes in this run (child rocprofv3 --pmc passes); the default "
+                    "N = 1 run (practice62, no --no-extras) does so by itself")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="never start the child rocprofv3 passes (the traffic then comes from profiles/)")
     ap.add_argument("--dynamic-skip", action="store_true", help="mipgen.cpp:430 between the capture-size runs of the dense SVR scorer (regions of more than nine "
                     "capture sizes): tiles whose positions have all stopped are not scored; `value` then counts the candidates that WERE scored")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the N > 1 run: nccl = RCCL over xGMI (the measured "
@@ -444,7 +447,7 @@ def measure_traffic(args, kernel: str):
     if not exe:
         return None
     base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", args.config, "--scaling", args.scaling,
-            "--nsv", str(args.nsv), "--no-cpu-baseline", "--no-extras", "--no-parity-gate"]
+            "--nsv", str(args.nsv), "--no-cpu-baseline", "--no-extras", "--no-parity-gate", "--no-measure-traffic"]
     if args.regions:
         base += ["--regions", str(args.regions)]
     if args.method:
@@ -459,7 +462,7 @@ def measure_traffic(args, kernel: str):
         d = tempfile.mkdtemp(prefix="mipgen_pmc_", dir="/tmp")
         try:
             r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + base, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
             vals = []
             for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(fn)):
@@ -532,7 +535,8 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     traffic_run = None
-    if args.measure_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    default_line = args.gpus == 1 and args.config == "practice62" and not args.no_extras and not args.method and not args.regions
+    if (args.measure_traffic or default_line) and not args.no_measure_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         # child rocprofv3 passes, before this process initialises the GPU
         traffic_run = measure_traffic(args, "k_svr_dense" if (args.method or CONFIGS[args.config][1]) == "svr" else "k_logistic_dense")
 

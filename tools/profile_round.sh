@@ -18,12 +18,12 @@ cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 20 --warmup 5 --measure-traffic > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 tail -c 400 "$OUT/${TAG}_bench.json"; echo
 rm -rf "$OUT/prof_$TAG"
-B="--steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-parity-gate"
+B="--steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-parity-gate --no-measure-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/stats" -o s -- python3 "$R/bench.py" $B > /dev/null 2>&1
 cp "$(find "$OUT/prof_$TAG/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
 for cfg in "regions5k --method logistic" "regions5k --method svr" "exome"; do
   name=$(echo $cfg | tr -d ' -' )
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/stats_$name" -o s -- python3 "$R/bench.py" --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-parity-gate > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG/stats_$name" -o s -- python3 "$R/bench.py" --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-parity-gate --no-measure-traffic > /dev/null 2>&1
   cp "$(find "$OUT/prof_$TAG/stats_$name" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats_$name.csv"
 done
 i=0
@@ -31,12 +31,12 @@ for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_BUSY_CYCLES 
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
             "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/prof_$TAG/pmc$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-parity-gate > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/prof_$TAG/pmc$i" -o p -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-parity-gate --no-measure-traffic > /dev/null 2>&1
 done
 j=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   j=$((j+1))
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/prof_$TAG/lpmc$j" -o p -- python3 "$R/bench.py" --config regions5k --method logistic --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-parity-gate > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/prof_$TAG/lpmc$j" -o p -- python3 "$R/bench.py" --config regions5k --method logistic --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-parity-gate --no-measure-traffic > /dev/null 2>&1
 done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, sys, collections, statistics
