@@ -334,7 +334,7 @@ def cgroup_cpu_quota() -> float:
 
 def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
     """The reference CPU path (oracle/_ref: the real reference compiled from /root/reference by oracle/Makefile) timed on this box's host
-    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (8 regions at every 4th rank of its length-sorted BED: seconds to ~20 s of CPU work each).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
+    cores, on a bounded sample of the practice62 / capture 140-180 / SVR workload (8 regions at every 3rd rank of its length-sorted BED: seconds to ~20 s of CPU work each).  The reference is single-threaded and not re-entrant: multi-core = independent processes on BED shards.
       leg A  one process per sample region, -O2, all_mips written: the emitted-candidate count of every sample region and the single-process
              rate; beside them ONE process of the binary AS SHIPPED (/root/reference/makefile:3-4: no -O flag) on the shortest region;
       leg B  C = all physical cores (capped by the container's cgroup CPU quota, if any) processes at once, -O2, -silent_mode on (no all_mips text): `value` = sum over the processes of
@@ -363,10 +363,10 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                 break
     except OSError:
         pass
-    # 8 sample regions at every 4th rank of the length-sorted BED (ranks 0, 4, ... 28 of 62: 60 to ~150 bp, one to all nine capture sizes after
+    # 8 sample regions at every 3rd rank of the length-sorted BED (ranks 0, 3, ... 21 of 62: 60 to ~120 bp, one to three capture sizes after
     # the static skip of mipgen.cpp:429) - seconds to ~20 s of reference CPU work each, not only the shortest regions
     by_len = sorted(ivs, key=lambda v: (v.bed_end - v.bed_start))
-    pool = [by_len[min(4 * i, len(by_len) - 1)] for i in range(8)]
+    pool = [by_len[min(3 * i, len(by_len) - 1)] for i in range(8)]
     shortest = min(range(len(pool)), key=lambda i: pool[i].bed_end - pool[i].bed_start)
     work = tempfile.mkdtemp(prefix="mipgen_cpu_")          # not /dev/shm: it is mounted noexec on the GPU boxes (the binary is copied beside its model)
 
@@ -411,7 +411,7 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                    "scope": "reference binary, tile_regions only (enumeration + scoring + selection; from its 'bwa copy number analysis finished' line to exit), "
                             "-O2, -silent_mode on in the multi-process leg; end_to_end_value includes its input stage and the stand-in bwa / FASTQ I/O",
                    "sample": f"practice62 / capture 140-180 / SVR n_sv={n_sv}: {cores} concurrent reference processes (-O2, -silent_mode on), one region each from the "
-                             f"{len(pool)} sample regions (every 4th of the length-sorted BED: {'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp), "
+                             f"{len(pool)} sample regions (every 3rd of the length-sorted BED: {'/'.join(str(v.bed_end - v.bed_start) for v in pool)} bp), "
                              f"{n_all} emitted candidates, tile_regions {min(b['hot'] for b in B):.1f}-{max(b['hot'] for b in B):.1f} s per process, {wall:.1f} s wall; "
                              f"alone: {A[shortest]['len']}-bp region, {A[shortest]['n']} candidates, tile_regions {A[shortest]['hot']:.1f} s of {A[shortest]['seconds']:.1f} s"}
             if O0:
