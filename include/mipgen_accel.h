@@ -50,8 +50,11 @@ extern "C" {
 /* ABI version.  Struct layouts are unchanged since 1; 2 marks BEHAVIOUR changes of existing entry points that a caller written against 1
  * must know about (result windows): mipgen_accel_score_resident fails with MIPGEN_E_STATE on a batch of several result windows;
  * mipgen_accel_download_replay's emitted counts / survivors and mipgen_accel_download_results' range are those of the window scored last;
- * copy fields saturated at 65535 mean "look the count up"; survivor / collapse downloads are validated per result window. */
-#define MIPGEN_ACCEL_ABI_VERSION 2
+ * copy fields saturated at 65535 mean "look the count up"; survivor / collapse downloads are validated per result window.
+ * 3: SVR requests on parameter sets outside the tiled kernel's limits succeed (list route) instead of failing with MIPGEN_E_INVALID; a download may fail
+ * with MIPGEN_E_STATE when a print-exact re-score list overflowed; new entry points (mipgen_accel_window_uniqueness_begin / _flags_region / _end,
+ * mipgen_accel_set_dynamic_skip / _skipped_candidates / _skip_state). */
+#define MIPGEN_ACCEL_ABI_VERSION 3
 
 #define MIPGEN_MAX_ARM_PAIRS 256     /* flattened (ext,lig) list, enumeration order */
 #define MIPGEN_N_FEATURES 192        /* SVMipv4.cpp:14 TOTAL_FEATURES */

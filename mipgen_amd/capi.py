@@ -23,7 +23,7 @@ MAX_OLIGO = 64
 
 SCORE_LOGISTIC, SCORE_SVR, SCORE_MIXED = 0, 1, 2
 
-ABI_VERSION = 2          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
+ABI_VERSION = 3          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
 FLAG_VALID, FLAG_GUARD, FLAG_MAPPING, FLAG_MASKING, FLAG_SNP, FLAG_HAS_SNP_MIP = 1, 2, 4, 8, 16, 32
 
 
