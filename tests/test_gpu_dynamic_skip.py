@@ -81,3 +81,52 @@ def test_dynamic_skip_changes_nothing_but_the_work(rho, expect):
         assert int(b["em"][a["grids"].index(g)]) == n_emit
         assert np.array_equal(np.where(mine["cand_index"] >= 0, mine["cand_index"] - g.offset, -1), osurv["cand_index"])
         pos0 += g.n_pos
+
+
+def _fuzz_configs():
+    import os
+    rng = np.random.default_rng(20261003)
+    grid = [(e, l) for e in range(16, 31) for l in range(18, 31) if 38 <= e + l <= 47]
+    out = []
+    for i in range(int(os.environ.get("MIPGEN_FUZZ_SKIP_N", "8"))):
+        inc = int(rng.choice([2, 3, 5, 7]))
+        K = int(rng.integers(10, 31))
+        lo = int(rng.integers(100, 140))
+        n_pairs = int(rng.integers(2, 58))
+        idx = sorted(rng.permutation(len(grid))[:n_pairs].tolist(), key=lambda j: (-(grid[j][0] + grid[j][1]), grid[j][0]))
+        out.append((i, lo, lo + inc * (K - 1), inc, [grid[j] for j in idx], float(rng.uniform(-3.2, -1.2)), float(rng.uniform(1.6, 2.8)),
+                    int(rng.integers(5000, 9_000_000)), int(rng.choice([120, 250, 600]))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _fuzz_configs(), ids=lambda c: f"skip{c[0]}_C{c[1]}-{c[2]}x{c[3]}_A{len(c[4])}_rho{c[5]:.2f}_up{c[6]:.2f}")
+def test_dynamic_skip_random_configurations(cfg):
+    """Random capture ranges of 10..30 sizes (2..4 runs), arm-pair subsets, rho and upper score limit: the skipping launch and the full one give the
+    same emitted mask, emitted counts and survivors, and never leave out a constructed candidate."""
+    i, lo, hi, inc, pairs, rho, upper, start, length = cfg
+    from mipgen_amd import synth
+    P = capi.make_params(lo, hi, score_method=capi.SCORE_SVR, capture_increment=inc, arm_pairs=pairs, svr_optimal=upper)
+    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 256, rho=rho)
+    genome = workloads.regions5k_genome()
+    iv = [synth.Interval("1", start, start + length, f"z{i}")]
+    res = {}
+    for on in (False, True):
+        acc = capi.Accel(P)
+        acc.load_model_file(mp)
+        acc.set_sv_split(1)
+        acc.set_dynamic_skip(on)
+        regions = workloads.build_regions5k(acc, genome, iv, P)
+        grids = acc.upload(regions)
+        acc.score_window(0, capi.SCORE_SVR)
+        scores, records = acc.download()
+        acc.replay_condense()
+        em, surv, mask = acc.download_replay()
+        res[on] = (scores, records, em.copy(), surv.copy(), mask.copy(), acc.skipped_candidates(), grids[0].n_sizes)
+        acc.close()
+    a, b = res[False], res[True]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    assert a[3].tobytes() == b[3].tobytes()
+    emitted = a[4] != 0
+    assert np.array_equal(a[0][emitted], b[0][emitted], equal_nan=True)
+    left_out = np.isnan(b[0]) & ~np.isnan(a[0])
+    assert not (left_out & emitted).any() and int(left_out.sum()) == b[5]
