@@ -130,3 +130,4 @@ def test_dynamic_skip_random_configurations(cfg):
     assert np.array_equal(a[0][emitted], b[0][emitted], equal_nan=True)
     left_out = np.isnan(b[0]) & ~np.isnan(a[0])
     assert not (left_out & emitted).any() and int(left_out.sum()) == b[5]
+    print(f"SKIPSTAT sizes {b[6]} emitted {emitted.mean():.3f} skipped {b[5] / max(1, a[0].size):.3f}")
