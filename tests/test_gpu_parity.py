@@ -172,6 +172,38 @@ def test_replay_condense_vs_oracle(name, genome):
     acc.close()
 
 
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small"])
+def test_all_oracle_chain_vs_device_chain(name, genome):
+    """The chain closed on BOTH sides: the oracle's own dense scores -> its replay -> its condense fold, against the device's scores -> replay ->
+    fold.  (The test above feeds the oracle's control flow the device's scores; here nothing crosses.)  Candidate indices, records and emitted
+    masks must be identical - the two score sets differ by ~1e-14, which flips a comparison only on an exact tie -, scores within 1e-5."""
+    meta = H.load_design(name)
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
+    om = po.Model(_model_path(meta)) if meta["model"] and method == capi.SCORE_SVR else None
+    acc = capi.Accel(P)
+    if meta["model"]:
+        acc.load_model_file(_model_path(meta))
+    grids, scores, records = acc.score_regions(regions, method)
+    acc.replay_condense()
+    emitted, surv, mask = acc.download_replay()
+    pos0 = 0
+    for ri, (rd, g) in enumerate(zip(regions, grids)):
+        _, os_, or_ = po.score_region_dense(P, rd, method, om)
+        n_emit, omask = po.replay_region(P, rd, os_, or_)
+        osurv = po.condense_region(P, rd, os_, or_, omask)
+        assert emitted[ri] == n_emit
+        assert np.array_equal(mask[g.offset:g.offset + g.count], omask)
+        got = surv[2 * pos0:2 * (pos0 + g.n_pos)]
+        assert np.array_equal(got["cand_index"], np.where(osurv["cand_index"] >= 0, osurv["cand_index"] + g.offset, -1))
+        assert np.array_equal(got["record"], osurv["record"])
+        both_nan = np.isnan(got["score"]) & np.isnan(osurv["score"])
+        assert np.all(both_nan | (np.abs(got["score"] - osurv["score"]) <= 1e-5))
+        pos0 += g.n_pos
+    acc.close()
+
+
 def test_edge_cases(genome):
     """Empty batch, ragged capture-size sets (static skip), the widest capture sweep (120-250, K=27), regions at the
     chromosome start (bounds skips), copy 0 / 100 / 101, N runs."""
