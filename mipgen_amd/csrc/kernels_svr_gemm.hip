@@ -110,10 +110,12 @@ __global__ __launch_bounds__(256) void k_svr_gemm(int n, const double* __restric
         for (int c = 0; c < NCH; c++) {                               // unrolled: the A operands are addressed statically
             const int g = tile * NCH + c, buf = c & 1;                // NCH is even: chunk g sits in buffer g & 1 = c & 1
             if (g + 1 < n_chunks) fetch(g + 1);                       // in flight under the matrix instructions below
-            const double* bb = &sB[buf][lk * SG_BP + li];
+            // volatile: four plain ds_read_b64 per step (2 LDS cycles each); merged into two ds_read2_b64 they occupy the LDS array for 8 cycles each
+            typedef volatile __attribute__((address_space(3))) const double lds_vcd;
+            lds_vcd* bb = (lds_vcd*)&sB[buf][lk * SG_BP + li];
 #pragma unroll
             for (int t = 0; t < SG_KC / 4; t++) {
-                const double* b = bb + (4 * t) * SG_BP;
+                lds_vcd* b = bb + (4 * t) * SG_BP;
                 const double b0 = b[0], b1 = b[16], b2 = b[32], b3 = b[48];
                 d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c * (SG_KC / 4) + t], b0, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c * (SG_KC / 4) + t], b1, d1, 0, 0, 0);

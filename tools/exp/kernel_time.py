@@ -19,6 +19,9 @@ else:
     acc.load_model_file(workloads.svr_model_path("gpurun_out/bench_cache", workloads.practice62()[0], 1024))
     regions = workloads.build_exome(acc, chrom_len, all_iv[:2048], P)
 acc.upload(regions)
+if len(sys.argv) > 3:                       # phase ablation of a -DMIPGEN_DIAG build: 1 no scan, 2 no tables, 4 no candidate steps (timing only)
+    import ctypes
+    capi._lib.mipgen_svr_debug_set(ctypes.c_int(int(sys.argv[3])))
 acc.set_timing(True)
 ts = []
 for _ in range(12):
@@ -27,4 +30,4 @@ ts = np.array(ts[2:])
 sc, rec = acc.download()
 import hashlib
 chk = hashlib.md5(np.ascontiguousarray(sc).tobytes()).hexdigest()[:12] + " sum=%r" % float(np.nansum(sc))
-print(f"{cfg} {lib_path or 'product'}: kernel ms min {ts.min():.3f} median {np.median(ts):.3f}  checksum {chk!r}")
+print(f"{cfg} {lib_path or 'product'} {' '.join(sys.argv[3:])}: kernel ms min {ts.min():.3f} median {np.median(ts):.3f}  checksum {chk!r}")

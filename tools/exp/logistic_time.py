@@ -1,0 +1,21 @@
+# tools/exp/logistic_time.py [LIB]: kernel times of the dense logistic path on 24 x 5 kb regions (capture 120-250), for A/B runs of scratch builds
+import os, sys, hashlib, numpy as np
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R)
+from mipgen_amd import capi, workloads
+lib_path = sys.argv[1] if len(sys.argv) > 1 else None
+if lib_path:
+    capi.LIB_PATH = os.path.join(R, lib_path); capi._lib = capi.load_library(capi.LIB_PATH)
+P = capi.make_params(120, 250, score_method=capi.SCORE_LOGISTIC)
+acc = capi.Accel(P)
+ivs = workloads.regions5k_intervals(24)
+regions = workloads.build_regions5k(acc, workloads.regions5k_genome(), ivs, P, with_lrc=False)
+acc.upload(regions)
+acc.set_timing(True)
+ts = []
+for _ in range(14):
+    acc.score_window(0, capi.SCORE_LOGISTIC); ts.append([acc.last_kernel_ms(k) for k in range(3)])
+ts = np.array(ts[3:])
+sc, rec = acc.download()
+chk = hashlib.md5(np.ascontiguousarray(sc).tobytes()).hexdigest()[:12] + hashlib.md5(np.ascontiguousarray(rec).tobytes()).hexdigest()[:8]
+print(f"regions5k logistic {lib_path or 'product'}: kernel ms (min over runs) {ts.min(axis=0).round(3).tolist()} median {np.median(ts, axis=0).round(3).tolist()} checksum {chk}")
