@@ -14,8 +14,11 @@ acc.upload(regions)
 acc.set_timing(True)
 ts = []
 for _ in range(14):
-    acc.score_window(0, capi.SCORE_LOGISTIC); ts.append([acc.last_kernel_ms(k) for k in range(3)])
+    acc.score_window(0, capi.SCORE_LOGISTIC); t2 = acc.last_kernel_ms(2)
+    acc.replay_condense(); ts.append([t2, acc.last_kernel_ms(3)])
 ts = np.array(ts[3:])
 sc, rec = acc.download()
+em, surv, _ = acc.download_replay(want_mask=False)
 chk = hashlib.md5(np.ascontiguousarray(sc).tobytes()).hexdigest()[:12] + hashlib.md5(np.ascontiguousarray(rec).tobytes()).hexdigest()[:8]
-print(f"regions5k logistic {lib_path or 'product'}: kernel ms (min over runs) {ts.min(axis=0).round(3).tolist()} median {np.median(ts, axis=0).round(3).tolist()} checksum {chk}")
+chk2 = hashlib.md5(np.ascontiguousarray(em).tobytes()).hexdigest()[:8] + hashlib.md5(np.ascontiguousarray(surv).tobytes()).hexdigest()[:8]
+print(f"regions5k logistic {lib_path or 'product'}: [k_logistic_dense, replay + condense] ms min {ts.min(axis=0).round(3).tolist()} median {np.median(ts, axis=0).round(3).tolist()} checksum {chk} replay {chk2}")
