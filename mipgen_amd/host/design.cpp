@@ -16,6 +16,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <future>
 
 #include "../../include/mipgen_host.h"
 #include "mipgen_host.hpp"
@@ -119,6 +120,9 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         d->regions = load_regions(o);
         if (d->regions.empty()) { std::cerr << "[mipgen] region file could not be opened" << std::endl; throw 6; }
         clk.lap("options + BED sort / merge");
+        // -gpu_copy_counter: the genome behind the bwa index is read while the region sequences are sliced (it only looks at the regions' chromosome names)
+        std::future<void> genome_ready;
+        if (gpu_copies) genome_ready = std::async(std::launch::async, [&o, d_ = d.get()]() { load_genome(o, d_->regions, d_->genome); });
         out.progress << "successfully loaded features for mip design; retrieving chromosomal sequence\n";
         std::cerr << "[mipgen] features loaded; retrieving chromosomal sequence\n";
         if (o.has("-genome_dir")) { if (!load_sequences_from_genome_dir(o, d->regions)) { std::cerr << "[mipgen] chromosome fasta not acquired" << std::endl; throw 7; } }
@@ -133,7 +137,7 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         out.progress << "all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         std::cerr << "[mipgen] all " << d->tables.snp_load_count << " snps loaded; generating files for bwa\n";
         if (gpu_copies) {
-            load_genome(o, d->regions, d->genome);
+            genome_ready.get();                                                                                      // SURVEY.md section 8f-3 (load_genome, started above)
             d->copies_deferred = true;
             for (Region& r : d->regions) r.copy_deferred = true;
             out.progress << "exact oligo copy numbers and capture-window uniqueness counted on the accelerator\n";

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <future>
 #include <iostream>
 #include <sstream>
 
@@ -140,16 +142,36 @@ static bool slurp_fasta(const std::string& path, std::vector<std::string>& recor
 
 bool load_sequences_from_genome_dir(const Options& o, std::vector<Region>& regs)
 {
-    std::string chr = "0", chr_seq;
     std::ofstream fa(o.project_name + ".feature_sequences.fa");
     const std::string dir = o.arg("-genome_dir");
-    for (Region& r : regs) {
-        if (chr != r.chr) {
-            chr_seq.clear();
-            chr = r.chr;
-            std::vector<std::string> recs;
-            if (!slurp_fasta(dir + "/chr" + chr + ".fa", recs)) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; return false; }
-            for (std::string& rec : recs) { upper(rec); if (chr_seq.empty()) chr_seq.swap(rec); else chr_seq += rec; }      // every sequence line of the file, as the reference joins them
+    // The chromosome files are read and joined ahead of the regions that slice them (up to four loads in flight: a 300 Mb genome is 0.5 s of
+    // fread + line joining + toupper on one core).  One load per RUN of regions on the same chromosome, as the reference reloads on every change.
+    struct Loaded { bool ok = false; std::string seq; };
+    auto load_chr = [dir](std::string chr) {
+        Loaded l;
+        std::vector<std::string> recs;
+        if (!slurp_fasta(dir + "/chr" + chr + ".fa", recs)) return l;
+        for (std::string& rec : recs) { upper(rec); if (l.seq.empty()) l.seq.swap(rec); else l.seq += rec; }      // every sequence line of the file, as the reference joins them
+        l.ok = true;
+        return l;
+    };
+    std::vector<size_t> run_first;                                               // first region of every run
+    for (size_t i = 0; i < regs.size(); i++) if (i == 0 || regs[i].chr != regs[i - 1].chr) run_first.push_back(i);
+    std::deque<std::future<Loaded>> ahead;
+    size_t next_run = 0;
+    auto top_up = [&]() { while (next_run < run_first.size() && ahead.size() < 4) ahead.push_back(std::async(std::launch::async, load_chr, regs[run_first[next_run++]].chr)); };
+    std::string chr_seq;
+    size_t run = 0;
+    for (size_t i = 0; i < regs.size(); i++) {
+        Region& r = regs[i];
+        if (run < run_first.size() && run_first[run] == i) {
+            top_up();
+            Loaded l = ahead.front().get();
+            ahead.pop_front();
+            run++;
+            top_up();
+            if (!l.ok) { std::cerr << "[mipgen] fasta file could not be opened" << std::endl; for (auto& f : ahead) f.wait(); return false; }
+            chr_seq.swap(l.seq);
         }
         const int cs = r.start_fl - o.max_capture < 1 ? 1 : r.start_fl - o.max_capture;
         const int ce = r.stop_fl + o.max_capture + 15 > (int)chr_seq.size() ? (int)chr_seq.size() : r.stop_fl + o.max_capture + 15;
