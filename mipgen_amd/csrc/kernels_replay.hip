@@ -21,6 +21,7 @@
 // This removes the device-to-host copy of the dense grid (16 B/candidate) for silent designs: 2 survivors per position remain.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <algorithm>
 #include "common.h"
 #include "device_utils.h"
 
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
                 const bool valid = (MIPGEN_REC_FLAGS(br[q]) & MIPGEN_FLAG_VALID) != 0;           // :443-444 (0 outside the row)
                 const uint64_t vmask = __ballot(valid);
                 bool mine = valid;
-                if (heuristic && vmask) {
+                // (rows whose constructed pairs all score in [0, 1) cannot trigger :494 - every truncated score is 0: see k_replay_condense_carry)
+                if (heuristic && vmask && __ballot(valid && !(plus >= 0.0 && plus < 1.0 && minus >= 0.0 && minus < 1.0))) {
                     // the pair before me in my list that was constructed: its truncated scores are what :494 compares against
                     const uint64_t below = vmask & seg_below;
                     const int src = below ? top_bit(below) : lane;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
                 int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
                 // Quick reject, exact: once a candidate is held (:1695 no longer applies) every other rule needs a higher score (:1717,1731),
                 // fewer SNPs (:1725), a copy number above the target (:1709) or masked bases (:1701) - most rows have none of these
-                if (best_idx >= 0 && !__ballot(mine && (sc > best_score || ext_copy > target_copy || lig_copy > target_copy || masked_any_counts ||
+                if (best_idx >= 0 && !(em[q] & __ballot(sc > best_score || ext_copy > target_copy || lig_copy > target_copy || masked_any_counts ||
                                                         MIPGEN_REC_MASKED_N(r) != 0 || (int)MIPGEN_REC_SNP_COUNT(r) < best_snp))) continue;
                 const bool saturated = mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0;
                 if (__ballot(saturated) && saturated) {                    // (the uniform test first: no exec-mask bookkeeping in the common case)
@@ -416,7 +418,8 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
                 }
                 const bool ok = mine && !((int64_t)ext_copy * lig_copy > max_product) && !(MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING);   // :1689-1690
                 const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
-                const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / arm_sum;
+                double cur_masked = 0.0;                                   // (the division only where an emitted candidate has masked bases: 0 / x is exactly 0)
+                if (em[q] & __ballot(MIPGEN_REC_MASKED_N(r) != 0)) cur_masked = (double)MIPGEN_REC_MASKED_N(r) / arm_sum;
                 const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
                 uint64_t pending = __ballot(ok);
                 while (pending) {
@@ -496,6 +499,11 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
     const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
     const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;
     const uint64_t seg_below = seg & below_me, seg_above = seg & ~below_me & ~lane_bit;
+    const int target_copy = P->target_arm_copy;
+    const int64_t max_product = P->max_arm_copy_product;
+    const double thr = P->masked_arm_threshold;
+    const bool masked_any_counts = thr < 0.0;                                        // then even an arm without masked bases is "above the threshold" (:1701)
+    const double arm_sum = (double)(l + e);
 
     // ---- the position's rows: scores and records of both strands, one round trip ----
     double bp[CR], bm[CR];
@@ -517,10 +525,13 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
         uint64_t emit_all = 0;
         if (!(pbs > upper)) {                                                // :430
             const double plus = bp[q], minus = bm[q];
-            const bool valid = (MIPGEN_REC_FLAGS(rp[q]) & MIPGEN_FLAG_VALID) != 0;               // :443-444
+            const bool valid = in && (MIPGEN_REC_FLAGS(rp[q]) & MIPGEN_FLAG_VALID) != 0;         // :443-444
             const uint64_t vmask = __ballot(valid);
             bool mine = valid;
-            if (heuristic && vmask) {
+            // :494 compares a score with the TRUNCATED score of the pair before it: while every constructed pair of the row scores in [0, 1) - any
+            // logistic row without a guard value or a NaN - all those integers are 0 and the test (plus < 0 && minus < 0) fails on every lane: one
+            // ballot instead of the shuffles (exact: any other row takes the general path)
+            if (heuristic && vmask && __ballot(valid && !(plus >= 0.0 && plus < 1.0 && minus >= 0.0 && minus < 1.0))) {
                 const uint64_t below = vmask & seg_below;
                 const int src = below ? top_bit(below) : lane;
                 const double pp = __shfl(plus, src, 64), pm = __shfl(minus, src, 64);
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
                     }
                 }
                 n_emitted += 2ull * (unsigned)__builtin_popcountll(emit_all);
-                if (emitted && (emit_all & lane_bit)) {
+                if (emitted && __builtin_amdgcn_inverse_ballot_w64(emit_all)) {
                     const int64_t idx = base + ((int64_t)q * 2) * A + lane;
                     emitted[idx] = 1; emitted[idx + A] = 1;
                 }
@@ -559,11 +570,6 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
     if (n_emitted && lane == 0) atomicAdd(&emitted_per_region[ri], n_emitted);
 
     // ---- condense, mipgen.cpp:1670-1746, from the registers ----
-    const int target_copy = P->target_arm_copy;
-    const int64_t max_product = P->max_arm_copy_product;
-    const double thr = P->masked_arm_threshold;
-    const bool masked_any_counts = thr < 0.0;                                        // then even an arm without masked bases is "above the threshold" (:1701)
-    const double arm_sum = (double)(l + e);
     int chosen_copy = 0;
     double chosen_masked = 0.0;
     for (int s = 0; s < 2; s++) {
@@ -576,15 +582,15 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
         for (int q = CR - 1; q >= 0; q--) {                                  // newest first (push_front, :475,489)
             if (stop || !em[q]) continue;
             const int ki = q;
-            const bool mine = (em[q] & lane_bit) != 0;
             const uint64_t r = s ? rm[q] : rp[q];
             const double sc = s ? bm[q] : bp[q];
             int ext_copy = (int)MIPGEN_REC_EXT_COPY(r), lig_copy = (int)MIPGEN_REC_LIG_COPY(r);
             // quick reject, exact (see k_replay_condense_narrow)
-            if (best_idx >= 0 && !__ballot(mine && (sc > best_score || ext_copy > target_copy || lig_copy > target_copy || masked_any_counts ||
+            // (the emitted lanes gate every ballot as a uniform mask: no per-lane copy of it)
+            if (best_idx >= 0 && !(em[q] & __ballot(sc > best_score || ext_copy > target_copy || lig_copy > target_copy || masked_any_counts ||
                                                     MIPGEN_REC_MASKED_N(r) != 0 || (int)MIPGEN_REC_SNP_COUNT(r) < best_snp))) continue;
-            const bool saturated = mine && (ext_copy == 65535 || lig_copy == 65535) && R.copy_off >= 0;
-            if (__ballot(saturated) && saturated) {
+            const uint64_t sat_mask = R.copy_off >= 0 ? em[q] & __ballot(ext_copy == 65535 || lig_copy == 65535) : 0;
+            if (sat_mask && __builtin_amdgcn_inverse_ballot_w64(sat_mask)) {
                 const int C = P->max_capture - (R.k0 + ki) * P->inc, p = R.first_pos + pi, ss = C - e - l;
                 const int ext_start = s ? p + ss : p - e, lig_start = s ? p - l : p + ss;
                 const int se = P->len_slot[e], sl = P->len_slot[l];
@@ -592,11 +598,13 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
                 ext_copy = (se >= 0 && ie >= 0 && ie < R.seq_len) ? copy[R.copy_off + (int64_t)se * R.seq_len + ie] : 0;
                 lig_copy = (sl >= 0 && il >= 0 && il < R.seq_len) ? copy[R.copy_off + (int64_t)sl * R.seq_len + il] : 0;
             }
-            const bool ok = mine && !((int64_t)ext_copy * lig_copy > max_product) && !(MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING);   // :1689-1690
+            const bool ok = !((int64_t)ext_copy * lig_copy > max_product) && !(MIPGEN_REC_FLAGS(r) & MIPGEN_FLAG_MAPPING);   // :1689-1690 (of an emitted lane: the mask below)
             const int cur_copy = ext_copy > lig_copy ? ext_copy : lig_copy;
-            const double cur_masked = (double)MIPGEN_REC_MASKED_N(r) / arm_sum;
+            // (the division only where an emitted candidate has masked bases at all: 0 / x is exactly 0)
+            double cur_masked = 0.0;
+            if (em[q] & __ballot(MIPGEN_REC_MASKED_N(r) != 0)) cur_masked = (double)MIPGEN_REC_MASKED_N(r) / arm_sum;
             const int snp = (int)MIPGEN_REC_SNP_COUNT(r);
-            uint64_t pending = __ballot(ok);
+            uint64_t pending = em[q] & __ballot(ok);
             while (pending) {
                 const bool rA = best_idx < 0;                                                                     // :1695
                 const bool rB = (cur_masked > thr) & (cur_masked < chosen_masked);                                // :1701
