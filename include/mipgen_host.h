@@ -86,6 +86,11 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
 /* counters after the regions selected so far: all / collapsed / picked records written, gaps reported */
 int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps);
 
+/* Relative device time of every region (dense-grid candidates; for svr designs weighted with the factor-table entries of the dense SVR scorer): the
+ * weights mipgen_design_run balances its contiguous device shards with, for a caller that shards the regions itself (one process per GPU:
+ * mipgen_amd/mp_design.py).  capacity >= mipgen_design_region_count. */
+int mipgen_design_region_weights(const mipgen_design* d, int64_t* weights, int32_t capacity);
+
 /*
  * tile_regions on the accelerator: one libmipgen_accel handle per device, regions sharded over the devices in contiguous ranges
  * balanced by dense-grid size, each device scoring / replaying / condensing its result windows on its own thread while the calling

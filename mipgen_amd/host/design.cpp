@@ -645,6 +645,23 @@ static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_c
     return (int64_t)(2.7 * (double)cand + 47.0 * (double)ent);
 }
 
+static int64_t region_weight_of(const mipgen_design* d, int i)
+{
+    const Options& o = d->o;
+    std::set<int> es, ls;
+    for (auto& pr : o.arm_pairs) { es.insert(pr.first); ls.insert(pr.second); }
+    const Region& r = d->regions[(size_t)i];
+    return region_cost(r.start_fl, r.stop_fl, o.min_capture, o.max_capture, o.capture_increment, o.max_mip_overlap, (int)o.arm_pairs.size(), (int)es.size(),
+                       (int)ls.size(), o.max_arm_sum, o.min_arm_sum, o.score_method == MIPGEN_SCORE_SVR);
+}
+
+extern "C" int mipgen_design_region_weights(const mipgen_design* d, int64_t* weights, int32_t capacity)
+{
+    if (!d || !weights || capacity < (int32_t)d->regions.size()) return fail(MIPGEN_HOST_E_USAGE, 0, "bad arguments");
+    for (int i = 0; i < (int)d->regions.size(); i++) weights[i] = region_weight_of(d, i);
+    return 0;
+}
+
 extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
 {
     if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
@@ -656,17 +673,8 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     // contiguous region ranges balanced by dense-grid size (the reference's region order is the order of the selection stage)
     std::vector<int64_t> weight((size_t)n);
     int64_t total = 0;
-    {
-        const Options& o = d->o;
-        std::set<int> es, ls;
-        for (auto& pr : o.arm_pairs) { es.insert(pr.first); ls.insert(pr.second); }
-        for (int i = 0; i < n; i++) {
-            const Region& r = d->regions[(size_t)i];
-            weight[(size_t)i] = region_cost(r.start_fl, r.stop_fl, o.min_capture, o.max_capture, o.capture_increment, o.max_mip_overlap, (int)o.arm_pairs.size(),
-                                            (int)es.size(), (int)ls.size(), o.max_arm_sum, o.min_arm_sum, o.score_method == MIPGEN_SCORE_SVR);
-            total += weight[(size_t)i];
-        }
-    }
+    if (n > 0 && mipgen_design_region_weights(d, weight.data(), n)) return -1;
+    for (int i = 0; i < n; i++) total += weight[(size_t)i];
     std::vector<std::pair<int, int>> shard;
     {
         int lo = 0;

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
     "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region",
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
-    "mipgen_design_select_region_collapsed", "mipgen_design_counters",
+    "mipgen_design_select_region_collapsed", "mipgen_design_counters", "mipgen_design_region_weights",
     "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
 ]
 
@@ -60,6 +60,7 @@ def load_library():
     lib.mipgen_design_select_region_collapsed.argtypes = [vp, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.c_int64, C.POINTER(C.c_double),
                                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int32, RESCORE_FN, vp]
     lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
+    lib.mipgen_design_region_weights.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_devices.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_window_candidates.argtypes = [vp, C.c_int64]
@@ -141,6 +142,13 @@ class Design:
             self._check(self.lib.mipgen_design_select_region_collapsed(*args, collapsed.ctypes.data_as(C.POINTER(C.c_int32)), collapsed.shape[0] // 2, fn, None))
         else:
             self._check(self.lib.mipgen_design_select_region(*args, fn, None))
+
+    def region_weights(self) -> np.ndarray:
+        """Relative device time per region: the weights of the device shards (mipgen_design_run's own rule)."""
+        n = self.region_count()
+        w = np.zeros(max(n, 1), dtype=np.int64)
+        self._check(self.lib.mipgen_design_region_weights(self.h, w.ctypes.data_as(C.POINTER(C.c_int64)), n))
+        return w[:n]
 
     def counters(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()

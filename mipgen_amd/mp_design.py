@@ -1,0 +1,195 @@
+"""One process per GPU: a whole mipgen design through `torch.distributed` (RCCL over xGMI on the GPU box).
+
+    python -m mipgen_amd.mp_design --gpus N -- -regions_to_scan x.bed -project_name out -min_capture_size 150 ... [any mipgen flag]
+
+The reference's tile_regions (/root/reference/mipgen.cpp:412-515) enumerates, scores and condenses every region independently and then picks
+sequentially in region order (the rand() stream and the used-arm sets persist across regions, :97, :1863).  So:
+
+  every rank   opens the design (options + input stage of libmipgen_host.so; ranks > 0 write their copies of the input-stage files into a
+               scratch directory), takes its contiguous shard of the regions - balanced with the weights the in-process driver uses
+               (mipgen_design_region_weights) -, scores + replays + condenses it on ITS GPU (libmipgen_accel.so) and
+  one exchange gathers the condensed survivors (2 per scan position, 24 bytes each), the per-region emitted counts and grids to rank 0, which
+  rank 0       runs the selection stage region by region (mipgen_design_select_region) and writes the design's files.
+
+Silent logistic / svr designs (`-silent_mode on` is added when absent); mixed designs and the all_mips text stay with the in-process multi-GPU
+driver (`mipgen -gpus N`).  `--backend gloo --share-gpus` runs the same code on a one-GPU box (tests).  The product has no CPU path: without
+a HIP device this fails."""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _split_args(argv: List[str]):
+    import argparse
+    if "--" in argv:
+        k = argv.index("--")
+        own, flags = argv[:k], argv[k + 1:]
+    else:
+        own, flags = argv, []
+    ap = argparse.ArgumentParser(prog="python -m mipgen_amd.mp_design", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1, help="processes = GPUs of this node")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI; gloo + --share-gpus: tests on a one-GPU box")
+    ap.add_argument("--share-gpus", action="store_true", help="ranks beyond the visible devices wrap around (never a measurement)")
+    ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--mipgen-path", default=os.path.join(HERE, "mipgen"), help="argv[0] of the design: mipgen_svr.model is looked for beside it (mipgen.cpp:409)")
+    args = ap.parse_args(own)
+    if not flags:
+        ap.error("the mipgen flags follow `--`")
+    return args, flags
+
+
+def _launch(args, argv: List[str]) -> int:
+    """--gpus N > 1 without a launcher: start torch.distributed.run as a CHILD (nothing here has touched a GPU; a GPU-initialised process never execs)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(args.master_port), "-m", "mipgen_amd.mp_design"] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
+def _all_ranks_ok(dist, torch, xdev, ok: bool) -> bool:
+    """Every rank reports once, after its shard is scored (or failed): the gather only starts when all of them succeeded."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=xdev if xdev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+class _View:
+    """A region of the design in the C layout (pointers into libmipgen_host's arrays), as capi.Accel.upload takes it."""
+
+    def __init__(self, c):
+        self.c = c
+        self.alleles = None
+
+
+def main(argv: List[str]) -> int:
+    args, flags = _split_args(argv)
+    if "RANK" not in os.environ and args.gpus > 1:
+        return _launch(args, argv)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mipgen_amd import capi, dist as mdist, hostapi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("mipgen_amd.mp_design needs an MI355X: the hot path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        if not (args.share_gpus and args.backend == "gloo"):
+            raise SystemExit(f"rank {rank} needs GPU {local_rank}, but this node shows {torch.cuda.device_count()} device(s): one process per GPU")
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    xdev = f"cuda:{local_rank}" if args.backend == "nccl" else None      # where the tensors of the gather live
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+
+    t_start = time.perf_counter()
+    flags = list(flags)
+    if "-silent_mode" in flags:
+        k = flags.index("-silent_mode")
+        if k + 1 >= len(flags) or flags[k + 1] != "on":
+            raise SystemExit("mp_design: only silent designs (the all_mips text of several ranks is the in-process driver's: mipgen -gpus N)")
+    else:
+        flags += ["-silent_mode", "on"]
+    scratch = None
+    if rank > 0:                                                           # the input stage writes files named after the project: ranks > 0 keep theirs out of the way
+        scratch = tempfile.mkdtemp(prefix=f"mipgen_rank{rank}_")
+        name = "mipgen_design"
+        if "-project_name" in flags:
+            k = flags.index("-project_name")
+            name = os.path.basename(flags[k + 1]) or name
+            flags[k + 1] = os.path.join(scratch, name)
+        else:
+            flags += ["-project_name", os.path.join(scratch, name)]
+    rc = 0
+    d = None
+    try:
+        d = hostapi.Design([args.mipgen_path] + flags)
+        if d.score_method == capi.SCORE_MIXED:
+            raise SystemExit("mp_design: mixed designs re-score survivors on the accelerator that holds their region - use the in-process driver (mipgen -gpus N)")
+        P = d.params()
+        n = d.region_count()
+        scan = capi.SCORE_SVR if d.score_method == capi.SCORE_SVR else capi.SCORE_LOGISTIC
+        shards = mdist.shard_regions(d.region_weights().tolist(), world)
+        lo, hi = shards[rank]
+        t_inputs = time.perf_counter()
+        acc = capi.Accel(P, device=local_rank)
+        if scan == capi.SCORE_SVR:
+            acc.load_model_file(d.model_path)
+            acc.set_dynamic_skip(True)                                     # mipgen.cpp:430 between the capture-size runs, as the front end does
+            if hi > lo:                                                    # long-range content of the shard's regions, on the device
+                views0 = [d.region(i) for i in range(lo, hi)]
+                lrc = acc.long_range_content_batch([d.long_range_seq(i) for i in range(lo, hi)], [v.seq_start for v in views0], [v.seq_stop for v in views0])
+                for k, i in enumerate(range(lo, hi)):
+                    d.set_long_range_content(i, lrc[k])
+        views = [_View(d.region(i)) for i in range(lo, hi)]
+        if views:
+            grids = acc.upload(views)
+            acc.score_condense_all(scan)
+            emitted, surv = acc.download_survivors()
+        else:
+            grids, emitted, surv = [], np.zeros(0, dtype=np.int64), np.zeros(0, dtype=capi.SURVIVOR_DTYPE)
+        garr = np.array([[g.offset, g.count, g.first_pos, g.n_pos, g.first_size_index, g.n_sizes] for g in grids], dtype=np.int64).reshape(-1)
+        t_scored = time.perf_counter()
+        if distributed and not _all_ranks_ok(dist, torch, xdev, True):
+            raise SystemExit(1)
+        if distributed:
+            # the one exchange step of the path: condensed survivors (+ the per-region counts and grids) -> rank 0
+            all_surv = mdist.gather_to_rank0(surv, xdev)
+            all_emitted = mdist.gather_to_rank0(emitted, xdev)
+            all_grids = mdist.gather_to_rank0(garr, xdev)
+        else:
+            all_surv, all_emitted, all_grids = surv, emitted, garr
+        t_gathered = time.perf_counter()
+        acc.close()
+        if rank == 0:
+            all_grids = all_grids.reshape(-1, 6)
+            assert all_grids.shape[0] == n and all_emitted.shape[0] == n, "the gather lost regions"
+            pos = 0
+            for i in range(n):
+                g = capi.Grid()
+                g.offset, g.count, g.first_pos, g.n_pos, g.first_size_index, g.n_sizes = (int(x) for x in all_grids[i])
+                d.select_region(i, g, all_surv[2 * pos:2 * (pos + g.n_pos)], int(all_emitted[i]))
+                pos += g.n_pos
+            c = d.counters()
+            t_end = time.perf_counter()
+            print(json.dumps({"regions": n, "ranks": world, "backend": args.backend if distributed else None, "shards": shards,
+                              "survivors_gathered": int(all_surv.shape[0]), "emitted_candidates": int(all_emitted.sum()), "picked": c["picked"], "gaps": c["gaps"],
+                              "seconds": {"inputs": round(t_inputs - t_start, 3), "score + condense (rank 0's shard)": round(t_scored - t_inputs, 3),
+                                          "gather": round(t_gathered - t_scored, 3), "selection": round(t_end - t_gathered, 3)}}), flush=True)
+    except (hostapi.HostError, capi.AccelError) as e:
+        print(f"[mp_design] rank {rank}: {e}", file=sys.stderr)
+        rc = 1
+        if distributed:
+            _all_ranks_ok(dist, torch, xdev, False)                          # the other ranks learn of it instead of waiting in the gather
+    finally:
+        if d is not None:
+            d.close()
+        if scratch:
+            shutil.rmtree(scratch, ignore_errors=True)
+    if distributed:
+        if rc == 0:
+            dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -62,3 +62,18 @@ def test_region_cost_weights_and_contiguous_shards():
         assert sh[0][0] == 0 and sh[-1][1] == len(ivs) and all(a[1] == b[0] for a, b in zip(sh, sh[1:])) and all(hi > lo for lo, hi in sh)
         tot = [w_svr[lo:hi].sum() for lo, hi in sh]
         assert max(tot) / (sum(tot) / world) < 1.05
+
+
+def test_multi_process_design_has_no_cpu_path():
+    """mipgen_amd/mp_design.py (one process per GPU) refuses to run without a HIP device - the product never falls back to the CPU - and says what
+    it wants when the mipgen flags are missing."""
+    import sys
+    import torch
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "mipgen_amd.mp_design", "--gpus", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"the mipgen flags follow" in p.stderr
+    if torch.cuda.is_available():
+        return
+    p = subprocess.run([sys.executable, "-m", "mipgen_amd.mp_design", "--gpus", "1", "--", "-regions_to_scan", "x.bed"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"no CPU fallback" in p.stderr

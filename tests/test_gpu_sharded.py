@@ -174,3 +174,29 @@ def test_region_cost_weights_balance_the_svr_shards():
         ms.append(acc.last_kernel_ms(0))
         acc.close()
     assert abs(ms[0] - ms[1]) <= 0.10 * max(ms), ms
+
+
+@pytest.mark.parametrize("name", ["long_default", "logistic_snp_trf", "svr_two_size_runs", "practice62_config2_svr"])
+def test_one_process_per_rank_design_through_torch_distributed(name, tmp_path):
+    """The multi-process product path (mipgen_amd/mp_design.py): one process per rank, every rank scores its cost-model shard of the design's regions
+    on the accelerator, one torch.distributed gather of the condensed survivors, the sequential selection stage on rank 0 - and the picked / snp files
+    are the ones the real reference wrote.  Two ranks share the box's GPU and exchange through gloo here (`--backend gloo --share-gpus`: everything but
+    RCCL itself is the code of an 8-GPU run); run as a child process."""
+    import json
+    import subprocess
+    import sys
+    meta = H.load_design(name)
+    if len(meta["intervals"]) < 2:
+        pytest.skip("one region: nothing to shard")
+    work = str(tmp_path / "mp")
+    os.makedirs(work)
+    argv = H.prepare_cli_workdir(meta, work)
+    env = dict(os.environ, FAKEBWA_MODE=meta["bwa"], PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-m", "mipgen_amd.mp_design", "--gpus", "2", "--backend", "gloo", "--share-gpus", "--mipgen-path", argv[0], "--"] + argv[1:],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=work, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 2 and line["regions"] == len(meta["intervals"]) and len(line["shards"]) == 2
+    assert all(hi > lo for lo, hi in line["shards"]) and line["shards"][0][1] == line["shards"][1][0]          # both ranks hold a share, contiguous
+    assert line["picked"] == meta["lines"]["picked_mips"] - 1
+    H.compare_outputs(meta, work, keys=("picked_mips", "snp_mips"), check_all=False)
