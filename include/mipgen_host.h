@@ -58,6 +58,8 @@ const char* mipgen_design_model_path(const mipgen_design* d);                  /
 int32_t mipgen_design_region_count(const mipgen_design* d);
 /* Region i (after sort + merge) in the accelerator's input layout; the pointers stay valid until mipgen_design_close. */
 int mipgen_design_region(const mipgen_design* d, int32_t i, mipgen_region* out);
+/* regions first .. first + n - 1 at once (one call for a rank's whole shard) */
+int mipgen_design_regions(const mipgen_design* d, int32_t first, int32_t n, mipgen_region* out);
 /* region +/- 1000 bases for Featurev5::get_long_range_content (svr / mixed designs; empty otherwise) */
 int mipgen_design_long_range_seq(const mipgen_design* d, int32_t i, const char** seq, int32_t* len);
 int mipgen_design_set_long_range_content(mipgen_design* d, int32_t i, const double* lrc44);
@@ -83,6 +85,12 @@ int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* 
 int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors,
                                           int64_t emitted, const double* scores, const uint64_t* records, const uint8_t* emitted_mask,
                                           const int32_t* collapsed, int32_t n_bases, mipgen_rescore_fn rescore, void* ctx);
+/* The same for a run of regions of a SILENT logistic / svr design (no dense results, no re-score hook): regions first .. first + n - 1 with their grids,
+ * their survivors one after the other (2 * n_pos each) and their emitted counts - one call for a gathered batch (mipgen_amd/mp_design.py).  collapsed /
+ * n_bases: the accelerator's collapse_mips results of the regions one after the other (mipgen_accel_download_collapsed: 2 * n_bases[k] entries for region
+ * first + k) or both NULL (the host folds the survivors itself: ten times slower on exome-sized designs). */
+int mipgen_design_select_regions(mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors, const int64_t* emitted,
+                                 const int32_t* collapsed, const int32_t* n_bases);
 /* counters after the regions selected so far: all / collapsed / picked records written, gaps reported */
 int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps);
 

@@ -402,6 +402,14 @@ class Accel:
         self._regions = regions
         return self.grids
 
+    def upload_array(self, arr, n: int) -> List[Grid]:
+        """upload() for a ready-made ctypes array of Region (hostapi.Design.regions)."""
+        grids = (Grid * max(n, 1))()
+        self._check(self.lib.mipgen_accel_upload_regions(self.h, arr, n, grids))
+        self.grids = list(grids)[:n]
+        self._regions = arr
+        return self.grids
+
     def batch_candidates(self) -> int:
         return int(self.lib.mipgen_accel_batch_candidates(self.h))
 

@@ -228,10 +228,32 @@ int mipgen_design_set_long_range_content(mipgen_design* d, int32_t i, const doub
     return 0;
 }
 
+int mipgen_design_regions(const mipgen_design* d, int32_t first, int32_t n, mipgen_region* out)
+{
+    if (!d || n < 0 || first < 0 || first + n > (int32_t)d->regions.size() || (n > 0 && !out)) return fail(MIPGEN_HOST_E_USAGE, 0, "region range out of bounds");
+    for (int32_t k = 0; k < n; k++) if (int rc = mipgen_design_region(d, first + k, &out[k])) return rc;
+    return 0;
+}
+
 int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors, int64_t emitted,
                                 const double* scores, const uint64_t* records, const uint8_t* emitted_mask, mipgen_rescore_fn rescore, void* ctx)
 {
     return mipgen_design_select_region_collapsed(d, i, grid, survivors, emitted, scores, records, emitted_mask, nullptr, 0, rescore, ctx);
+}
+
+int mipgen_design_select_regions(mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors, const int64_t* emitted,
+                                 const int32_t* collapsed, const int32_t* n_bases)
+{
+    if (!d || n < 0 || (n > 0 && (!grids || !survivors || !emitted)) || ((collapsed != nullptr) != (n_bases != nullptr)))
+        return fail(MIPGEN_HOST_E_USAGE, 0, "bad arguments");
+    int64_t pos = 0, col = 0;
+    for (int32_t k = 0; k < n; k++) {                                  // silent designs: survivors only (2 per scan position, region after region)
+        if (int rc = mipgen_design_select_region_collapsed(d, first + k, &grids[k], survivors + 2 * pos, emitted[k], nullptr, nullptr, nullptr,
+                                                           collapsed ? collapsed + col : nullptr, collapsed ? n_bases[k] : 0, nullptr, nullptr)) return rc;
+        pos += grids[k].n_pos;
+        if (collapsed) col += 2 * (int64_t)n_bases[k];
+    }
+    return 0;
 }
 
 int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors, int64_t emitted,

@@ -18,12 +18,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmipgen_host.so")
 
 RESCORE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32, C.POINTER(capi.Candidate))
+# numpy image of capi.Grid (mipgen_grid)
+GRID_DTYPE = np.dtype([(name, np.int64 if ct is C.c_int64 else np.int32) for name, ct in capi.Grid._fields_], align=True)
+assert GRID_DTYPE.itemsize == C.sizeof(capi.Grid)
 
 EXPORTED_SYMBOLS = [
     "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
-    "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region",
+    "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region", "mipgen_design_regions",
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
-    "mipgen_design_select_region_collapsed", "mipgen_design_counters", "mipgen_design_region_weights",
+    "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_counters", "mipgen_design_region_weights",
     "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
 ]
 
@@ -53,6 +56,7 @@ def load_library():
     lib.mipgen_design_model_path.restype = C.c_char_p
     lib.mipgen_design_region_count.argtypes = [vp]
     lib.mipgen_design_region.argtypes = [vp, C.c_int32, C.POINTER(capi.Region)]
+    lib.mipgen_design_regions.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.Region)]
     lib.mipgen_design_long_range_seq.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     lib.mipgen_design_set_long_range_content.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     lib.mipgen_design_select_region.argtypes = [vp, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.c_int64, C.POINTER(C.c_double),
@@ -61,6 +65,8 @@ def load_library():
                                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int32, RESCORE_FN, vp]
     lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.mipgen_design_region_weights.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
+    lib.mipgen_design_select_regions.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.POINTER(C.c_int64),
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_devices.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_window_candidates.argtypes = [vp, C.c_int64]
@@ -117,6 +123,12 @@ class Design:
         self._check(self.lib.mipgen_design_region(self.h, i, C.byref(r)))
         return r
 
+    def regions(self, first: int, n: int):
+        """The C views of regions first .. first + n - 1 as one ctypes array (what mipgen_accel_upload_regions takes)."""
+        arr = (capi.Region * max(n, 1))()
+        self._check(self.lib.mipgen_design_regions(self.h, first, n, arr))
+        return arr
+
     def long_range_seq(self, i: int) -> bytes:
         s, n = C.c_char_p(), C.c_int32()
         self._check(self.lib.mipgen_design_long_range_seq(self.h, i, C.byref(s), C.byref(n)))
@@ -142,6 +154,29 @@ class Design:
             self._check(self.lib.mipgen_design_select_region_collapsed(*args, collapsed.ctypes.data_as(C.POINTER(C.c_int32)), collapsed.shape[0] // 2, fn, None))
         else:
             self._check(self.lib.mipgen_design_select_region(*args, fn, None))
+
+    def select_regions(self, first: int, grids: np.ndarray, survivors: np.ndarray, emitted: np.ndarray, collapsed: Optional[np.ndarray] = None,
+                       n_bases: Optional[np.ndarray] = None) -> None:
+        """Selection stage for a run of regions of a silent logistic / svr design in one call: `grids` an int64 array [n][6] (offset, count, first_pos,
+        n_pos, first_size_index, n_sizes per region), `survivors` the regions' survivors one after the other, `emitted` their emitted counts;
+        `collapsed` / `n_bases`: the accelerator's collapse results of the regions (capi.Accel.download_collapsed) and their bases per region."""
+        survivors = np.ascontiguousarray(survivors)
+        emitted = np.ascontiguousarray(emitted, dtype=np.int64)
+        g6 = np.ascontiguousarray(grids, dtype=np.int64).reshape(-1, 6)
+        n = g6.shape[0]
+        assert survivors.dtype == capi.SURVIVOR_DTYPE and emitted.shape[0] == n and survivors.shape[0] == 2 * int(g6[:, 3].sum())
+        garr = np.zeros(n, dtype=GRID_DTYPE)
+        for k, f in enumerate(("offset", "count", "first_pos", "n_pos", "first_size_index", "n_sizes")):
+            garr[f] = g6[:, k]
+        i32p = C.POINTER(C.c_int32)
+        cp = nbp = None
+        if collapsed is not None:
+            collapsed = np.ascontiguousarray(collapsed, dtype=np.int32)
+            n_bases = np.ascontiguousarray(n_bases, dtype=np.int32)
+            assert n_bases.shape[0] == n and collapsed.shape[0] == 2 * int(n_bases.astype(np.int64).sum())
+            cp, nbp = collapsed.ctypes.data_as(i32p), n_bases.ctypes.data_as(i32p)
+        self._check(self.lib.mipgen_design_select_regions(self.h, first, n, garr.ctypes.data_as(C.POINTER(capi.Grid)),
+                                                          survivors.ctypes.data_as(C.POINTER(capi.Survivor)), emitted.ctypes.data_as(C.POINTER(C.c_int64)), cp, nbp))
 
     def region_weights(self) -> np.ndarray:
         """Relative device time per region: the weights of the device shards (mipgen_design_run's own rule)."""

@@ -8,7 +8,8 @@ sequentially in region order (the rand() stream and the used-arm sets persist ac
   every rank   opens the design (options + input stage of libmipgen_host.so; ranks > 0 write their copies of the input-stage files into a
                scratch directory), takes its contiguous shard of the regions - balanced with the weights the in-process driver uses
                (mipgen_design_region_weights) -, scores + replays + condenses it on ITS GPU (libmipgen_accel.so) and
-  one exchange gathers the condensed survivors (2 per scan position, 24 bytes each), the per-region emitted counts and grids to rank 0, which
+  one exchange gathers the condensed survivors (2 per scan position, 24 bytes each), the collapse results (2 per base), the per-region emitted
+               counts and grids to rank 0, which
   rank 0       runs the selection stage region by region (mipgen_design_select_region) and writes the design's files.
 
 Silent logistic / svr designs (`-silent_mode on` is added when absent); mixed designs and the all_mips text stay with the in-process multi-GPU
@@ -61,14 +62,6 @@ def _all_ranks_ok(dist, torch, xdev, ok: bool) -> bool:
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=xdev if xdev else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(int(t.item()))
-
-
-class _View:
-    """A region of the design in the C layout (pointers into libmipgen_host's arrays), as capi.Accel.upload takes it."""
-
-    def __init__(self, c):
-        self.c = c
-        self.alleles = None
 
 
 def main(argv: List[str]) -> int:
@@ -135,18 +128,22 @@ def main(argv: List[str]) -> int:
             acc.load_model_file(d.model_path)
             acc.set_dynamic_skip(True)                                     # mipgen.cpp:430 between the capture-size runs, as the front end does
             if hi > lo:                                                    # long-range content of the shard's regions, on the device
-                views0 = [d.region(i) for i in range(lo, hi)]
-                lrc = acc.long_range_content_batch([d.long_range_seq(i) for i in range(lo, hi)], [v.seq_start for v in views0], [v.seq_stop for v in views0])
+                views0 = d.regions(lo, hi - lo)
+                lrc = acc.long_range_content_batch([d.long_range_seq(i) for i in range(lo, hi)], [views0[k].seq_start for k in range(hi - lo)],
+                                                   [views0[k].seq_stop for k in range(hi - lo)])
                 for k, i in enumerate(range(lo, hi)):
                     d.set_long_range_content(i, lrc[k])
-        views = [_View(d.region(i)) for i in range(lo, hi)]
-        if views:
-            grids = acc.upload(views)
-            acc.score_condense_all(scan)
+        if hi > lo:
+            grids = acc.upload_array(d.regions(lo, hi - lo), hi - lo)       # the shard's regions in the C layout, straight from libmipgen_host's arrays
+            acc.score_condense_all(scan)                                    # score + replay + condense + collapse of every result window
             emitted, surv = acc.download_survivors()
+            col = acc.download_collapsed(-1)                                # collapse_mips of the shard: 2 entries per base, region after region
+            nbase = np.array([acc.region_bases(k)[1] for k in range(hi - lo)], dtype=np.int32)
         else:
             grids, emitted, surv = [], np.zeros(0, dtype=np.int64), np.zeros(0, dtype=capi.SURVIVOR_DTYPE)
-        garr = np.array([[g.offset, g.count, g.first_pos, g.n_pos, g.first_size_index, g.n_sizes] for g in grids], dtype=np.int64).reshape(-1)
+            col, nbase = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+        garr = np.frombuffer(bytes((capi.Grid * len(grids))(*grids)), dtype=hostapi.GRID_DTYPE) if grids else np.zeros(0, dtype=hostapi.GRID_DTYPE)
+        garr = np.stack([garr[f].astype(np.int64) for f in ("offset", "count", "first_pos", "n_pos", "first_size_index", "n_sizes")], axis=1).reshape(-1) if grids else np.zeros(0, dtype=np.int64)
         t_scored = time.perf_counter()
         if distributed and not _all_ranks_ok(dist, torch, xdev, True):
             raise SystemExit(1)
@@ -155,19 +152,17 @@ def main(argv: List[str]) -> int:
             all_surv = mdist.gather_to_rank0(surv, xdev)
             all_emitted = mdist.gather_to_rank0(emitted, xdev)
             all_grids = mdist.gather_to_rank0(garr, xdev)
+            all_col = mdist.gather_to_rank0(col, xdev)
+            all_nbase = mdist.gather_to_rank0(nbase, xdev)
         else:
-            all_surv, all_emitted, all_grids = surv, emitted, garr
+            all_surv, all_emitted, all_grids, all_col, all_nbase = surv, emitted, garr, col, nbase
         t_gathered = time.perf_counter()
         acc.close()
         if rank == 0:
             all_grids = all_grids.reshape(-1, 6)
             assert all_grids.shape[0] == n and all_emitted.shape[0] == n, "the gather lost regions"
-            pos = 0
-            for i in range(n):
-                g = capi.Grid()
-                g.offset, g.count, g.first_pos, g.n_pos, g.first_size_index, g.n_sizes = (int(x) for x in all_grids[i])
-                d.select_region(i, g, all_surv[2 * pos:2 * (pos + g.n_pos)], int(all_emitted[i]))
-                pos += g.n_pos
+            # the sequential selection stage over all regions, in one call (a per-region Python loop costs 90 us per region: 18 s for 200,000)
+            d.select_regions(0, all_grids, all_surv, all_emitted, all_col, all_nbase)
             c = d.counters()
             t_end = time.perf_counter()
             print(json.dumps({"regions": n, "ranks": world, "backend": args.backend if distributed else None, "shards": shards,
