@@ -231,7 +231,17 @@ int mipgen_design_set_long_range_content(mipgen_design* d, int32_t i, const doub
 int mipgen_design_regions(const mipgen_design* d, int32_t first, int32_t n, mipgen_region* out)
 {
     if (!d || n < 0 || first < 0 || first + n > (int32_t)d->regions.size() || (n > 0 && !out)) return fail(MIPGEN_HOST_E_USAGE, 0, "region range out of bounds");
-    for (int32_t k = 0; k < n; k++) if (int rc = mipgen_design_region(d, first + k, &out[k])) return rc;
+    if (d->copies_deferred && n > 0) {                                 // -gpu_copy_counter: host tables for THIS range only (a rank's shard), counted on the accelerator
+        mipgen_design* md = const_cast<mipgen_design*>(d);
+        std::lock_guard<std::mutex> lock(md->copies_mu);
+        bool ready = true;
+        for (int32_t k = 0; k < n; k++) ready = ready && md->regions[(size_t)(first + k)].copy_ready;
+        if (!ready) {
+            try { gpu_copy_numbers(md->o, md->genome, md->regions, first, first + n); } catch (int e) { return fail(MIPGEN_HOST_E_ACCEL, e, std::string("accelerator: ") + mipgen_accel_last_error()); }
+            for (int32_t k = 0; k < n; k++) { Region& r = md->regions[(size_t)(first + k)]; r.copy_deferred = false; attach_copy_tables(md->o, r); }
+        }
+    }
+    for (int32_t k = 0; k < n; k++) { const Region& r = d->regions[(size_t)(first + k)]; if (d->copies_deferred && !r.copy_ready) return fail(MIPGEN_HOST_E_USAGE, 0, "internal: copy tables"); fill_accel_region(r, out[k]); }
     return 0;
 }
 

@@ -525,26 +525,29 @@ void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::
 }
 
 // the counts as host tables (Region::copy_flat): for callers that score through their own accelerator handle
-void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs)
+void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1)
 {
+    if (r1 < 0) r1 = (int)regs.size();                                // (the default: every region)
+    if (r1 <= r0) return;
     std::vector<const char*> cs; std::vector<int64_t> cl;
     for (const std::string& c : chroms) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
     std::vector<int32_t> lengths(o.oligo_sizes.begin(), o.oligo_sizes.end());
     std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<int32_t*> outp;
-    for (size_t i = 0; i < regs.size(); i++) {
-        rs.push_back(regs[i].seq.data()); rl.push_back((int32_t)regs[i].seq.size());
-        regs[i].copy_flat.assign(lengths.size() * regs[i].seq.size(), 0);
-        outp.push_back(regs[i].copy_flat.data());
+    for (int i = r0; i < r1; i++) {
+        Region& r = regs[(size_t)i];
+        rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size());
+        r.copy_flat.assign(lengths.size() * r.seq.size(), 0);
+        outp.push_back(r.copy_flat.data());
     }
     mipgen_params ap = o.accel_params();
     mipgen_accel* h = nullptr;
     if (mipgen_accel_create(&ap, 0, nullptr, &h)) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; throw 17; }
-    const int rc = mipgen_accel_count_oligo_copies(h, (int32_t)cs.size(), cs.data(), cl.data(), (int32_t)regs.size(), rs.data(), rl.data(),
+    const int rc = mipgen_accel_count_oligo_copies(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(),
                                                    (int32_t)lengths.size(), lengths.data(), outp.data());
     if (rc) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; mipgen_accel_destroy(h); throw 11; }
-    try { gpu_window_flags(o, h, chroms, regs, 0, (int)regs.size()); } catch (...) { mipgen_accel_destroy(h); throw; }
+    try { gpu_window_flags(o, h, chroms, regs, r0, r1); } catch (...) { mipgen_accel_destroy(h); throw; }
     mipgen_accel_destroy(h);
-    for (Region& r : regs) r.copy_ready = true;
+    for (int i = r0; i < r1; i++) regs[(size_t)i].copy_ready = true;
 }
 
 void fill_accel_region(const Region& r, mipgen_region& out, bool resident_copies)

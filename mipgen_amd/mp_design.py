@@ -162,6 +162,11 @@ def main(argv: List[str]) -> int:
             all_grids = all_grids.reshape(-1, 6)
             assert all_grids.shape[0] == n and all_emitted.shape[0] == n, "the gather lost regions"
             # the sequential selection stage over all regions, in one call (a per-region Python loop costs 90 us per region: 18 s for 200,000)
+            # -gpu_copy_counter on: where a survivor's 16-bit copy field saturates the selection looks the true count up in the host tables - then (and
+            # only then) rank 0 builds them for every region; the ranks otherwise only ever build their own shard's
+            rec = all_surv["record"]
+            if bool((((capi.rec_ext_copy(rec) == 65535) | (capi.rec_lig_copy(rec) == 65535)) & (all_surv["cand_index"] >= 0)).any()):
+                d.regions(0, n)
             d.select_regions(0, all_grids, all_surv, all_emitted, all_col, all_nbase)
             c = d.counters()
             t_end = time.perf_counter()
