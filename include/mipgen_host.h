@@ -85,12 +85,18 @@ int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* 
 int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mipgen_grid* grid, const mipgen_survivor* survivors,
                                           int64_t emitted, const double* scores, const uint64_t* records, const uint8_t* emitted_mask,
                                           const int32_t* collapsed, int32_t n_bases, mipgen_rescore_fn rescore, void* ctx);
-/* The same for a run of regions of a SILENT logistic / svr design (no dense results, no re-score hook): regions first .. first + n - 1 with their grids,
- * their survivors one after the other (2 * n_pos each) and their emitted counts - one call for a gathered batch (mipgen_amd/mp_design.py).  collapsed /
- * n_bases: the accelerator's collapse_mips results of the regions one after the other (mipgen_accel_download_collapsed: 2 * n_bases[k] entries for region
- * first + k) or both NULL (the host folds the survivors itself: ten times slower on exome-sized designs). */
+/* The same for a run of regions of a SILENT design (no dense results): regions first .. first + n - 1 with their grids, their survivors one after the
+ * other (2 * n_pos each) and their emitted counts - one call for a gathered batch (mipgen_amd/mp_design.py).  collapsed / n_bases: the accelerator's
+ * collapse_mips results of the regions one after the other (mipgen_accel_download_collapsed: 2 * n_bases[k] entries for region first + k) or both NULL (the
+ * host folds the survivors itself: ten times slower on exome-sized designs).  svr: mixed designs - the SVR score of every survivor, parallel to
+ * `survivors` (what mipgen.cpp:1523-1527,1873-1877 re-score on demand); NULL otherwise. */
 int mipgen_design_select_regions(mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors, const int64_t* emitted,
-                                 const int32_t* collapsed, const int32_t* n_bases);
+                                 const int32_t* collapsed, const int32_t* n_bases, const double* svr);
+/* Mixed designs: the survivors of regions first .. first + n - 1 (grids / survivors as above) as candidates for mipgen_accel_score_candidates on a handle
+ * whose resident batch is exactly these regions (candidate.region = 0 .. n - 1), and where[j] = the survivor slot candidate j came from.
+ * capacity 0: only *count is set. */
+int mipgen_design_survivor_candidates(const mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors,
+                                      mipgen_candidate* cands, int64_t* where, int64_t capacity, int64_t* count);
 /* counters after the regions selected so far: all / collapsed / picked records written, gaps reported */
 int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps);
 

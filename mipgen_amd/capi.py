@@ -638,6 +638,13 @@ class Accel:
             ints if ints is not None else None))
         return scores, records, feats, ints
 
+    def score_candidate_array(self, arr, n: int, method: int) -> np.ndarray:
+        """score_candidates() for a ready-made ctypes array of Candidate: scores only."""
+        scores = np.empty(max(n, 1), dtype=np.float64)
+        if n:
+            self._check(self.lib.mipgen_accel_score_candidates(self.h, arr, n, method, scores.ctypes.data_as(C.POINTER(C.c_double)), None, None, None))
+        return scores[:n]
+
     def long_range_content_batch(self, seqs: Sequence[bytes], starts: Sequence[int], stops: Sequence[int]) -> np.ndarray:
         n = len(seqs)
         out = np.empty((n, N_LRC), dtype=np.float64)

@@ -251,15 +251,62 @@ int mipgen_design_select_region(mipgen_design* d, int32_t i, const mipgen_grid* 
     return mipgen_design_select_region_collapsed(d, i, grid, survivors, emitted, scores, records, emitted_mask, nullptr, 0, rescore, ctx);
 }
 
+namespace {
+struct ArrayRescorer {                           // mixed designs through mipgen_design_select_regions: the SVR score of every survivor, parallel to the survivors
+    const double* svr = nullptr;
+    const mipgen_survivor* surv = nullptr;
+    int64_t pos0 = 0;
+    const mipgen_grid* g = nullptr;
+    static double fn(void* ctx, int32_t, const mipgen_candidate* c)
+    {
+        auto* self = (ArrayRescorer*)ctx;
+        const int64_t k = 2 * (self->pos0 + (c->scan_start - self->g->first_pos)) + c->strand;
+        if (c->scan_start < self->g->first_pos || c->scan_start >= self->g->first_pos + self->g->n_pos || self->surv[k].cand_index < 0) {
+            std::cerr << "[mipgen] re-score of a candidate that did not survive condense" << std::endl;
+            throw 20;
+        }
+        return self->svr[k];
+    }
+};
+}  // namespace
+
+int mipgen_design_survivor_candidates(const mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors,
+                                      mipgen_candidate* cands, int64_t* where, int64_t capacity, int64_t* count)
+{
+    if (!d || !count || n < 0 || first < 0 || first + n > (int32_t)d->regions.size() || (n > 0 && (!grids || !survivors)) || (capacity > 0 && (!cands || !where)))
+        return fail(MIPGEN_HOST_E_USAGE, 0, "bad arguments");
+    const Options& o = d->o;
+    int64_t m = 0, q0 = 0;
+    for (int32_t bi = 0; bi < n; bi++) {
+        const mipgen_grid& g = grids[bi];
+        for (int64_t q = 2 * q0; q < 2 * (q0 + g.n_pos); q++) {
+            const mipgen_survivor& sv = survivors[q];
+            if (sv.cand_index < 0) continue;
+            if (m < capacity) {
+                const Cand c = make_cand(o, d->regions[(size_t)(first + bi)], g, sv.cand_index - g.offset, sv.score, sv.record);
+                cands[m] = mipgen_candidate{bi, c.scan_start, c.capture, c.ext_len, c.lig_len, c.strand};
+                where[m] = q;
+            }
+            m++;
+        }
+        q0 += g.n_pos;
+    }
+    *count = m;
+    return m > capacity && capacity > 0 ? fail(MIPGEN_HOST_E_USAGE, 0, "candidate capacity too small") : 0;
+}
+
 int mipgen_design_select_regions(mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors, const int64_t* emitted,
-                                 const int32_t* collapsed, const int32_t* n_bases)
+                                 const int32_t* collapsed, const int32_t* n_bases, const double* svr)
 {
     if (!d || n < 0 || (n > 0 && (!grids || !survivors || !emitted)) || ((collapsed != nullptr) != (n_bases != nullptr)))
         return fail(MIPGEN_HOST_E_USAGE, 0, "bad arguments");
+    if (d->o.score_method == MIPGEN_SCORE_MIXED && !svr) return fail(MIPGEN_HOST_E_USAGE, 0, "a mixed design needs the SVR scores of its survivors");
     int64_t pos = 0, col = 0;
     for (int32_t k = 0; k < n; k++) {                                  // silent designs: survivors only (2 per scan position, region after region)
+        ArrayRescorer rs;
+        rs.svr = svr; rs.surv = survivors; rs.pos0 = pos; rs.g = &grids[k];
         if (int rc = mipgen_design_select_region_collapsed(d, first + k, &grids[k], survivors + 2 * pos, emitted[k], nullptr, nullptr, nullptr,
-                                                           collapsed ? collapsed + col : nullptr, collapsed ? n_bases[k] : 0, nullptr, nullptr)) return rc;
+                                                           collapsed ? collapsed + col : nullptr, collapsed ? n_bases[k] : 0, svr ? &ArrayRescorer::fn : nullptr, svr ? &rs : nullptr)) return rc;
         pos += grids[k].n_pos;
         if (collapsed) col += 2 * (int64_t)n_bases[k];
     }

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
     "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region", "mipgen_design_regions",
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
-    "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_counters", "mipgen_design_region_weights",
+    "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_survivor_candidates", "mipgen_design_counters", "mipgen_design_region_weights",
     "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
 ]
 
@@ -66,7 +66,9 @@ def load_library():
     lib.mipgen_design_counters.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.mipgen_design_region_weights.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
     lib.mipgen_design_select_regions.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.POINTER(C.c_int64),
-                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    lib.mipgen_design_survivor_candidates.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.POINTER(capi.Candidate),
+                                                      C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_devices.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_window_candidates.argtypes = [vp, C.c_int64]
@@ -155,28 +157,53 @@ class Design:
         else:
             self._check(self.lib.mipgen_design_select_region(*args, fn, None))
 
-    def select_regions(self, first: int, grids: np.ndarray, survivors: np.ndarray, emitted: np.ndarray, collapsed: Optional[np.ndarray] = None,
-                       n_bases: Optional[np.ndarray] = None) -> None:
-        """Selection stage for a run of regions of a silent logistic / svr design in one call: `grids` an int64 array [n][6] (offset, count, first_pos,
-        n_pos, first_size_index, n_sizes per region), `survivors` the regions' survivors one after the other, `emitted` their emitted counts;
-        `collapsed` / `n_bases`: the accelerator's collapse results of the regions (capi.Accel.download_collapsed) and their bases per region."""
-        survivors = np.ascontiguousarray(survivors)
-        emitted = np.ascontiguousarray(emitted, dtype=np.int64)
+    @staticmethod
+    def _grid_array(grids: np.ndarray) -> np.ndarray:
         g6 = np.ascontiguousarray(grids, dtype=np.int64).reshape(-1, 6)
-        n = g6.shape[0]
-        assert survivors.dtype == capi.SURVIVOR_DTYPE and emitted.shape[0] == n and survivors.shape[0] == 2 * int(g6[:, 3].sum())
-        garr = np.zeros(n, dtype=GRID_DTYPE)
+        garr = np.zeros(g6.shape[0], dtype=GRID_DTYPE)
         for k, f in enumerate(("offset", "count", "first_pos", "n_pos", "first_size_index", "n_sizes")):
             garr[f] = g6[:, k]
+        return garr
+
+    def select_regions(self, first: int, grids: np.ndarray, survivors: np.ndarray, emitted: np.ndarray, collapsed: Optional[np.ndarray] = None,
+                       n_bases: Optional[np.ndarray] = None, svr: Optional[np.ndarray] = None) -> None:
+        """Selection stage for a run of regions of a silent design in one call: `grids` an int64 array [n][6] (offset, count, first_pos, n_pos,
+        first_size_index, n_sizes per region), `survivors` the regions' survivors one after the other, `emitted` their emitted counts; `collapsed` /
+        `n_bases`: the accelerator's collapse results of the regions (capi.Accel.download_collapsed) and their bases per region; `svr` (mixed designs):
+        the SVR score of every survivor, parallel to `survivors`."""
+        survivors = np.ascontiguousarray(survivors)
+        emitted = np.ascontiguousarray(emitted, dtype=np.int64)
+        garr = self._grid_array(grids)
+        n = garr.shape[0]
+        assert survivors.dtype == capi.SURVIVOR_DTYPE and emitted.shape[0] == n and survivors.shape[0] == 2 * int(garr["n_pos"].astype(np.int64).sum())
         i32p = C.POINTER(C.c_int32)
-        cp = nbp = None
+        cp = nbp = sp = None
         if collapsed is not None:
             collapsed = np.ascontiguousarray(collapsed, dtype=np.int32)
             n_bases = np.ascontiguousarray(n_bases, dtype=np.int32)
             assert n_bases.shape[0] == n and collapsed.shape[0] == 2 * int(n_bases.astype(np.int64).sum())
             cp, nbp = collapsed.ctypes.data_as(i32p), n_bases.ctypes.data_as(i32p)
+        if svr is not None:
+            svr = np.ascontiguousarray(svr, dtype=np.float64)
+            assert svr.shape[0] == survivors.shape[0]
+            sp = svr.ctypes.data_as(C.POINTER(C.c_double))
         self._check(self.lib.mipgen_design_select_regions(self.h, first, n, garr.ctypes.data_as(C.POINTER(capi.Grid)),
-                                                          survivors.ctypes.data_as(C.POINTER(capi.Survivor)), emitted.ctypes.data_as(C.POINTER(C.c_int64)), cp, nbp))
+                                                          survivors.ctypes.data_as(C.POINTER(capi.Survivor)), emitted.ctypes.data_as(C.POINTER(C.c_int64)), cp, nbp, sp))
+
+    def survivor_candidates(self, first: int, grids: np.ndarray, survivors: np.ndarray):
+        """Mixed designs: the survivors of regions first .. as a ctypes array of capi.Candidate (region = index inside the run) for an SVR re-score on
+        the handle that holds exactly these regions, and the survivor slot of every candidate."""
+        survivors = np.ascontiguousarray(survivors)
+        garr = self._grid_array(grids)
+        n = garr.shape[0]
+        m = int((survivors["cand_index"] >= 0).sum())
+        cands = (capi.Candidate * max(m, 1))()
+        where = np.zeros(max(m, 1), dtype=np.int64)
+        cnt = C.c_int64()
+        self._check(self.lib.mipgen_design_survivor_candidates(self.h, first, n, garr.ctypes.data_as(C.POINTER(capi.Grid)), survivors.ctypes.data_as(C.POINTER(capi.Survivor)),
+                                                               cands, where.ctypes.data_as(C.POINTER(C.c_int64)), m, C.byref(cnt)))
+        assert cnt.value == m
+        return cands, where[:m], m
 
     def region_weights(self) -> np.ndarray:
         """Relative device time per region: the weights of the device shards (mipgen_design_run's own rule)."""

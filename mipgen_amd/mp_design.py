@@ -12,8 +12,8 @@ sequentially in region order (the rand() stream and the used-arm sets persist ac
                counts and grids to rank 0, which
   rank 0       runs the selection stage region by region (mipgen_design_select_region) and writes the design's files.
 
-Silent logistic / svr designs (`-silent_mode on` is added when absent); mixed designs and the all_mips text stay with the in-process multi-GPU
-driver (`mipgen -gpus N`).  `--backend gloo --share-gpus` runs the same code on a one-GPU box (tests).  The product has no CPU path: without
+Silent designs of every score method (`-silent_mode on` is added when absent; mixed designs re-score their condensed survivors with the SVR on the
+rank that holds the region, before the gather); the all_mips text of non-silent designs stays with the in-process multi-GPU driver (`mipgen -gpus N`).  `--backend gloo --share-gpus` runs the same code on a one-GPU box (tests).  The product has no CPU path: without
 a HIP device this fails."""
 from __future__ import annotations
 
@@ -115,8 +115,6 @@ def main(argv: List[str]) -> int:
     d = None
     try:
         d = hostapi.Design([args.mipgen_path] + flags)
-        if d.score_method == capi.SCORE_MIXED:
-            raise SystemExit("mp_design: mixed designs re-score survivors on the accelerator that holds their region - use the in-process driver (mipgen -gpus N)")
         P = d.params()
         n = d.region_count()
         scan = capi.SCORE_SVR if d.score_method == capi.SCORE_SVR else capi.SCORE_LOGISTIC
@@ -124,9 +122,11 @@ def main(argv: List[str]) -> int:
         lo, hi = shards[rank]
         t_inputs = time.perf_counter()
         acc = capi.Accel(P, device=local_rank)
-        if scan == capi.SCORE_SVR:
+        mixed = d.score_method == capi.SCORE_MIXED
+        if scan == capi.SCORE_SVR or mixed:
             acc.load_model_file(d.model_path)
-            acc.set_dynamic_skip(True)                                     # mipgen.cpp:430 between the capture-size runs, as the front end does
+            if scan == capi.SCORE_SVR:
+                acc.set_dynamic_skip(True)                                 # mipgen.cpp:430 between the capture-size runs, as the front end does
             if hi > lo:                                                    # long-range content of the shard's regions, on the device
                 views0 = d.regions(lo, hi - lo)
                 lrc = acc.long_range_content_batch([d.long_range_seq(i) for i in range(lo, hi)], [views0[k].seq_start for k in range(hi - lo)],
@@ -142,8 +142,16 @@ def main(argv: List[str]) -> int:
         else:
             grids, emitted, surv = [], np.zeros(0, dtype=np.int64), np.zeros(0, dtype=capi.SURVIVOR_DTYPE)
             col, nbase = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+        svr = np.zeros(0, dtype=np.float64)
         garr = np.frombuffer(bytes((capi.Grid * len(grids))(*grids)), dtype=hostapi.GRID_DTYPE) if grids else np.zeros(0, dtype=hostapi.GRID_DTYPE)
         garr = np.stack([garr[f].astype(np.int64) for f in ("offset", "count", "first_pos", "n_pos", "first_size_index", "n_sizes")], axis=1).reshape(-1) if grids else np.zeros(0, dtype=np.int64)
+        if mixed:
+            # mixed designs: every condensed survivor of the shard through the SVR as ONE list on the handle that holds its region (the pick stage
+            # re-scores a subset of them, mipgen.cpp:1523-1527,1873-1877): features per candidate, then the FP64 matrix cores (k_svr_gemm)
+            svr = np.full(surv.shape[0], np.nan)
+            if hi > lo:
+                cands, where, m = d.survivor_candidates(lo, garr, surv)
+                svr[where] = acc.score_candidate_array(cands, m, capi.SCORE_SVR)
         t_scored = time.perf_counter()
         if distributed and not _all_ranks_ok(dist, torch, xdev, True):
             raise SystemExit(1)
@@ -154,8 +162,9 @@ def main(argv: List[str]) -> int:
             all_grids = mdist.gather_to_rank0(garr, xdev)
             all_col = mdist.gather_to_rank0(col, xdev)
             all_nbase = mdist.gather_to_rank0(nbase, xdev)
+            all_svr = mdist.gather_to_rank0(svr, xdev) if mixed else None
         else:
-            all_surv, all_emitted, all_grids, all_col, all_nbase = surv, emitted, garr, col, nbase
+            all_surv, all_emitted, all_grids, all_col, all_nbase, all_svr = surv, emitted, garr, col, nbase, (svr if mixed else None)
         t_gathered = time.perf_counter()
         acc.close()
         if rank == 0:
@@ -167,7 +176,7 @@ def main(argv: List[str]) -> int:
             rec = all_surv["record"]
             if bool((((capi.rec_ext_copy(rec) == 65535) | (capi.rec_lig_copy(rec) == 65535)) & (all_surv["cand_index"] >= 0)).any()):
                 d.regions(0, n)
-            d.select_regions(0, all_grids, all_surv, all_emitted, all_col, all_nbase)
+            d.select_regions(0, all_grids, all_surv, all_emitted, all_col, all_nbase, all_svr)
             c = d.counters()
             t_end = time.perf_counter()
             print(json.dumps({"regions": n, "ranks": world, "backend": args.backend if distributed else None, "shards": shards,

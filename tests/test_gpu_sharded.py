@@ -176,7 +176,7 @@ def test_region_cost_weights_balance_the_svr_shards():
     assert abs(ms[0] - ms[1]) <= 0.10 * max(ms), ms
 
 
-@pytest.mark.parametrize("name", ["long_default", "logistic_snp_trf", "svr_two_size_runs", "practice62_config2_svr"])
+@pytest.mark.parametrize("name", ["long_default", "logistic_snp_trf", "svr_two_size_runs", "practice62_config2_svr", "mixed_12_regions", "mixed_small"])
 def test_one_process_per_rank_design_through_torch_distributed(name, tmp_path):
     """The multi-process product path (mipgen_amd/mp_design.py): one process per rank, every rank scores its cost-model shard of the design's regions
     on the accelerator, one torch.distributed gather of the condensed survivors, the sequential selection stage on rank 0 - and the picked / snp files
