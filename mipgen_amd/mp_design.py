@@ -113,6 +113,7 @@ def main(argv: List[str]) -> int:
             flags += ["-project_name", os.path.join(scratch, name)]
     rc = 0
     d = None
+    reported = False                                                       # this rank has taken part in the "shard scored" exchange
     try:
         d = hostapi.Design([args.mipgen_path] + flags)
         P = d.params()
@@ -153,8 +154,10 @@ def main(argv: List[str]) -> int:
                 cands, where, m = d.survivor_candidates(lo, garr, surv)
                 svr[where] = acc.score_candidate_array(cands, m, capi.SCORE_SVR)
         t_scored = time.perf_counter()
-        if distributed and not _all_ranks_ok(dist, torch, xdev, True):
-            raise SystemExit(1)
+        if distributed:
+            reported = True
+            if not _all_ranks_ok(dist, torch, xdev, True):
+                raise SystemExit(1)
         if distributed:
             # the one exchange step of the path: condensed survivors (+ the per-region counts and grids) -> rank 0
             all_surv = mdist.gather_to_rank0(surv, xdev)
@@ -186,7 +189,7 @@ def main(argv: List[str]) -> int:
     except (hostapi.HostError, capi.AccelError) as e:
         print(f"[mp_design] rank {rank}: {e}", file=sys.stderr)
         rc = 1
-        if distributed:
+        if distributed and not reported:
             _all_ranks_ok(dist, torch, xdev, False)                          # the other ranks learn of it instead of waiting in the gather
     finally:
         if d is not None:
