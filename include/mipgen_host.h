@@ -111,7 +111,7 @@ int mipgen_design_region_weights(const mipgen_design* d, int64_t* weights, int32
  * thread consumes the windows in region order through mipgen_design_select_region.  n_devices <= 0: mipgen_design_set_devices / the
  * command line's -gpus, else every visible HIP device.  Devices beyond the visible count wrap around (two handles on one GPU: a functional
  * test of the sharding).  Non-silent designs receive their all_mips records as text formatted on the device, with any number of workers
- * (records are numbered design-wide: each worker first counts what it emits, mipgen.cpp:474,488,792).
+ * (records are numbered design-wide, mipgen.cpp:474,488,792: a worker numbers from 0, the consumer shifts the numbers by what the workers before it wrote).
  */
 int mipgen_design_run(mipgen_design* d, int32_t n_devices);
 /* Front-end knobs (the library reads no environment variables): device workers of mipgen_design_run (0 = every visible device; option -gpus),

@@ -419,40 +419,26 @@ struct WindowResult {
     std::vector<double> scores;
     std::vector<uint64_t> records;
     std::vector<uint8_t> mask;
-    std::vector<char> text;                      // the window's all_mips records, formatted on the device (single-worker runs)
+    std::vector<char> text;                      // the window's all_mips records, formatted on the device, numbered from the worker's own first record
+    int64_t n_rec = 0;                           // how far they advance the design-wide all_mip_counter
     bool has_text = false;
     bool last = false;
     int error = 0;
     std::string msg;
 };
 
-// all_mips records are numbered design-wide in generation order (mipgen.cpp:474,488,792): with several device workers a worker learns the
-// number of its first record from the emitted totals of the workers before it
+// the first failure of a run, shared by the device workers (a worker that only learns of the abort reports this one)
 struct RecordOrder {
     std::mutex m;
-    std::condition_variable cv;
-    std::vector<int64_t> total;                  // records worker k emits (valid once done[k])
-    std::vector<char> done;
     bool abort = false;
-    int err_code = 0;                            // the first failure that stopped the run (a worker that only learns of the abort reports this one)
+    int err_code = 0;
     std::string err_msg;
-    explicit RecordOrder(int n) : total((size_t)n, 0), done((size_t)n, 0) {}
-    void publish(int k, int64_t n) { std::lock_guard<std::mutex> lk(m); total[(size_t)k] = n; done[(size_t)k] = 1; cv.notify_all(); }
-    bool first_index(int k, int64_t* out)       // blocks until every worker before k has published; false when the run is aborting
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { if (abort) return true; for (int j = 0; j < k; j++) if (!done[(size_t)j]) return false; return true; });
-        if (abort) return false;
-        int64_t s = 0;
-        for (int j = 0; j < k; j++) s += total[(size_t)j];
-        *out = s;
-        return true;
-    }
+    explicit RecordOrder(int) {}
     void stop(int code = 0, const std::string& msg = std::string())
     {
         std::lock_guard<std::mutex> lk(m);
         if (code && !err_code) { err_code = code; err_msg = msg; }
-        abort = true; cv.notify_all();
+        abort = true;
     }
     void first_error(int* code, std::string* msg) { std::lock_guard<std::mutex> lk(m); *code = err_code; *msg = err_msg; }
 };
@@ -580,40 +566,11 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     lap(2);
     const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;               // mixed scans with logistic (:467)
     const int nw = mipgen_accel_window_count(h);
-    // Non-silent designs get their all_mips records as text from the device.  The records are numbered design-wide,
-    // so every worker first counts what it will emit (score + replay of its windows: the count depends on the scores), publishes the total
-    // and waits for the totals of the workers before it; a worker whose shard is one window keeps that window's results for the second pass.
+    // Non-silent designs get their all_mips records as text from the device.  The records are numbered design-wide
+    // (mipgen.cpp:474,488,792): a worker numbers its own from 0 and the consumer - which drains the workers in order and knows by then how many
+    // records the workers before this one wrote - adds that base to the last column while it copies the text (write_renumbered).  No counting
+    // pass: every window is scored once, with any number of workers.
     const bool text = !o.silent;
-    bool first_window_ready = false;
-    int64_t counted = -1, written = 0;           // records the counting pass saw / the formatting pass numbered (must agree)
-    if (text && order->total.size() > 1) {
-        int64_t mine = 0;
-        std::vector<int64_t> em;
-        for (int w = 0; w < nw; w++) {
-            if (ch->aborted()) { mipgen_accel_destroy(h); return; }
-            int32_t wr0 = 0, wn = 0;
-            mipgen_accel_window_info(h, w, &wr0, &wn, nullptr, nullptr, nullptr, nullptr);
-            if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
-            em.assign((size_t)wn, 0);
-            if (mipgen_accel_download_replay(h, em.data(), nullptr, 0, nullptr, 0)) { bail(19); return; }
-            for (int64_t e : em) mine += e;
-        }
-        first_window_ready = nw == 1;
-        order->publish(k_worker, mine);
-        if (!order->first_index(k_worker, &all_before)) {
-            // another worker failed (or the consumer stopped the run) while this one was counting.  The consumer may be blocked on THIS worker's
-            // channel (it drains the channels in worker order): it must get a terminal result - carrying the failure that stopped the run.
-            mipgen_accel_destroy(h);
-            std::unique_ptr<WindowResult> r(new WindowResult());
-            order->first_error(&r->error, &r->msg);
-            if (!r->error) { r->error = 19; r->msg = "device worker stopped: the run was aborted"; }
-            r->last = true;
-            ch->push(std::move(r));
-            return;
-        }
-        counted = mine;
-        lap(3);
-    }
     for (int w = 0; w < nw; w++) {
         if (ch->aborted()) { mipgen_accel_destroy(h); return; }       // the selection stage failed: do not score what nobody will consume
         int32_t wr0 = 0, wn = 0;
@@ -624,7 +581,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
         for (auto& g : res->grids) g.offset -= c0;
         res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np));
-        if (!first_window_ready && (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h))) { bail(19); return; }
+        if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
         if (mipgen_accel_collapse(h)) { bail(19); return; }
         res->col_off.assign((size_t)wn + 1, 0);
         for (int bi = 0; bi < wn; bi++) {
@@ -652,14 +609,8 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
             res->text.resize((size_t)n_bytes);
             if (mipgen_accel_download_text(h, res->text.data(), n_bytes)) { bail(19); return; }
             res->has_text = true;
+            res->n_rec = n_rec;
             all_before += n_rec;
-            written += n_rec;
-            if (counted >= 0 && (written > counted || (w == nw - 1 && written != counted))) {
-                // the design-wide record numbers of the workers behind this one were derived from `counted`
-                mipgen_accel_destroy(h);
-                fail_out(19, "all_mips numbering: the counting pass saw " + std::to_string(counted) + " records, the formatting pass " + std::to_string(written));
-                return;
-            }
         }
         lap(4);
         for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
@@ -724,6 +675,38 @@ static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_c
     return (int64_t)(2.7 * (double)cand + 47.0 * (double)ent);
 }
 
+// all_mips text of a worker that numbered its records from 0: the last column is <label>_<index, at least four digits>[_SNP_a|_SNP_b] (print_details,
+// mipgen.cpp:792); every index is raised by `base`.  ~0.1 us per record on the consumer thread, instead of a second scoring pass on the device.
+static void write_renumbered(std::ostream& os, const std::vector<char>& text, int64_t base)
+{
+    const char* p = text.data();
+    const char* const end = p + text.size();
+    std::string buf;
+    buf.reserve((size_t)1 << 20);
+    char num[32];
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;                                            // end of the line's text
+        const char* dend = le;
+        if (le - p >= 6 && le[-6] == '_' && le[-5] == 'S' && le[-4] == 'N' && le[-3] == 'P' && le[-2] == '_' && (le[-1] == 'a' || le[-1] == 'b')) dend = le - 6;
+        const char* dbeg = dend;
+        while (dbeg > p && dbeg[-1] >= '0' && dbeg[-1] <= '9') dbeg--;
+        if (dbeg == dend || dbeg == p || dbeg[-1] != '_') { buf.append(p, (size_t)(le - p)); }   // (not a record line: copied as it is)
+        else {
+            int64_t v = 0;
+            for (const char* q = dbeg; q < dend; q++) v = v * 10 + (*q - '0');
+            buf.append(p, (size_t)(dbeg - p));
+            const int k = snprintf(num, sizeof num, "%04lld", (long long)(v + base));
+            buf.append(num, (size_t)k);
+            buf.append(dend, (size_t)(le - dend));
+        }
+        if (nl) buf.push_back('\n');
+        p = nl ? nl + 1 : end;
+        if (buf.size() >= ((size_t)1 << 20) - 4096) { os.write(buf.data(), (std::streamsize)buf.size()); buf.clear(); }
+    }
+    if (!buf.empty()) os.write(buf.data(), (std::streamsize)buf.size());
+}
+
 static int64_t region_weight_of(const mipgen_design* d, int i)
 {
     const Options& o = d->o;
@@ -778,14 +761,20 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     StageClock clk(d->timing);
     if (d->selector) d->selector->fine_timing = d->timing;
     double t_wait = 0.0, t_select = 0.0;
+    int64_t records_total = 0;                   // all_mips records written so far (the device text of all workers)
     for (int k = 0; k < n_devices && rc == 0; k++) {
+        const int64_t records_before_worker = records_total;     // what worker k's own numbering (from 0) has to be shifted by
         for (;;) {
             const auto tw0 = std::chrono::steady_clock::now();
             std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
             const auto tw1 = std::chrono::steady_clock::now();
             t_wait += std::chrono::duration<double>(tw1 - tw0).count();
             if (w->error) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
-            if (w->has_text) d->out.all.write(w->text.data(), (std::streamsize)w->text.size());     // numbered by the device from this window's first index
+            if (w->has_text) {
+                if (records_before_worker) write_renumbered(d->out.all, w->text, records_before_worker);
+                else d->out.all.write(w->text.data(), (std::streamsize)w->text.size());             // (the first worker's numbers are the design's)
+                records_total += w->n_rec;
+            }
             int64_t pos0 = 0;
             for (int bi = 0; bi < w->r1 - w->r0 && rc == 0; bi++) {
                 const mipgen_grid& g = w->grids[(size_t)bi];
