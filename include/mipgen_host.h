@@ -97,6 +97,13 @@ int mipgen_design_select_regions(mipgen_design* d, int32_t first, int32_t n, con
  * capacity 0: only *count is set. */
 int mipgen_design_survivor_candidates(const mipgen_design* d, int32_t first, int32_t n, const mipgen_grid* grids, const mipgen_survivor* survivors,
                                       mipgen_candidate* cands, int64_t* where, int64_t capacity, int64_t* count);
+/* Non-silent designs whose all_mips records were formatted on the accelerator (mipgen_accel_format_all_mips) by a caller of its own (mipgen_amd/mp_design.py):
+ * what that call needs - the record names of regions first .. first + n - 1 (pointers into the design's strings, valid until close) and the -mip_middle
+ * sequence - and the way back: append formatted records to the all_mips file, every record number (last column, `label_0042[_SNP_a]`) raised by
+ * renumber_base (a rank numbers its records from 0; the base is what the ranks before it wrote). */
+int mipgen_design_record_names(const mipgen_design* d, int32_t first, int32_t n, mipgen_record_names* out);
+const char* mipgen_design_middle(const mipgen_design* d);
+int mipgen_design_write_all_mips(mipgen_design* d, const char* text, int64_t n_bytes, int64_t renumber_base);
 /* counters after the regions selected so far: all / collapsed / picked records written, gaps reported */
 int mipgen_design_counters(const mipgen_design* d, int64_t* all_mips, int64_t* collapsed, int64_t* picked, int64_t* gaps);
 

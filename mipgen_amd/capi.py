@@ -665,6 +665,14 @@ class Accel:
                                                              chrom_seq_stop, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def format_all_mips_array(self, names_arr, middle: bytes, first_index: int = 0) -> Tuple[bytes, int]:
+        """format_all_mips() for a ready-made ctypes array of RecordNames (hostapi.Design.record_names)."""
+        nrec, nb = C.c_int64(), C.c_int64()
+        self._check(self.lib.mipgen_accel_format_all_mips(self.h, names_arr, middle, first_index, C.byref(nrec), C.byref(nb)))
+        buf = C.create_string_buffer(max(nb.value, 1))
+        self._check(self.lib.mipgen_accel_download_text(self.h, buf, nb.value))
+        return buf.raw[:nb.value], nrec.value
+
     def replay_condense(self) -> None:
         self._check(self.lib.mipgen_accel_replay_condense(self.h))
 

@@ -707,6 +707,28 @@ static void write_renumbered(std::ostream& os, const std::vector<char>& text, in
     if (!buf.empty()) os.write(buf.data(), (std::streamsize)buf.size());
 }
 
+extern "C" int mipgen_design_record_names(const mipgen_design* d, int32_t first, int32_t n, mipgen_record_names* out)
+{
+    if (!d || n < 0 || first < 0 || first + n > (int32_t)d->regions.size() || (n > 0 && !out)) return fail(MIPGEN_HOST_E_USAGE, 0, "region range out of bounds");
+    for (int32_t k = 0; k < n; k++) {
+        const Region& r = d->regions[(size_t)(first + k)];
+        out[k] = mipgen_record_names{r.chr.c_str(), r.label.c_str(), r.start - 1, r.stop};
+    }
+    return 0;
+}
+
+extern "C" const char* mipgen_design_middle(const mipgen_design* d) { return d ? d->o.middle.c_str() : ""; }
+
+extern "C" int mipgen_design_write_all_mips(mipgen_design* d, const char* text, int64_t n_bytes, int64_t renumber_base)
+{
+    if (!d || n_bytes < 0 || (n_bytes > 0 && !text) || renumber_base < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad arguments");
+    if (d->o.silent) return fail(MIPGEN_HOST_E_USAGE, 0, "a silent design has no all_mips records");
+    if (n_bytes == 0) return 0;
+    if (renumber_base) { std::vector<char> v(text, text + n_bytes); write_renumbered(d->out.all, v, renumber_base); }
+    else d->out.all.write(text, (std::streamsize)n_bytes);
+    return 0;
+}
+
 static int64_t region_weight_of(const mipgen_design* d, int i)
 {
     const Options& o = d->o;

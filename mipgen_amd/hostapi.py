@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = [
     "mipgen_host_last_error", "mipgen_host_last_circumstance", "mipgen_design_open", "mipgen_design_close", "mipgen_design_params",
     "mipgen_design_score_method", "mipgen_design_silent", "mipgen_design_model_path", "mipgen_design_region_count", "mipgen_design_region", "mipgen_design_regions",
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
-    "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_survivor_candidates", "mipgen_design_counters", "mipgen_design_region_weights",
+    "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_survivor_candidates", "mipgen_design_record_names", "mipgen_design_middle",
+    "mipgen_design_write_all_mips", "mipgen_design_counters", "mipgen_design_region_weights",
     "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
 ]
 
@@ -67,6 +68,10 @@ def load_library():
     lib.mipgen_design_region_weights.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]
     lib.mipgen_design_select_regions.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.POINTER(C.c_int64),
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    lib.mipgen_design_record_names.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.RecordNames)]
+    lib.mipgen_design_middle.argtypes = [vp]
+    lib.mipgen_design_middle.restype = C.c_char_p
+    lib.mipgen_design_write_all_mips.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64]
     lib.mipgen_design_survivor_candidates.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(capi.Grid), C.POINTER(capi.Survivor), C.POINTER(capi.Candidate),
                                                       C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
@@ -204,6 +209,20 @@ class Design:
                                                                cands, where.ctypes.data_as(C.POINTER(C.c_int64)), m, C.byref(cnt)))
         assert cnt.value == m
         return cands, where[:m], m
+
+    def record_names(self, first: int, n: int):
+        """ctypes array of capi.RecordNames for regions first .. first + n - 1 (what mipgen_accel_format_all_mips takes)."""
+        arr = (capi.RecordNames * max(n, 1))()
+        self._check(self.lib.mipgen_design_record_names(self.h, first, n, arr))
+        return arr
+
+    @property
+    def middle(self) -> bytes:
+        return self.lib.mipgen_design_middle(self.h)
+
+    def write_all_mips(self, text: bytes, renumber_base: int = 0) -> None:
+        """Append device-formatted all_mips records to the design's file, their record numbers raised by renumber_base."""
+        self._check(self.lib.mipgen_design_write_all_mips(self.h, text, len(text), renumber_base))
 
     def region_weights(self) -> np.ndarray:
         """Relative device time per region: the weights of the device shards (mipgen_design_run's own rule)."""

@@ -12,8 +12,9 @@ sequentially in region order (the rand() stream and the used-arm sets persist ac
                counts and grids to rank 0, which
   rank 0       runs the selection stage region by region (mipgen_design_select_region) and writes the design's files.
 
-Silent designs of every score method (`-silent_mode on` is added when absent; mixed designs re-score their condensed survivors with the SVR on the
-rank that holds the region, before the gather); the all_mips text of non-silent designs stays with the in-process multi-GPU driver (`mipgen -gpus N`).  `--backend gloo --share-gpus` runs the same code on a one-GPU box (tests).  The product has no CPU path: without
+Every score method (mixed designs re-score their condensed survivors with the SVR on the rank that holds the region, before the gather), silent or
+not: a non-silent design's all_mips records are formatted on every rank's GPU with the rank's own numbering into a part file beside the outputs, and
+rank 0 appends the parts in rank order with the record numbers shifted by what the ranks before wrote (mipgen.cpp:474,488,792).  `--backend gloo --share-gpus` runs the same code on a one-GPU box (tests).  The product has no CPU path: without
 a HIP device this fails."""
 from __future__ import annotations
 
@@ -95,12 +96,7 @@ def main(argv: List[str]) -> int:
 
     t_start = time.perf_counter()
     flags = list(flags)
-    if "-silent_mode" in flags:
-        k = flags.index("-silent_mode")
-        if k + 1 >= len(flags) or flags[k + 1] != "on":
-            raise SystemExit("mp_design: only silent designs (the all_mips text of several ranks is the in-process driver's: mipgen -gpus N)")
-    else:
-        flags += ["-silent_mode", "on"]
+    project = flags[flags.index("-project_name") + 1] if "-project_name" in flags and flags.index("-project_name") + 1 < len(flags) else None
     scratch = None
     if rank > 0:                                                           # the input stage writes files named after the project: ranks > 0 keep theirs out of the way
         scratch = tempfile.mkdtemp(prefix=f"mipgen_rank{rank}_")
@@ -134,11 +130,35 @@ def main(argv: List[str]) -> int:
                                                    [views0[k].seq_stop for k in range(hi - lo)])
                 for k, i in enumerate(range(lo, hi)):
                     d.set_long_range_content(i, lrc[k])
-        if hi > lo:
+        text_design = not d.silent                                         # all_mips records: formatted on the device, window by window
+        part_path = (project or "mipgen_design") + f".all_mips.rank{rank}.part"   # (rank 0's project path: one node, one file system)
+        local_rec = 0
+        if text_design:
+            acc.set_window_candidates(64 << 20)                            # the front end's window policy for designs that fetch per-window results
+        if hi > lo and not text_design:
             grids = acc.upload_array(d.regions(lo, hi - lo), hi - lo)       # the shard's regions in the C layout, straight from libmipgen_host's arrays
             acc.score_condense_all(scan)                                    # score + replay + condense + collapse of every result window
             emitted, surv = acc.download_survivors()
             col = acc.download_collapsed(-1)                                # collapse_mips of the shard: 2 entries per base, region after region
+            nbase = np.array([acc.region_bases(k)[1] for k in range(hi - lo)], dtype=np.int32)
+        elif hi > lo:
+            # non-silent: window by window - score, replay + condense, collapse, then print_details on the device (mipgen.cpp:765-794) with the rank's
+            # own record numbers (from 0: rank 0 shifts them by what the ranks before wrote); the text goes to a part file beside the design's outputs
+            grids = acc.upload_array(d.regions(lo, hi - lo), hi - lo)
+            em_p, surv_p, col_p = [], [], []
+            with open(part_path, "wb") as part:
+                for w in range(acc.window_count()):
+                    wi = acc.window_info(w)
+                    acc.score_window(w, scan)
+                    acc.replay_condense()
+                    acc.collapse()
+                    col_p.append(acc.download_collapsed(w))
+                    e_w, s_w, _ = acc.download_replay(want_mask=False, window=w)
+                    text, nrec = acc.format_all_mips_array(d.record_names(lo + wi["first_region"], wi["n_regions"]), d.middle, local_rec)
+                    part.write(text)
+                    local_rec += nrec
+                    em_p.append(e_w); surv_p.append(s_w)
+            emitted, surv, col = np.concatenate(em_p), np.concatenate(surv_p), np.concatenate(col_p)
             nbase = np.array([acc.region_bases(k)[1] for k in range(hi - lo)], dtype=np.int32)
         else:
             grids, emitted, surv = [], np.zeros(0, dtype=np.int64), np.zeros(0, dtype=capi.SURVIVOR_DTYPE)
@@ -168,8 +188,32 @@ def main(argv: List[str]) -> int:
             all_svr = mdist.gather_to_rank0(svr, xdev) if mixed else None
         else:
             all_surv, all_emitted, all_grids, all_col, all_nbase, all_svr = surv, emitted, garr, col, nbase, (svr if mixed else None)
+        rec_base, rec_total = (mdist.exclusive_offsets(local_rec, xdev) if distributed else (0, local_rec)) if text_design else (0, 0)
+        rec_bases = None
+        if text_design and distributed:
+            rec_bases = mdist.gather_to_rank0(np.array([rec_base], dtype=np.int64), xdev)
         t_gathered = time.perf_counter()
         acc.close()
+        if rank == 0 and text_design:
+            # the all_mips file: rank after rank, every rank's own numbering shifted by what the ranks before it wrote (whole lines, 64 MB at a time)
+            for r in range(world):
+                pp = (project or "mipgen_design") + f".all_mips.rank{r}.part"
+                if not os.path.exists(pp):
+                    continue
+                base_r = int(rec_bases[r]) if rec_bases is not None else 0
+                with open(pp, "rb") as fh:
+                    carry = b""
+                    while True:
+                        chunk = fh.read(64 << 20)
+                        if not chunk:
+                            break
+                        chunk = carry + chunk
+                        cut = chunk.rfind(b"\n") + 1
+                        carry = chunk[cut:]
+                        if cut:
+                            d.write_all_mips(chunk[:cut], base_r)
+                    if carry:
+                        d.write_all_mips(carry, base_r)
         if rank == 0:
             all_grids = all_grids.reshape(-1, 6)
             assert all_grids.shape[0] == n and all_emitted.shape[0] == n, "the gather lost regions"
@@ -198,8 +242,12 @@ def main(argv: List[str]) -> int:
             shutil.rmtree(scratch, ignore_errors=True)
     if distributed:
         if rc == 0:
-            dist.barrier()
+            dist.barrier()                                                   # rank 0 has read every part file
         dist.destroy_process_group()
+    try:
+        os.remove((project or "mipgen_design") + f".all_mips.rank{rank}.part")
+    except OSError:
+        pass
     return rc
 
 
