@@ -125,6 +125,9 @@ int mipgen_design_run(mipgen_design* d, int32_t n_devices);
  * cap on the candidates of one result window (0 = default policy; option -gpu_window_candidates; tests force several windows with it),
  * stage timings on stderr (option -gpu_timing on). */
 int mipgen_design_set_devices(mipgen_design* d, int32_t n_devices);
+/* -gpu_copy_counter on, regions fetched through mipgen_design_region(s): the HIP device their copy numbers are counted on (default 0; a rank of a
+ * one-process-per-GPU run passes its own) */
+int mipgen_design_set_api_device(mipgen_design* d, int32_t device);
 int mipgen_design_set_window_candidates(mipgen_design* d, int64_t max_candidates);
 int mipgen_design_set_timing(mipgen_design* d, int32_t on);
 

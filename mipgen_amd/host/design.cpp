@@ -60,6 +60,7 @@ struct mipgen_design {
     // -gpu_copy_counter on: the genome the arm oligos are counted against.  The device workers of mipgen_design_tile_regions count their own
     // shard and keep the tables in HBM; host tables are only built for a caller that asks for the regions (mipgen_design_region).
     std::vector<std::string> genome;
+    int api_device = 0;                          // the HIP device mipgen_design_region(s) counts the deferred copy numbers on (mipgen_design_set_api_device)
     bool copies_deferred = false;
     std::mutex copies_mu;
     // front-end knobs (mipgen_design_set_*; the command line's -gpus / -gpu_window_candidates / -gpu_timing extension options): no environment
@@ -205,7 +206,7 @@ int mipgen_design_region(const mipgen_design* d, int32_t i, mipgen_region* out)
         mipgen_design* md = const_cast<mipgen_design*>(d);
         std::lock_guard<std::mutex> lock(md->copies_mu);
         if (!md->regions[(size_t)i].copy_ready) {
-            try { gpu_copy_numbers(md->o, md->genome, md->regions); } catch (int e) { return fail(MIPGEN_HOST_E_ACCEL, e, std::string("accelerator: ") + mipgen_accel_last_error()); }
+            try { gpu_copy_numbers(md->o, md->genome, md->regions, 0, -1, md->api_device); } catch (int e) { return fail(MIPGEN_HOST_E_ACCEL, e, std::string("accelerator: ") + mipgen_accel_last_error()); }
             for (Region& r : md->regions) { r.copy_deferred = false; attach_copy_tables(md->o, r); }
         }
     }
@@ -237,7 +238,7 @@ int mipgen_design_regions(const mipgen_design* d, int32_t first, int32_t n, mipg
         bool ready = true;
         for (int32_t k = 0; k < n; k++) ready = ready && md->regions[(size_t)(first + k)].copy_ready;
         if (!ready) {
-            try { gpu_copy_numbers(md->o, md->genome, md->regions, first, first + n); } catch (int e) { return fail(MIPGEN_HOST_E_ACCEL, e, std::string("accelerator: ") + mipgen_accel_last_error()); }
+            try { gpu_copy_numbers(md->o, md->genome, md->regions, first, first + n, md->api_device); } catch (int e) { return fail(MIPGEN_HOST_E_ACCEL, e, std::string("accelerator: ") + mipgen_accel_last_error()); }
             for (int32_t k = 0; k < n; k++) { Region& r = md->regions[(size_t)(first + k)]; r.copy_deferred = false; attach_copy_tables(md->o, r); }
         }
     }
@@ -374,6 +375,12 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
     return 0;
 }
 
+int mipgen_design_set_api_device(mipgen_design* d, int32_t device)
+{
+    if (!d || device < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad argument");
+    d->api_device = device;
+    return 0;
+}
 int mipgen_design_set_devices(mipgen_design* d, int32_t n_devices)
 {
     if (!d || n_devices < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad argument");

@@ -525,7 +525,7 @@ void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::
 }
 
 // the counts as host tables (Region::copy_flat): for callers that score through their own accelerator handle
-void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1)
+void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1, int device)
 {
     if (r1 < 0) r1 = (int)regs.size();                                // (the default: every region)
     if (r1 <= r0) return;
@@ -541,7 +541,7 @@ void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, 
     }
     mipgen_params ap = o.accel_params();
     mipgen_accel* h = nullptr;
-    if (mipgen_accel_create(&ap, 0, nullptr, &h)) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; throw 17; }
+    if (mipgen_accel_create(&ap, device, nullptr, &h)) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; throw 17; }
     const int rc = mipgen_accel_count_oligo_copies(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(),
                                                    (int32_t)lengths.size(), lengths.data(), outp.data());
     if (rc) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; mipgen_accel_destroy(h); throw 11; }

@@ -92,7 +92,7 @@ void find_copy(const Options& o, Tables& t);
 void attach_tables(const Options& o, const Tables& t, Region& r);                          // fill copy/unmappable/snp slices
 // -gpu_copy_counter on: exact oligo copy numbers from the accelerator's k-mer counter instead of the bwa round trip; throws int on failure
 void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<std::string>& chroms);   // the genome behind the bwa index
-void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0 = 0, int r1 = -1);   // regions r0 .. r1 - 1 (r1 < 0: all)
+void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0 = 0, int r1 = -1, int device = 0);   // regions r0 .. r1 - 1 (r1 < 0: all), counted on `device`
 // -gpu_copy_counter on: Region::unmappable of regions [r0, r1) from the accelerator's window uniqueness test (mipgen.cpp:806-823, 841-868)
 void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1); // host tables (copy_flat)
 void attach_copy_tables(const Options& o, Region& r);                                                  // copy_ptr from copy_store / copy_flat

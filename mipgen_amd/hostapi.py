@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
     "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_survivor_candidates", "mipgen_design_record_names", "mipgen_design_middle",
     "mipgen_design_write_all_mips", "mipgen_design_counters", "mipgen_design_region_weights",
-    "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
+    "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_api_device", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
 ]
 
 _lib = None
@@ -76,6 +76,7 @@ def load_library():
                                                       C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]
     lib.mipgen_design_run.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_devices.argtypes = [vp, C.c_int32]
+    lib.mipgen_design_set_api_device.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_window_candidates.argtypes = [vp, C.c_int64]
     lib.mipgen_design_set_timing.argtypes = [vp, C.c_int32]
     lib.mipgen_host_rand_stream.argtypes = [C.POINTER(C.c_int32), C.c_int32]
@@ -120,6 +121,9 @@ class Design:
     @property
     def model_path(self) -> str:
         return self.lib.mipgen_design_model_path(self.h).decode()
+
+    def set_api_device(self, device: int) -> None:
+        self._check(self.lib.mipgen_design_set_api_device(self.h, device))
 
     def region_count(self) -> int:
         return int(self.lib.mipgen_design_region_count(self.h))

@@ -112,6 +112,7 @@ def main(argv: List[str]) -> int:
     reported = False                                                       # this rank has taken part in the "shard scored" exchange
     try:
         d = hostapi.Design([args.mipgen_path] + flags)
+        d.set_api_device(local_rank)                                       # (-gpu_copy_counter on: the shard's copy numbers are counted on this rank's GPU)
         P = d.params()
         n = d.region_count()
         scan = capi.SCORE_SVR if d.score_method == capi.SCORE_SVR else capi.SCORE_LOGISTIC
