@@ -207,3 +207,22 @@ def test_one_process_per_rank_design_through_torch_distributed(name, tmp_path):
         # record numbers (mipgen.cpp:474,488,792) - all four files are the reference's
         H.compare_outputs(meta, work)
         assert not [f for f in os.listdir(work) if f.endswith(".part")]
+
+
+def test_four_ranks_number_the_all_mips_records_design_wide(tmp_path):
+    """BASELINE configs[0] (62 regions, 2.18 M all_mips records) through mipgen_amd/mp_design.py with FOUR ranks on the box's GPU: three renumbering bases,
+    every output file the reference's."""
+    import json
+    import subprocess
+    import sys
+    meta = H.load_design("practice62_config1")
+    work = str(tmp_path / "mp4")
+    os.makedirs(work)
+    argv = H.prepare_cli_workdir(meta, work)
+    env = dict(os.environ, FAKEBWA_MODE=meta["bwa"], PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-m", "mipgen_amd.mp_design", "--gpus", "4", "--backend", "gloo", "--share-gpus", "--mipgen-path", argv[0], "--"] + argv[1:],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=work, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 4 and len(line["shards"]) == 4 and all(hi > lo for lo, hi in line["shards"])
+    H.compare_outputs(meta, work)
