@@ -104,6 +104,8 @@ def parse_args():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of the N > 1 run: nccl = RCCL over xGMI (the measured "
                     "path); gloo = the same exchange through host memory (tests of the N > 1 logic on boxes without a second GPU)")
     ap.add_argument("--share-gpus", action="store_true", help="tests only: ranks beyond the visible devices share them (rank r on GPU r mod devices; gloo only)")
+    ap.add_argument("--force-dist", action="store_true", help="tests only: take the N > 1 code path (process group, per-step gather) with a world of ONE rank - "
+                    "the RCCL calls of the step on a one-GPU box; needs RANK / WORLD_SIZE / MASTER_* in the environment (torch.distributed.run --nproc-per-node 1)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
     if a.config is None:
@@ -555,7 +557,7 @@ def main() -> None:
             raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this node shows {torch.cuda.device_count()} device(s): one process per GPU")
         local_rank %= torch.cuda.device_count()             # tests of the N > 1 logic on a one-GPU box (never a measurement: `shared_gpus` in the line)
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     xdev = "cuda" if args.backend == "nccl" else "cpu"      # where the tensors of the collectives live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -42,6 +42,7 @@ def _split_args(argv: List[str]):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI; gloo + --share-gpus: tests on a one-GPU box")
     ap.add_argument("--share-gpus", action="store_true", help="ranks beyond the visible devices wrap around (never a measurement)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--force-dist", action="store_true", help="tests: the process-group code path with a world of one rank (under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--mipgen-path", default=os.path.join(HERE, "mipgen"), help="argv[0] of the design: mipgen_svr.model is looked for beside it (mipgen.cpp:409)")
     args = ap.parse_args(own)
     if not flags:
@@ -85,7 +86,7 @@ def main(argv: List[str]) -> int:
             raise SystemExit(f"rank {rank} needs GPU {local_rank}, but this node shows {torch.cuda.device_count()} device(s): one process per GPU")
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     xdev = f"cuda:{local_rank}" if args.backend == "nccl" else None      # where the tensors of the gather live
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

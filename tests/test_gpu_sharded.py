@@ -226,3 +226,45 @@ def test_four_ranks_number_the_all_mips_records_design_wide(tmp_path):
     line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert line["ranks"] == 4 and len(line["shards"]) == 4 and all(hi > lo for lo, hi in line["shards"])
     H.compare_outputs(meta, work)
+
+
+def test_rccl_collectives_of_the_multi_gpu_paths_with_one_rank():
+    """The RCCL calls of bench.py --gpus N and mipgen_amd/mp_design.py (backend nccl, CUDA tensors, the dtypes they use) on a process group of one rank:
+    no multi-GPU box was available to this build, so at least the API surface - init with device_id, all_gather / gather of byte buffers, all_reduce
+    MAX / MIN, barrier - has executed on RCCL before the driver's run.  Child process (tests/rccl_one_rank_worker.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_one_rank_worker.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root, env=env)
+    assert p.returncode == 0 and b"rccl one-rank collectives ok" in p.stdout, p.stderr.decode()[-3000:]
+
+
+def test_bench_and_mp_design_take_their_rccl_code_path_with_one_rank(tmp_path):
+    """bench.py and mipgen_amd/mp_design.py through `torch.distributed.run --nproc-per-node 1` with the default backend (nccl = RCCL) and --force-dist: the
+    N > 1 code of both - process group with device_id, size exchange, the per-step gather straight from the library's survivor array in HBM (bench), the
+    gathers of survivors / collapse results / grids and the record-number scan (mp_design) - executes on RCCL on this one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    p = subprocess.run(launch + ["--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                                 "--no-extras", "--no-measure-traffic"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["backend"] == "nccl" and line["parity_checked"] is True
+    assert line["config"]["survivors_gathered_per_step"] == line["config"]["survivors_rank0"] > 0        # the gather ran, on device memory
+    meta = H.load_design("logistic_snp_trf")
+    work = str(tmp_path / "mp1")
+    os.makedirs(work)
+    argv = H.prepare_cli_workdir(meta, work)
+    p = subprocess.run(launch + ["--master-port", "29562", "-m", "mipgen_amd.mp_design", "--gpus", "1", "--force-dist", "--mipgen-path", argv[0], "--"] + argv[1:],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=work, env=dict(env, FAKEBWA_MODE=meta["bwa"]))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 1 and line["backend"] == "nccl"
+    H.compare_outputs(meta, work)
