@@ -57,6 +57,7 @@ struct mipgen_design {
     std::string model_path;
     int next_region = 0;
     bool closed = false;
+    bool failed = false;                         // a selection / accelerator failure: the design does not announce its completion (mipgen.cpp:532-533 is only reached on success)
     // -gpu_copy_counter on: the genome the arm oligos are counted against.  The device workers of mipgen_design_tile_regions count their own
     // shard and keep the tables in HBM; host tables are only built for a caller that asks for the regions (mipgen_design_region).
     std::vector<std::string> genome;
@@ -176,11 +177,14 @@ int mipgen_design_close(mipgen_design* d)
         Outputs& out = d->out;
         const Options& o = d->o;
         out.all.close(); out.collapsed.close(); out.picked.close(); out.snp.close();
-        out.progress << "mip picking complete:\n" << o.project_name << ".picked_mips.txt\n and \n" << o.project_name << ".snps_mips.txt\n";
-        std::cerr << "[mipgen] mip picking complete:\n" << o.project_name << ".picked_mips.txt\n and \n" << o.project_name << ".snp_mips.txt\n";
-        if (out.bad_design_count > 0) {
-            out.progress << "WARNING: There are " << out.bad_design_count << " gaps in covering supplied regions\n";
-            std::cerr << "[mipgen] WARNING: There are " << out.bad_design_count << " gaps in covering supplied regions\n";
+        // the reference announces completion at the end of tile_regions (mipgen.cpp:532-538); a run that threw never gets there (:2029-2035)
+        if (!d->failed && d->next_region == (int)d->regions.size()) {
+            out.progress << "mip picking complete:\n" << o.project_name << ".picked_mips.txt\n and \n" << o.project_name << ".snps_mips.txt\n";
+            std::cerr << "[mipgen] mip picking complete:\n" << o.project_name << ".picked_mips.txt\n and \n" << o.project_name << ".snp_mips.txt\n";
+            if (out.bad_design_count > 0) {
+                out.progress << "WARNING: There are " << out.bad_design_count << " gaps in covering supplied regions\n";
+                std::cerr << "[mipgen] WARNING: There are " << out.bad_design_count << " gaps in covering supplied regions\n";
+            }
         }
         out.progress.close();
     }
@@ -363,11 +367,13 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
         d->selector->run_region(r, *grid, survivors, grid->offset, o.score_method == MIPGEN_SCORE_MIXED ? &rs_fn : nullptr, lower, upper, collapsed, n_bases);
     } catch (int e) {
         d->flush_err();
+        d->failed = true;
         char msg[96];
         snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);
         return fail(MIPGEN_HOST_E_INPUT, e, msg);
     } catch (std::exception& e) {
         d->flush_err();
+        d->failed = true;
         return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
     }
     d->next_region = i + 1;
@@ -834,6 +840,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     if (rc) order.stop();
     if (rc) for (auto& c : chans) { std::lock_guard<std::mutex> lk(c->m); c->q.clear(); }
     for (auto& t : threads) t.join();
+    if (rc) d->failed = true;
     return rc;
 }
 
