@@ -26,7 +26,7 @@ hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, i
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
                                           double*, uint64_t*);
 size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l, int n_threads);
-hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int threads, size_t lds_bytes, const DevParams*, const SvrGeom*,
+hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int n_tiles_few, size_t lds_bytes, const DevParams*, const SvrGeom*, const SvrGeom* geom_few,
                                    const DevRegion*, const SvrTile*, const uint8_t*, const int32_t*, const double* log10_tab,
                                    const double* model, int n_sv, double gamma_l2e, double rho, double s_guard,
                                    const uint64_t* records, double* scores, int64_t n_cand, int n_split, double* partials);
@@ -105,7 +105,9 @@ struct Window {
     int64_t cand0 = 0, n_cand = 0;   // batch-wide candidate index of the first candidate; candidates
     int64_t pos0 = 0, n_pos = 0;     // batch-wide scan-position index; positions
     int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0, col_tile0 = 0, n_col_tiles = 0, ld_tile0 = 0, n_ld_tiles = 0;
+    int n_svr_few = 0;               // the LAST n_svr_few of the window's dense SVR tiles run with the few-sizes thread geometry (regions of one or two capture sizes)
     std::vector<int> lvl_tile0;      // dense SVR tiles by capture-size run: run l = svr_tiles_lvl[lvl_tile0[l], lvl_tile0[l + 1])
+    int lvl0_few = 0;                // ... the last lvl0_few tiles of run 0 with the few-sizes geometry (such regions have one run)
     int64_t base0 = 0, n_base_entries = 0;   // collapsed entries (2 per base) of the window inside the batch-wide array
 };
 
@@ -192,6 +194,8 @@ struct mipgen_accel {
     HostConsts* dconsts = nullptr;
     HostConsts hconsts;
     SvrGeom geom;
+    SvrGeom geom_few;                // thread geometry of the tiles of regions that keep one or two capture sizes: more, shorter arm-pair chunks
+    bool have_few = false;           // (twice the chunks, half the lanes per chunk: such a tile fills a quarter of the main geometry's lanes)
     // model
     int n_sv = 0;
     double gamma = 0, rho = 0, s_guard = 0;
@@ -402,6 +406,19 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
         snprintf(msg, sizeof msg, "too many arm pairs for the dense SVR kernel (max %d)", SVR_MAX_CHUNK * (SVR_MAX_THREADS / 64));
         h->svr_geometry_error = msg;
         G.wpc = 1;
+    }
+    // Regions that keep ONE or TWO capture sizes after the static skip of mipgen.cpp:429 (short exons: half of an exome BED) hold few (position,
+    // size) items per tile - the tile's positions are bound by its LDS, not by the lanes -, so with the main geometry half of the wavefronts own no
+    // candidate while the others walk fifteen pairs each.  Their tiles run with twice the chunks of half the length on two wavefronts each.
+    h->geom_few = G;
+    h->have_few = false;
+    if (h->svr_geometry_error.empty() && G.wpc == 4 && G.chunk_len > 8) {
+        SvrGeom& F = h->geom_few;
+        const int max_chunks = SVR_MAX_THREADS / 64 / 2;
+        F.chunk_len = (D.n_pairs + max_chunks - 1) / max_chunks;
+        F.nchunk = (D.n_pairs + F.chunk_len - 1) / F.chunk_len;
+        F.wpc = 2;
+        h->have_few = F.chunk_len < G.chunk_len && F.nchunk * F.wpc * 64 <= SVR_MAX_THREADS;
     }
     {
         const int n_arm = std::max(G.n_e, G.n_l) | 1;            // table row pitch in slots (as in the kernel)
@@ -988,7 +1005,6 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
     const DevParams& D = h->hp;
     const int Lmax = std::max(D.e_max, D.l_max);
     const int n_arm = std::max(h->geom.n_e, h->geom.n_l) | 1;
-    const int lanes = 64 * h->geom.wpc;
     std::vector<SvrTile> st, st_lvl;
     std::vector<double> st_cost;
     size_t svr_lds = 0;
@@ -1000,8 +1016,9 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
     struct Run { int ki0, kc, np; };
     struct Shape { std::vector<Run> runs; size_t lds = 0; };
     std::unordered_map<uint64_t, Shape> shapes;
-    auto shape_of = [&](const DevRegion& d) -> const Shape& {
-        const uint64_t key = ((uint64_t)(uint32_t)d.n_pos << 32) | ((uint64_t)(uint16_t)d.k0 << 16) | (uint64_t)(uint16_t)d.n_sizes;
+    auto shape_of = [&](const DevRegion& d, bool few) -> const Shape& {
+        const int lanes = 64 * (few ? h->geom_few.wpc : h->geom.wpc);
+        const uint64_t key = ((uint64_t)(uint32_t)d.n_pos << 32) | ((uint64_t)(uint16_t)d.k0 << 16) | (uint64_t)(uint16_t)d.n_sizes | (few ? (uint64_t)1 << 15 : 0);
         auto it = shapes.find(key);
         if (it != shapes.end()) return it->second;
         Shape best;
@@ -1046,10 +1063,19 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
     };
     for (Window& w : h->windows) {
         w.svr_tile0 = (int)st.size();
+        // the few-sizes geometry is a launch of its own: taken when the window holds enough such regions to fill the chip a few times over
+        // (a handful of them stay with the main launch: an extra launch ends with the tail of its last tile)
+        int n_few_regions = 0;
+        for (int i = w.r0; i < w.r1; i++) if (h->hregions[i].n_pos > 0 && h->hregions[i].n_sizes >= 1 && h->hregions[i].n_sizes <= 2) n_few_regions++;
+        const bool win_few = h->have_few && n_few_regions >= h->n_cu;
+        std::vector<uint8_t> st_few;                           // per tile of this window: few-sizes geometry?
         for (int i = w.r0; i < w.r1; i++) {
             const DevRegion& d = h->hregions[i];
             if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
-            const Shape& shape = shape_of(d);
+            // the SHAPE of such a region's tiles does not depend on which launch takes them (a score's last bits depend on where its tile starts:
+            // the window sums are differences of tile-relative prefix sums), so a region scores bit-identically in any window or shard
+            const bool few = win_few && d.n_sizes <= 2;
+            const Shape& shape = shape_of(d, h->have_few && d.n_sizes <= 2);
             if (shape.runs.empty()) { svr_lds = (size_t)1 << 30; continue; }
             svr_lds = std::max(svr_lds, shape.lds);
             const int Cmax = D.max_capture - d.k0 * D.inc;
@@ -1063,7 +1089,7 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
                     const int Cmax_t = Cmax - r.ki0 * D.inc, ssmax = Cmax_t - D.min_sum, ssr = (r.kc - 1) * D.inc + D.max_sum - D.min_sum + 1;
                     const double ent = (npt + (npt + ssr - 1)) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)npt * ssr;
                     const double cost = 19.0 * ent + 100.0 * (npt + ssmax + 2 * Lmax) + 75000.0;
-                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc, (int)lvl, 0}; st.push_back(t); st_cost.push_back(cost); }
+                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc, (int)lvl, 0}; st.push_back(t); st_cost.push_back(cost); st_few.push_back(few ? 1 : 0); }
                 }
             }
         }
@@ -1073,10 +1099,13 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
             const size_t t0 = (size_t)w.svr_tile0, n = st.size() - t0;
             std::vector<size_t> order(n);
             for (size_t k = 0; k < n; k++) order[k] = k;
-            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st_cost[t0 + a] > st_cost[t0 + b]; });
+            // (the tiles of the few-sizes geometry behind the others: the window's second launch)
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return st_few[a] != st_few[b] ? st_few[a] < st_few[b] : st_cost[t0 + a] > st_cost[t0 + b]; });
             std::vector<SvrTile> sorted(n);
             for (size_t k = 0; k < n; k++) sorted[k] = st[t0 + order[k]];
             std::copy(sorted.begin(), sorted.end(), st.begin() + (ptrdiff_t)t0);
+            w.n_svr_few = 0;
+            for (size_t k = 0; k < n; k++) w.n_svr_few += st_few[k];
         }
         w.n_svr_tiles = (int)st.size() - w.svr_tile0;
         // the same tiles grouped by capture-size run (run 0 first, longest first inside a run): the launch order of the dynamic skip (kernels_skip.hip)
@@ -1086,9 +1115,10 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
             for (size_t k = 0; k < n; k++) wl = std::max(wl, st[t0 + k].level + 1);
             w.lvl_tile0.assign(1, (int)st_lvl.size());
             for (int lvl = 0; lvl < wl; lvl++) {
-                for (size_t k = 0; k < n; k++) if (st[t0 + k].level == lvl) st_lvl.push_back(st[t0 + k]);
+                for (size_t k = 0; k < n; k++) if (st[t0 + k].level == lvl) st_lvl.push_back(st[t0 + k]);      // (order kept: run 0 ends with the few-sizes tiles)
                 w.lvl_tile0.push_back((int)st_lvl.size());
             }
+            w.lvl0_few = w.n_svr_few;                          // regions of one or two sizes have one run
         }
     }
     h->svr_batch_error.clear();
@@ -1255,12 +1285,13 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
                     HIP_TRY(hipStreamSynchronize(h->stream));
                     tl = h->svr_tiles_kept.p; nt = (int)kept;
                 }
-                HIP_TRY(mipgen_launch_svr_dense(h->stream, nt, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p, tl, h->bases.p, h->copy.p,
+                const int nt_few = l == 0 ? W.lvl0_few : 0;
+                HIP_TRY(mipgen_launch_svr_dense(h->stream, nt - nt_few, nt_few, h->svr_lds, h->dp, &h->geom, &h->geom_few, h->regions.p, tl, h->bases.p, h->copy.p,
                                                 (const double*)h->dconsts, h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, 1,
                                                 nullptr));
             }
         } else
-        HIP_TRY(mipgen_launch_svr_dense(h->stream, W.n_svr_tiles, h->geom.nchunk * h->geom.wpc * 64, h->svr_lds, h->dp, &h->geom, h->regions.p,
+        HIP_TRY(mipgen_launch_svr_dense(h->stream, W.n_svr_tiles - W.n_svr_few, W.n_svr_few, h->svr_lds, h->dp, &h->geom, &h->geom_few, h->regions.p,
                                         h->svr_tiles.p + W.svr_tile0, h->bases.p, h->copy.p, (const double*)h->dconsts /* log10_tab is the first member */,
                                         h->model.p, h->n_sv, gamma_l2e, h->rho, h->s_guard, h->records.p, h->scores.p, W.n_cand, split, h->partials.p));
         if (fix_dense) { if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand)) return rc; }

@@ -17,8 +17,13 @@ else:
     P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
     acc = capi.Accel(P)
     acc.load_model_file(workloads.svr_model_path("gpurun_out/bench_cache", workloads.practice62()[0], 1024))
-    regions = workloads.build_exome(acc, chrom_len, all_iv[:2048], P)
-acc.upload(regions)
+    ivs = all_iv[:2048]
+    if cfg.startswith("exomeK"):                # only the regions that keep K capture sizes (exomeK1 ... exomeK5)
+        gr = acc.upload(workloads.build_exome(acc, chrom_len, all_iv[:4096], P))
+        ivs = [iv for iv, g in zip(all_iv[:4096], gr) if g.n_sizes == int(cfg[6:])]
+    regions = workloads.build_exome(acc, chrom_len, ivs, P)
+grids = acc.upload(regions)
+print(cfg, "regions", len(regions), "candidates", sum(g.count for g in grids), file=sys.stderr)
 if len(sys.argv) > 3:                       # phase ablation of a -DMIPGEN_DIAG build: 1 no scan, 2 no tables, 4 no candidate steps (timing only)
     import ctypes
     capi._lib.mipgen_svr_debug_set(ctypes.c_int(int(sys.argv[3])))
