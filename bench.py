@@ -22,15 +22,15 @@ compares records / scores / replay / condensed survivors with the oracle (the ch
 as a rate) - SURVEY.md section 8d "correctness gate run with every measurement".
 
 N > 1: one process per GPU (`--gpus N` without a launcher starts `torch.distributed.run` itself, before anything touches a GPU).
-The BED is sharded over the ranks by dense-grid size (contiguous region ranges, no data-path collective while scoring); every step ends
+The BED is sharded over the ranks by the kernels' cost model (contiguous region ranges, no data-path collective while scoring); every step ends
 with ONE gather of the condensed survivors to rank 0 (RCCL over xGMI), where the sequential pick stage consumes them.
-  --scaling strong (default for N > 1)   ONE fixed BED cut N ways: by default --config exome (configs[3], the metric's multi-GPU config),
-                                         the first 65,536 of its 200,000 exons (--regions 200000 for all of them: ~20 s per pass per GPU-share)
-  --scaling weak (default for N = 1)     the BED grows with N: N practice62-sized instances / N x --regions
+  --scaling weak (default, every N)      the BED grows with N: N practice62-sized instances (62 N regions, 62 per rank) / N x --regions
+  --scaling strong                       ONE fixed BED cut N ways (--config exome --regions R)
 
-The scaling curve (driver: `bench.py --gpus N` for N = 1, 2, 4, 8) is ONE workload family: N > 1 shards the first 65,536 exons of the exome BED
-(strong scaling); the N = 1 default line keeps the configs[1] headline and carries a top-level `scale_base` = the same 65,536-exon BED measured
-on the one GPU in the same run (`python bench.py --gpus 1 --config exome --regions 65536 --scaling strong` is that point as a line of its own).
+The scaling curve (driver: `bench.py --gpus N` for N = 1, 2, 4, 8) is ONE workload family in `value`: the configs[1] headline batch, weak-scaled
+(`scale_family` names it in every line), so value(N) / (N value(1)) is a like-for-like efficiency.  The metric's own multi-GPU config (configs[3],
+the exome) rides along in every line as `exome_strong`: the first 65,536 exons cut N ways, one timed pass with its gather (at N = 1 the same
+object is also printed as `scale_base`); divide exome_strong.value of an N-rank line by the one of the N = 1 line - never by `value`.
 Every line names `rccl_ranks` (the world size torch.distributed reports after init_process_group; 1 without a process group) and the dense
 candidates of every rank.
 
@@ -80,10 +80,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: practice62 at N = 1, exome at N > 1")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: practice62 (every N)")
     ap.add_argument("--regions", type=int, default=0, help="regions of the workload to use (0 = the config's default)")
     ap.add_argument("--method", choices=["svr", "logistic"], default=None)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak at N = 1, strong (one BED cut N ways) at N > 1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default: weak (the BED grows with N); strong = one BED cut N ways")
     ap.add_argument("--nsv", type=int, default=1024)
     ap.add_argument("--min-capture", type=int, default=0)
     ap.add_argument("--max-capture", type=int, default=0)
@@ -109,9 +109,9 @@ def parse_args():
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", str(a.gpus)))
     if a.config is None:
-        a.config = "practice62" if world == 1 else "exome"
+        a.config = "practice62"
     if a.scaling is None:
-        a.scaling = "weak" if world == 1 else "strong"
+        a.scaling = "weak"
     if not a.regions and a.config == "exome" and world > 1 and a.scaling == "strong":
         a.regions = SCALE_REGIONS
     return a
@@ -458,6 +458,13 @@ def measure_traffic(args, kernel: str):
         base += ["--min-capture", str(args.min_capture)]
     if args.max_capture:
         base += ["--max-capture", str(args.max_capture)]
+    # everything that changes the launch travels to the child passes
+    if args.dynamic_skip:
+        base += ["--dynamic-skip"]
+    if args.sv_split:
+        base += ["--sv-split", str(args.sv_split)]
+    if args.window_candidates:
+        base += ["--window-candidates", str(args.window_candidates)]
     env = dict(os.environ, TMPDIR="/tmp")
     got = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -479,7 +486,7 @@ def measure_traffic(args, kernel: str):
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
     return {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_corrected": 2.0 * fetch, "write_bytes": write,
-            "launches_averaged": min(got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]), "kernel": kernel,
+            "launches_averaged": min(got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]), "kernel": kernel, "child_command": " ".join(base[1:]),
             "how": "child `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this workload (--steps 2 --warmup 1), mean per launch, "
                    "summed over the device; counter unit KiB; FETCH_SIZE x 2 = the gfx950 correction (MI355X_MICROARCH.md, HBM section)"}
 
@@ -490,12 +497,42 @@ def newest_profile(pattern: str):
 
 
 
-def exome_line(args, device: int, stream: int, model_path: str, n_regions: int = 0) -> dict:
-    """The metric's own multi-GPU config on ONE GPU (BASELINE configs[3]: exome200k, capture 150-170, SVR): one warm-up pass over the first result
-    window, then one timed pass over all of it through score_condense_all (records + k_svr_dense + replay / condense per result window).
-    n_regions = SCALE_REGIONS gives the `scale_base` line: exactly the BED `--gpus N > 1` cuts N ways."""
+class SurvivorGather:
+    """The one exchange step of the path: the handle's condensed survivors, straight from its array in HBM (mipgen_accel_survivors_device_ptr
+    wrapped as a torch tensor, no copy), gathered to rank 0 - RCCL over xGMI: direct peer -> root transfers (`--backend gloo`: through host memory)."""
+
+    def __init__(self, acc, world: int, rank: int, local_rank: int, xdev: str):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.rank = dist, rank
+        ptr, n_slots = acc.survivors_device_ptr()
+        self.nbytes = n_slots * 24
+
+        class _DevView:
+            def __init__(self, p, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (p, False), "version": 2}
+        self.send = torch.as_tensor(_DevView(ptr, max(n_slots, 1) * 24), device=f"cuda:{local_rank}")
+        sizes = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([self.nbytes], dtype=torch.int64, device=xdev))
+        self.sizes = [int(t.item()) for t in sizes]
+        mx = max(max(self.sizes), 24)
+        self.pad = torch.zeros(mx, dtype=torch.uint8, device=xdev)
+        self.recv = [torch.zeros(mx, dtype=torch.uint8, device=xdev) for _ in range(world)] if rank == 0 else None
+
+    def __call__(self) -> None:
+        self.pad[: self.nbytes].copy_(self.send[: self.nbytes])
+        self.dist.gather(self.pad, self.recv, dst=0)
+
+
+def exome_line(args, device: int, stream: int, model_path: str, n_regions: int = 0, rank: int = 0, world: int = 1, distributed: bool = False,
+               xdev: str = "cuda") -> dict:
+    """The metric's own multi-GPU config (BASELINE configs[3]: exome200k, capture 150-170, SVR): the first n_regions exons cut `world` ways by the
+    kernels' cost model, one warm-up pass over the first result window, then ONE timed pass of every rank over its shard through score_condense_all
+    (records + k_svr_dense + replay / condense per result window) + the gather of the survivors to rank 0; barrier on both sides, max over ranks.
+    world = 1: the whole BED on the one GPU (the `scale_base` / `exome_strong` point of the N = 1 line)."""
     import torch
-    from mipgen_amd import capi, workloads
+    import torch.distributed as dist
+    from mipgen_amd import capi, workloads, dist as mdist
     P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
     acc = capi.Accel(P, device=device, stream=stream)
     # the same support vectors as the headline's model, rho placed for the exome (workloads.MODEL_RHO): its replay takes early exits too
@@ -503,33 +540,86 @@ def exome_line(args, device: int, stream: int, model_path: str, n_regions: int =
     t0 = time.perf_counter()
     chrom_len, all_iv = workloads.exome_layout()
     ivs = all_iv[:min(n_regions or args.exome_regions, len(all_iv))]
-    regions = workloads.build_exome(acc, chrom_len, ivs, P, with_lrc=True)
+    lo, hi = mdist.shard_regions(workloads.shard_weights(ivs, P, True).tolist(), world)[rank] if world > 1 else (0, len(ivs))
+    regions = workloads.build_exome(acc, chrom_len, ivs[lo:hi], P, with_lrc=True)
     grids = acc.upload(regions)
     t_build = time.perf_counter() - t0
     n_cand = acc.batch_candidates()
     acc.set_timing(True)
     acc.score_window(0, capi.SCORE_SVR)                       # warm-up: tile lists, result arrays, code objects
+    gather = SurvivorGather(acc, world, rank, device, xdev) if distributed else None
+    if gather:
+        gather()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     acc.score_condense_all(capi.SCORE_SVR)
+    if gather:
+        gather()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
     torch.cuda.synchronize()
     d1 = time.perf_counter() - t1
+    per_rank = [n_cand]
+    if distributed:
+        tt = torch.tensor([d1], dtype=torch.float64, device=xdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        d1 = float(tt.item())
+        per = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([n_cand], dtype=torch.int64, device=xdev))
+        per_rank = [int(t.item()) for t in per]
+    total = sum(per_rank)
     emitted, surv = acc.download_survivors()
     n_sv = acc.model_info()[0]
-    ent = table_entries_min(P, grids)
-    flops = float(n_sv) * (3.0 * n_cand + 45.0 * ent)
-    line = {"what": f"exome200k (BASELINE configs[3]): the first {len(ivs)} of 200,000 exon-like intervals, capture 150-170, SVR n_sv={n_sv}, one timed pass on 1 GPU "
-                    f"({acc.window_count()} result windows; wall clock around score_condense_all)",
-            "value": n_cand / d1, "unit": "candidates/s", "seconds": d1, "dense_candidates": n_cand, "regions": len(regions),
-            "emitted_candidates": int(emitted.sum()), "survivors": int((surv["cand_index"] >= 0).sum()), "build_and_upload_seconds": t_build,
-            "roofline": {"bound": "fp64_valu", "achieved": flops / d1 / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / d1 / 1e12 / FP64_PEAK_TFLOPS,
-                         "kernel": "k_svr_dense (+ k_records, replay / condense: the whole pass is inside the clock)", "algorithmic_flops": flops,
-                         "table_entries_per_sv": ent,
-                         "hbm": {"achieved": ALG_BYTES_PER_CAND * n_cand / d1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ALG_BYTES_PER_CAND * n_cand / d1 / 1e9 / HBM_PEAK_GBS}}}
+    line = {"what": f"exome200k (BASELINE configs[3]): the first {len(ivs)} of 200,000 exon-like intervals, capture 150-170, SVR n_sv={n_sv}, cut {world} way(s) by the "
+                    f"kernels' cost model, one timed pass (rank 0: {acc.window_count()} result windows; wall clock around score_condense_all"
+                    f"{' + the gather of the survivors to rank 0' if distributed else ''}, max over ranks)",
+            "value": total / d1, "unit": "candidates/s", "seconds": d1, "dense_candidates": total, "dense_candidates_per_rank": per_rank, "regions": len(ivs),
+            "n_gpus": world, "scaling": "strong",
+            "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()), "build_and_upload_seconds": t_build}
+    if gather:
+        line["survivors_gathered"] = sum(gather.sizes) // 24
+    if world == 1:
+        ent = table_entries_min(P, grids)
+        flops = float(n_sv) * (3.0 * n_cand + 45.0 * ent)
+        line["roofline"] = {"bound": "fp64_valu", "achieved": flops / d1 / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / d1 / 1e12 / FP64_PEAK_TFLOPS,
+                            "kernel": "k_svr_dense (+ k_records, replay / condense: the whole pass is inside the clock)", "algorithmic_flops": flops,
+                            "table_entries_per_sv": ent,
+                            "hbm": {"achieved": ALG_BYTES_PER_CAND * n_cand / d1 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": ALG_BYTES_PER_CAND * n_cand / d1 / 1e9 / HBM_PEAK_GBS}}
     acc.close()
     del regions
     return line
+
+
+def exome_rates_by_sizes(args, device: int, stream: int, model_path: str, n_regions: int = 4096) -> dict:
+    """k_svr_dense on the exome regions that keep K capture sizes after the static skip of mipgen.cpp:429, K by K (the first n_regions exons):
+    regions of ONE size - half of an exome BED - share an arm factor between at most six candidates instead of thirty."""
+    from mipgen_amd import capi, workloads
+    P = capi.make_params(150, 170, score_method=capi.SCORE_SVR)
+    acc = capi.Accel(P, device=device, stream=stream)
+    acc.load_model_file(workloads.svr_model_path(os.path.dirname(model_path), workloads.practice62()[0], args.nsv, rho=workloads.MODEL_RHO["exome"]))
+    chrom_len, all_iv = workloads.exome_layout()
+    ivs = all_iv[:n_regions]
+    grids = acc.upload(workloads.build_exome(acc, chrom_len, ivs, P))
+    ks = [g.n_sizes for g in grids]
+    tot = float(sum(g.count for g in grids))
+    acc.set_timing(True)
+    out = {}
+    for K in sorted(set(ks)):
+        sub = [iv for iv, k in zip(ivs, ks) if k == K]
+        gr = acc.upload(workloads.build_exome(acc, chrom_len, sub, P))
+        n = sum(g.count for g in gr)
+        ms = []
+        for _ in range(3):
+            acc.score_window(0, capi.SCORE_SVR)
+            ms.append(acc.last_kernel_ms(0))
+        out[str(K)] = {"regions": len(sub), "dense_candidates": n, "candidates_share": n / tot, "k_svr_dense_ms": min(ms), "candidates_per_s": n / (min(ms) * 1e-3)}
+    acc.close()
+    return out
 
 
 def main() -> None:
@@ -585,28 +675,12 @@ def main() -> None:
     grids = acc.upload(regions)                            # inputs resident in HBM before the timed region
     n_cand = acc.batch_candidates()
     acc.set_timing(True)
-    surv_ptr, n_surv = acc.survivors_device_ptr()
-
-    class _DevView:                                        # the library's survivor array as a torch tensor (no copy): the gather's send buffer
-        def __init__(self, ptr, nbytes):
-            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-    send = torch.as_tensor(_DevView(surv_ptr, max(n_surv, 1) * 24), device=f"cuda:{local_rank}") if distributed else None
-    recv = None
-    if distributed:
-        sizes = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_surv * 24], dtype=torch.int64, device=xdev))
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(max(sizes), 24)
-        pad = torch.zeros(mx, dtype=torch.uint8, device=xdev)
-        if rank == 0:
-            recv = [torch.zeros(mx, dtype=torch.uint8, device=xdev) for _ in range(world)]
+    gather = SurvivorGather(acc, world, rank, local_rank, xdev) if distributed else None
 
     def step() -> None:
         acc.score_condense_all(m)
-        if distributed:
-            # the one exchange step of the path: condensed survivors -> rank 0 (RCCL gather; direct peer -> root transfers over xGMI)
-            pad[: n_surv * 24].copy_(send[: n_surv * 24])
-            dist.gather(pad, recv, dst=0)
+        if gather:
+            gather()                                        # the one exchange step of the path: condensed survivors -> rank 0
 
     # correctness gate of this measurement: rank 0 checks its batch against the oracle before anything is timed
     gate = None
@@ -637,26 +711,31 @@ def main() -> None:
         tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        per = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
-        dist.all_gather(per, torch.tensor([n_cand], dtype=torch.int64, device=xdev))
-        cand_per_rank = [int(t.item()) for t in per]
+        per = [torch.zeros(2, dtype=torch.int64, device=xdev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([n_cand, skipped_per_step], dtype=torch.int64, device=xdev))
+        cand_per_rank = [int(t[0].item()) for t in per]
+        skipped_per_rank = [int(t[1].item()) for t in per]  # every rank's own count: the ranks hold different regions
         total_cand = sum(cand_per_rank)
         rccl_ranks = dist.get_world_size()                  # what the process group itself reports
     else:
         total_cand = n_cand
         cand_per_rank = [n_cand]
+        skipped_per_rank = [skipped_per_step]
         rccl_ranks = 1
+    # the metric's own multi-GPU config beside the headline family, at every N: the first 65,536 exons cut `world` ways (collective calls: every rank)
+    exome_strong = None
+    if args.scale_base_regions > 0 and args.config == "practice62" and method == "svr" and not args.no_extras and not args.regions:
+        exome_strong = exome_line(args, local_rank, stream, model_path, n_regions=args.scale_base_regions, rank=rank, world=world, distributed=distributed, xdev=xdev)
 
     if rank == 0:
         emitted, surv = acc.download_survivors()
         survivors_gathered = 0
         if distributed:
-            survivors_gathered = sum(sizes) // 24
-            head = recv[0][:sizes[0]].cpu().numpy().view(capi.SURVIVOR_DTYPE)
+            survivors_gathered = sum(gather.sizes) // 24
+            head = gather.recv[0][:gather.sizes[0]].cpu().numpy().view(capi.SURVIVOR_DTYPE)
             assert np.array_equal(head["cand_index"], surv["cand_index"]), "rank 0's own slice of the gather differs from its survivors"
-        # with --dynamic-skip only the candidates that were scored count (rank 0's skipped share is known here; N > 1: every rank skips alike on the
-        # sharded exome, the line says what it counted)
-        value = (total_cand - skipped_per_step) * args.steps / dt
+        # with --dynamic-skip only the candidates that were scored count: the skipped candidates of EVERY rank are left out
+        value = (total_cand - sum(skipped_per_rank)) * args.steps / dt
         k_ms = float(np.mean(kernel_ms))
         n_sv = acc.model_info()[0] if method == "svr" else 0
         alg_bytes = ALG_BYTES_PER_CAND * n_cand
@@ -705,6 +784,8 @@ def main() -> None:
             "n_gpus": world, "rccl_ranks": rccl_ranks, "backend": args.backend if distributed else None, "shared_gpus": bool(args.share_gpus and distributed),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scale_family": (f"{args.config}, {args.scaling} scaling: `value` of every --gpus N line of this family is the same workload "
+                             f"{'grown N-fold (the same work per GPU)' if args.scaling == 'weak' else 'cut N ways'}; the exome (configs[3]) is `exome_strong`"),
             "config": {"workload": desc, "n_sv": n_sv, "regions_rank0": len(regions), "dense_candidates_rank0": n_cand,
                        "dense_candidates_all_ranks": total_cand, "dense_candidates_per_rank": cand_per_rank, "result_windows_rank0": acc.window_count(),
                        "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()),
@@ -712,11 +793,15 @@ def main() -> None:
                        "emitted_candidates_per_s_rank0": float(emitted.sum()) * args.steps / dt,
                        "survivors_gathered_per_step": survivors_gathered,
                        "dynamic_skip": bool(args.dynamic_skip), "skipped_candidates_per_step_rank0": int(skipped_per_step),
+                       "skipped_candidates_per_step_per_rank": skipped_per_rank,
                        "dense_candidates_covered_per_s": total_cand * args.steps / dt},
             "roofline": roof,
             "parity_checked": bool(gate), "parity_gate": gate,
             "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},
         }
+        if exome_strong:
+            exome_strong["compare_with"] = "exome_strong.value of the --gpus 1 line (the same BED on one GPU) - never with `value`, which is another workload"
+            out["exome_strong"] = exome_strong
         if method == "svr":
             out["fp64"] = {"pairs_per_launch": n_cand * n_sv, "pairs_per_s": n_cand * n_sv / (k_ms * 1e-3),
                            "naive_equiv_tflops": n_cand * n_sv * 600.0 / (k_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS}
@@ -733,13 +818,14 @@ def main() -> None:
         # ---- extras (N = 1, default workload): throughput vs nSV, and the logistic scorer on the same batch -------------------------
         if not args.no_extras and not distributed and args.config == "practice62" and method == "svr":
             extra = []
-            if args.scale_base_regions > 0:
-                # the N = 1 point of the scaling curve: the BED that `--gpus N` (N > 1) cuts N ways, on this one GPU, in this run
-                sb = exome_line(args, local_rank, stream, model_path, n_regions=args.scale_base_regions)
-                out["scale_base"] = {"value": sb["value"], "unit": sb["unit"], "workload": sb["what"], "seconds": sb["seconds"],
-                                     "dense_candidates": sb["dense_candidates"], "regions": sb["regions"], "n_gpus": 1, "scaling": "strong",
+            if exome_strong:
+                # the N = 1 point of the exome's strong-scaling curve under its round-4 name as well
+                out["scale_base"] = {"value": exome_strong["value"], "unit": exome_strong["unit"], "workload": exome_strong["what"], "seconds": exome_strong["seconds"],
+                                     "dense_candidates": exome_strong["dense_candidates"], "regions": exome_strong["regions"], "n_gpus": 1, "scaling": "strong",
                                      "equivalent_command": f"python bench.py --gpus 1 --config exome --regions {args.scale_base_regions} --scaling strong",
-                                     "roofline": sb["roofline"]}
+                                     "roofline": exome_strong["roofline"]}
+                extra.append({"what": "k_svr_dense on the exome regions that keep K capture sizes (mipgen.cpp:429), K by K: the first 4,096 exons",
+                              "by_capture_sizes": exome_rates_by_sizes(args, local_rank, stream, model_path)})
             if args.sustain_seconds > 0:
                 # the headline again, long enough for an outside observer (the driver's GPU-busy sampler) to see: same step, >= 2 s
                 reps = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)

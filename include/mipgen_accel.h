@@ -53,8 +53,9 @@ extern "C" {
  * copy fields saturated at 65535 mean "look the count up"; survivor / collapse downloads are validated per result window.
  * 3: SVR requests on parameter sets outside the tiled kernel's limits succeed (list route) instead of failing with MIPGEN_E_INVALID; a download may fail
  * with MIPGEN_E_STATE when a print-exact re-score list overflowed; new entry points (mipgen_accel_window_uniqueness_begin / _flags_region / _end,
- * mipgen_accel_set_dynamic_skip / _skipped_candidates / _skip_state). */
-#define MIPGEN_ACCEL_ABI_VERSION 3
+ * mipgen_accel_set_dynamic_skip / _skipped_candidates / _skip_state).
+ * 4: new entry points only (mipgen_accel_rescore_survivors / _download_survivor_scores, mipgen_accel_window_views, mipgen_accel_synchronize). */
+#define MIPGEN_ACCEL_ABI_VERSION 4
 
 #define MIPGEN_MAX_ARM_PAIRS 256     /* flattened (ext,lig) list, enumeration order */
 #define MIPGEN_N_FEATURES 192        /* SVMipv4.cpp:14 TOTAL_FEATURES */
@@ -300,6 +301,32 @@ int mipgen_accel_collapse(mipgen_accel* h);
 int mipgen_accel_region_bases(const mipgen_accel* h, int32_t region, int64_t* first_entry, int32_t* n_bases);
 /* window >= 0: the entries of that window's regions; window < 0: the whole batch (after mipgen_accel_score_condense_all) */
 int mipgen_accel_download_collapsed(mipgen_accel* h, int32_t window, int32_t* best_scan_index, int64_t capacity);
+
+/* ---- mixed designs: the SVR score of every condensed survivor, computed where the survivors are --------------------------------------
+ * The reference re-scores the MIPs its pick stage tests one at a time (mipgen.cpp:1523-1527, 1533-1537, 1546-1550, 1873-1877: get_parameters +
+ * predict_value, score overwritten in place).  mipgen_accel_rescore_survivors scores EVERY condensed survivor of the window scored + replayed
+ * last in one list call on the device (the same kernels and values as mipgen_accel_score_candidates on that list) and keeps the values in the
+ * handle, slot for slot beside the survivors (NaN where a slot holds no survivor); the selection stage looks them up. */
+int mipgen_accel_rescore_survivors(mipgen_accel* h);
+int mipgen_accel_download_survivor_scores(mipgen_accel* h, int32_t window, double* svr, int64_t capacity /* >= 2 * n_positions of the window */);
+
+/* ---- device-side views of a result window ---------------------------------------------------------------------------------------------
+ * For a caller that moves results between devices itself - the multi-GPU front end posts these arrays to GPU 0 with one grouped RCCL
+ * send / receive per window instead of taking them down each device's own PCIe link.  Pointers into the handle's own device arrays, valid
+ * until the next mipgen_accel_upload_regions / mipgen_accel_destroy (text: until the next mipgen_accel_format_all_mips); a field is NULL
+ * when the window does not hold it.  mipgen_accel_synchronize waits for everything the handle has enqueued, so that another stream may read
+ * them.  cand_index of the survivors is batch-wide: subtract first_candidate for the window-relative index of mipgen_accel_window_info. */
+typedef struct mipgen_window_views {
+    const void* emitted;             /* int64 [n_emitted]: emitted candidates per region of the window */
+    const void* survivors;           /* mipgen_survivor [n_survivors] = 2 per scan position */
+    const void* collapsed;           /* int32 [n_collapsed] = 2 per base, region after region (mipgen_accel_collapse) */
+    const void* survivor_svr;        /* double [n_survivors] (mipgen_accel_rescore_survivors) */
+    const void* text;                /* all_mips text of the last mipgen_accel_format_all_mips, if this is the window it ran on */
+    int64_t n_emitted, n_survivors, n_collapsed, n_text_bytes;
+    int64_t first_candidate;
+} mipgen_window_views;
+int mipgen_accel_window_views(mipgen_accel* h, int32_t window, mipgen_window_views* out);
+int mipgen_accel_synchronize(mipgen_accel* h);
 
 /* ---- section 8f-4: the all_mips records of a window, formatted on the device -----------------------------------------------------
  * print_details (mipgen.cpp:765-794) for every candidate the replay marked as constructed, in the reference's generation order

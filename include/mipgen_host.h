@@ -130,6 +130,12 @@ int mipgen_design_set_devices(mipgen_design* d, int32_t n_devices);
 int mipgen_design_set_api_device(mipgen_design* d, int32_t device);
 int mipgen_design_set_window_candidates(mipgen_design* d, int64_t max_candidates);
 int mipgen_design_set_timing(mipgen_design* d, int32_t on);
+/* How the device workers' result windows reach the selection stage (option -gpu_gather pcie|rccl).  0 = pcie (default): every worker downloads its
+ * windows over its own GPU's PCIe link.  1 = rccl: per window ONE grouped RCCL send / receive moves the window's emitted counts, condensed survivors,
+ * collapse results (+ SVR re-scores of a mixed design, + all_mips text) from the worker's HBM into a packed buffer on GPU 0 over xGMI, one D2H copy
+ * hands it to the selection stage while the workers score their next windows (the gather of /root/reference-equivalent per-region tables that
+ * mipgen.cpp:503-515 consumes in region order).  Needs one visible GPU per device worker. */
+int mipgen_design_set_gather(mipgen_design* d, int32_t rccl);
 
 /* The selection stage's private copy of glibc's never-seeded rand() stream (mipgen.cpp:1863 picks the first strand with rand() % 2):
  * its first n values, for checking it against the C library's. */

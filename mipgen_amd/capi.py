@@ -23,7 +23,7 @@ MAX_OLIGO = 64
 
 SCORE_LOGISTIC, SCORE_SVR, SCORE_MIXED = 0, 1, 2
 
-ABI_VERSION = 3          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
+ABI_VERSION = 4          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
 FLAG_VALID, FLAG_GUARD, FLAG_MAPPING, FLAG_MASKING, FLAG_SNP, FLAG_HAS_SNP_MIP = 1, 2, 4, 8, 16, 32
 
 
@@ -71,6 +71,11 @@ class Survivor(C.Structure):
 
 class RecordNames(C.Structure):
     _fields_ = [("chr", C.c_char_p), ("label", C.c_char_p), ("feature_start", C.c_int32), ("feature_stop", C.c_int32)]
+
+
+class WindowViews(C.Structure):      # mipgen_window_views: device pointers of a result window
+    _fields_ = [("emitted", C.c_void_p), ("survivors", C.c_void_p), ("collapsed", C.c_void_p), ("survivor_svr", C.c_void_p), ("text", C.c_void_p),
+                ("n_emitted", C.c_int64), ("n_survivors", C.c_int64), ("n_collapsed", C.c_int64), ("n_text_bytes", C.c_int64), ("first_candidate", C.c_int64)]
 
 
 SURVIVOR_DTYPE = np.dtype([("cand_index", "<i8"), ("score", "<f8"), ("record", "<u8")])
@@ -321,6 +326,12 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_format_all_mips.argtypes = [vp, C.POINTER(RecordNames), C.c_char_p, C.c_int64, i64p, i64p]
     lib.mipgen_accel_download_text.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mipgen_accel_long_range_content_batch.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p, C.POINTER(C.c_double)]
+    lib.mipgen_accel_rescore_survivors.argtypes = [vp]
+    lib.mipgen_accel_download_survivor_scores.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_int64]
+    lib.mipgen_accel_window_views.argtypes = [vp, C.c_int32, C.POINTER(WindowViews)]
+    lib.mipgen_accel_synchronize.argtypes = [vp]
+    for name in ("rescore_survivors", "download_survivor_scores", "window_views", "synchronize"):
+        getattr(lib, "mipgen_accel_" + name).restype = C.c_int
     for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
@@ -346,6 +357,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
     "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_window_uniqueness_begin", "mipgen_accel_window_flags_region",
     "mipgen_accel_window_uniqueness_end", "mipgen_accel_set_dynamic_skip", "mipgen_accel_skipped_candidates", "mipgen_accel_skip_state", "mipgen_accel_set_print_exact", "mipgen_accel_set_logistic_subruns",
+    "mipgen_accel_rescore_survivors", "mipgen_accel_download_survivor_scores", "mipgen_accel_window_views", "mipgen_accel_synchronize",
 ]
 
 
@@ -566,6 +578,23 @@ class Accel:
         out = np.empty(max(n, 1), dtype=np.int32)
         self._check(self.lib.mipgen_accel_download_collapsed(self.h, window, out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0]))
         return out[:n]
+
+    def rescore_survivors(self, window: Optional[int] = None) -> np.ndarray:
+        """SVR score of every condensed survivor of the window scored + replayed last (NaN where a slot holds no survivor)."""
+        self._check(self.lib.mipgen_accel_rescore_survivors(self.h))
+        w = 0 if window is None else window
+        n = 2 * self.window_info(w)["n_positions"]
+        out = np.empty(max(n, 1), dtype=np.float64)
+        self._check(self.lib.mipgen_accel_download_survivor_scores(self.h, w, out.ctypes.data_as(C.POINTER(C.c_double)), max(n, 1)))
+        return out[:n]
+
+    def window_views(self, window: int) -> "WindowViews":
+        v = WindowViews()
+        self._check(self.lib.mipgen_accel_window_views(self.h, window, C.byref(v)))
+        return v
+
+    def synchronize(self) -> None:
+        self._check(self.lib.mipgen_accel_synchronize(self.h))
 
     def survivors_device_ptr(self) -> Tuple[int, int]:
         p, n = C.c_void_p(), C.c_int64()

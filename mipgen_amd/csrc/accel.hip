@@ -49,6 +49,10 @@ hipError_t mipgen_launch_scatter_scores(hipStream_t, const double* src, const in
 hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t, const DevParams*, const DevRegion*, int r0, int r1, const mipgen_survivor* surv, int64_t n, int64_t cand0,
                                                   double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx, unsigned int* count, unsigned int cap);
 hipError_t mipgen_launch_scatter_surv_scores(hipStream_t, const double* src, const int64_t* idx, int cap, const unsigned int* n_dev, mipgen_survivor* surv, unsigned int* over);
+hipError_t mipgen_launch_surv_keep(hipStream_t, const mipgen_survivor* surv, int64_t n, int64_t* keep, double* svr);
+hipError_t mipgen_launch_surv_candidates(hipStream_t, const DevParams*, const DevRegion*, int r0, int r1, const mipgen_survivor* surv, int64_t n, int64_t cand0,
+                                         const int64_t* offs, mipgen_candidate* out, int64_t* out_idx);
+hipError_t mipgen_launch_scatter_f64(hipStream_t, const double* src, const int64_t* idx, int64_t n, double* dst);
 hipError_t mipgen_launch_long_range(hipStream_t, int n, const char* seqs, const int64_t* offs, const int32_t* lens, const int32_t* denoms,
                                     const LrcMers*, double* out);
 hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_pos, const DevParams*, int n_pairs, int n_sizes_max, const DevRegion*,
@@ -105,7 +109,7 @@ struct Window {
     int64_t cand0 = 0, n_cand = 0;   // batch-wide candidate index of the first candidate; candidates
     int64_t pos0 = 0, n_pos = 0;     // batch-wide scan-position index; positions
     int log_tile0 = 0, n_log_tiles = 0, svr_tile0 = 0, n_svr_tiles = 0, col_tile0 = 0, n_col_tiles = 0, ld_tile0 = 0, n_ld_tiles = 0;
-    int n_svr_few = 0;               // the LAST n_svr_few of the window's dense SVR tiles run with the few-sizes thread geometry (regions of one or two capture sizes)
+    int n_svr_few = 0;               // the LAST n_svr_few of the window's dense SVR tiles run with the few-sizes thread geometry (regions of one capture size)
     std::vector<int> lvl_tile0;      // dense SVR tiles by capture-size run: run l = svr_tiles_lvl[lvl_tile0[l], lvl_tile0[l + 1])
     int lvl0_few = 0;                // ... the last lvl0_few tiles of run 0 with the few-sizes geometry (such regions have one run)
     int64_t base0 = 0, n_base_entries = 0;   // collapsed entries (2 per base) of the window inside the batch-wide array
@@ -194,7 +198,7 @@ struct mipgen_accel {
     HostConsts* dconsts = nullptr;
     HostConsts hconsts;
     SvrGeom geom;
-    SvrGeom geom_few;                // thread geometry of the tiles of regions that keep one or two capture sizes: more, shorter arm-pair chunks
+    SvrGeom geom_few;                // thread geometry of the tiles of regions that keep one capture size: more, shorter arm-pair chunks
     bool have_few = false;           // (twice the chunks, half the lanes per chunk: such a tile fills a quarter of the main geometry's lanes)
     // model
     int n_sv = 0;
@@ -251,6 +255,9 @@ struct mipgen_accel {
     bool print_exact = true;
     double sum_abs_coef = 0.0;
     DevBuf<mipgen_candidate> pb_cands;
+    // mixed designs: SVR score of every condensed survivor of the batch (mipgen_accel_rescore_survivors), slot for slot beside `survivors`
+    DevBuf<double> surv_svr;
+    DevBuf<int64_t> rs_keep, rs_offs, rs_idx;
     DevBuf<int64_t> pb_idx;
     DevBuf<double> pb_scores;
     DevBuf<unsigned int> pb_count;
@@ -272,7 +279,8 @@ struct mipgen_accel {
     unsigned long long skipped_total = 0;
     bool skip_count_valid = false;
     unsigned int* pb_over = nullptr;         // host-mapped word: entries a re-score list could not hold (checked at the next download: pb_check)
-    std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed
+    std::vector<uint8_t> win_state;          // per result window: bit 0 = survivors / emitted counts are of the scores it holds now (replayed), bit 1 = collapsed,
+                                             // bit 2 = surv_svr holds the SVR scores of its current survivors
     DevBuf<double> model_t, sv_norm, sv_coef, sv_center;   // the model centred and transposed for the survivor-list scorer (kernels_svr_gemm.hip)
     int n_sv_pad = 0;
     double kmer_count_ms = -1.0;             // genome pass of the last mipgen_accel_count_oligo_copies
@@ -407,8 +415,8 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
         h->svr_geometry_error = msg;
         G.wpc = 1;
     }
-    // Regions that keep ONE or TWO capture sizes after the static skip of mipgen.cpp:429 (short exons: half of an exome BED) hold few (position,
-    // size) items per tile - the tile's positions are bound by its LDS, not by the lanes -, so with the main geometry half of the wavefronts own no
+    // Regions that keep ONE capture size after the static skip of mipgen.cpp:429 (short exons: half of an exome BED) hold few (position, size)
+    // items per tile - the tile's positions are bound by its LDS, not by the lanes -, so with the main geometry half of the wavefronts own no
     // candidate while the others walk fifteen pairs each.  Their tiles run with twice the chunks of half the length on two wavefronts each.
     h->geom_few = G;
     h->have_few = false;
@@ -1066,16 +1074,17 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
         // the few-sizes geometry is a launch of its own: taken when the window holds enough such regions to fill the chip a few times over
         // (a handful of them stay with the main launch: an extra launch ends with the tail of its last tile)
         int n_few_regions = 0;
-        for (int i = w.r0; i < w.r1; i++) if (h->hregions[i].n_pos > 0 && h->hregions[i].n_sizes >= 1 && h->hregions[i].n_sizes <= 2) n_few_regions++;
+        for (int i = w.r0; i < w.r1; i++) if (h->hregions[i].n_pos > 0 && h->hregions[i].n_sizes == 1) n_few_regions++;
         const bool win_few = h->have_few && n_few_regions >= h->n_cu;
         std::vector<uint8_t> st_few;                           // per tile of this window: few-sizes geometry?
         for (int i = w.r0; i < w.r1; i++) {
             const DevRegion& d = h->hregions[i];
             if (d.n_pos <= 0 || d.n_sizes <= 0) continue;
-            // the SHAPE of such a region's tiles does not depend on which launch takes them (a score's last bits depend on where its tile starts:
-            // the window sums are differences of tile-relative prefix sums), so a region scores bit-identically in any window or shard
-            const bool few = win_few && d.n_sizes <= 2;
-            const Shape& shape = shape_of(d, h->have_few && d.n_sizes <= 2);
+            // Regions of ONE capture size only, and with the shape the main launch would give them (their positions per tile are bound by the LDS -
+            // 70-90, inside either geometry's lanes): a score's last bits depend on where its tile starts - the window sums are differences of
+            // tile-relative prefix sums -, and a region must score bit-identically in any window or shard, whichever launch takes its tiles.
+            const bool few = win_few && d.n_sizes == 1;
+            const Shape& shape = shape_of(d, false);
             if (shape.runs.empty()) { svr_lds = (size_t)1 << 30; continue; }
             svr_lds = std::max(svr_lds, shape.lds);
             const int Cmax = D.max_capture - d.k0 * D.inc;
@@ -1118,7 +1127,7 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
                 for (size_t k = 0; k < n; k++) if (st[t0 + k].level == lvl) st_lvl.push_back(st[t0 + k]);      // (order kept: run 0 ends with the few-sizes tiles)
                 w.lvl_tile0.push_back((int)st_lvl.size());
             }
-            w.lvl0_few = w.n_svr_few;                          // regions of one or two sizes have one run
+            w.lvl0_few = w.n_svr_few;                          // regions of one size have one run
         }
     }
     h->svr_batch_error.clear();
@@ -1706,6 +1715,94 @@ int mipgen_accel_survivors_device_ptr(const mipgen_accel* h, void** survivors_de
     if (survivors_dev) *survivors_dev = h->survivors.p;
     if (n_survivors) *n_survivors = 2 * h->total_pos;
     return MIPGEN_OK;
+}
+
+// ---- mixed designs: every condensed survivor of the window scored last through the SVR, on the device ------------------------------------------
+// The reference re-scores the MIPs its pick stage tests, one at a time (mipgen.cpp:1523-1527, 1533-1537, 1546-1550, 1873-1877); here all survivors
+// of the window go through the list scorer in ONE call - candidate list built on the device from the survivor array (slot order), features +
+// matrix-core SVR (short lists: the literal per-candidate kernel), print-exact re-score - and the values stay in HBM beside the survivors
+// (slot for slot; NaN where a slot holds no survivor).  Same kernels, same values as mipgen_accel_score_candidates on the same list.
+int mipgen_accel_rescore_survivors(mipgen_accel* h)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    if (!h->replayed || h->cur_window < 0) return fail(MIPGEN_E_STATE, "mipgen_accel_replay_condense has not run on these scores");
+    if (h->model.p == nullptr) return fail(MIPGEN_E_MODEL, "SVR scoring requested but no model is loaded");
+    const int w = h->cur_window;
+    const Window& W = h->windows[(size_t)w];
+    const int64_t n = 2 * W.n_pos;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->surv_svr.reserve((size_t)std::max<int64_t>(2 * h->total_pos, 1))) return MIPGEN_E_NOMEM;
+    if (n > 0) {
+        if (h->rs_keep.reserve((size_t)n + 1) || h->rs_offs.reserve((size_t)n + 1) || h->rs_idx.reserve((size_t)n) || h->cand_in.reserve((size_t)n)) return MIPGEN_E_NOMEM;
+        const mipgen_survivor* surv = h->survivors.p + 2 * W.pos0;
+        double* svr = h->surv_svr.p + 2 * W.pos0;
+        HIP_TRY(mipgen_launch_surv_keep(h->stream, surv, n, h->rs_keep.p, svr));
+        size_t temp_bytes = 0;
+        HIP_TRY(mipgen_scan_i64(h->stream, nullptr, &temp_bytes, h->rs_keep.p, h->rs_offs.p, n + 1));
+        if (h->fmt_temp.reserve(temp_bytes + 16)) return MIPGEN_E_NOMEM;
+        HIP_TRY(mipgen_scan_i64(h->stream, h->fmt_temp.p, &temp_bytes, h->rs_keep.p, h->rs_offs.p, n + 1));
+        HIP_TRY(mipgen_launch_surv_candidates(h->stream, h->dp, h->regions.p, W.r0, W.r1, surv, n, W.cand0, h->rs_offs.p, h->cand_in.p, h->rs_idx.p));
+        int64_t m = 0;
+        HIP_TRY(hipMemcpyAsync(&m, h->rs_offs.p + n, sizeof m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (m > 0) {
+            if (m > INT32_MAX) return fail(MIPGEN_E_INVALID, "too many survivors in one window for the list scorer");
+            if (h->cand_scores.reserve((size_t)m) || h->cand_records.reserve((size_t)m)) return MIPGEN_E_NOMEM;
+            const bool batched = m >= 256;                                   // as mipgen_accel_score_candidates decides
+            if (batched) {
+                if (h->cand_feats.reserve((size_t)m * MIPGEN_N_FEATURES)) return MIPGEN_E_NOMEM;
+                HIP_TRY(mipgen_launch_features_batch(h->stream, (int)m, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->cand_records.p,
+                                                     h->cand_feats.p));
+                HIP_TRY(mipgen_launch_svr_gemm(h->stream, (int)m, h->cand_feats.p, h->cand_records.p, h->model_t.p, h->sv_norm.p, h->sv_coef.p, h->sv_center.p, h->n_sv_pad,
+                                               h->gamma, h->rho, h->cand_scores.p));
+                if (int rc = fix_print_boundaries(h, 0, 0, h->cand_in.p, h->cand_scores.p, h->cand_records.p, m)) return rc;
+            } else {
+                HIP_TRY(mipgen_launch_candidates(h->stream, (int)m, h->dp, h->regions.p, h->cand_in.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts,
+                                                 h->model.p, h->n_sv, h->gamma, h->rho, MIPGEN_SCORE_SVR, h->cand_scores.p, h->cand_records.p, nullptr, nullptr, 0, nullptr));
+            }
+            HIP_TRY(mipgen_launch_scatter_f64(h->stream, h->cand_scores.p, h->rs_idx.p, m, svr));
+        }
+    }
+    if ((size_t)w < h->win_state.size()) h->win_state[(size_t)w] |= 4;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_download_survivor_scores(mipgen_accel* h, int32_t window, double* svr, int64_t capacity)
+{
+    if (!h || !svr || window < 0 || window >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "bad arguments");
+    if ((size_t)window >= h->win_state.size() || !(h->win_state[(size_t)window] & 4)) return fail(MIPGEN_E_STATE, "mipgen_accel_rescore_survivors has not run on the current survivors of window %d", window);
+    const Window& W = h->windows[(size_t)window];
+    if (capacity < 2 * W.n_pos) return fail(MIPGEN_E_INVALID, "capacity too small");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc_pb = pb_check(h)) return rc_pb;
+    if (W.n_pos) HIP_TRY(hipMemcpy(svr, h->surv_svr.p + 2 * W.pos0, (size_t)(2 * W.n_pos) * sizeof(double), hipMemcpyDeviceToHost));
+    return MIPGEN_OK;
+}
+
+// ---- device-side views of a result window: for a caller that moves results between devices itself (the RCCL gather of the multi-GPU front end) ----
+int mipgen_accel_window_views(mipgen_accel* h, int32_t window, mipgen_window_views* out)
+{
+    if (!h || !out || window < 0 || window >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "bad arguments");
+    const uint8_t st = (size_t)window < h->win_state.size() ? h->win_state[(size_t)window] : 0;
+    if (!(st & 1)) return fail(MIPGEN_E_STATE, "window %d holds no current survivors (replay + condense first)", window);
+    const Window& W = h->windows[(size_t)window];
+    memset(out, 0, sizeof *out);
+    out->emitted = h->emitted_per_region.p + W.r0; out->n_emitted = W.r1 - W.r0;
+    out->survivors = h->survivors.p + 2 * W.pos0; out->n_survivors = 2 * W.n_pos;
+    if (st & 2) { out->collapsed = h->collapsed.p + W.base0; out->n_collapsed = W.n_base_entries; }
+    if (st & 4) out->survivor_svr = h->surv_svr.p + 2 * W.pos0;
+    if (window == h->cur_window && h->fmt_bytes > 0) { out->text = h->fmt_text.p; out->n_text_bytes = h->fmt_bytes; }
+    out->first_candidate = W.cand0;
+    return MIPGEN_OK;
+}
+
+int mipgen_accel_synchronize(mipgen_accel* h)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return pb_check(h);
 }
 
 // ---- section 8f-3: arm-oligo copy numbers by exact k-mer counting (opt-in replacement of the bwa round trip) ----------------

@@ -639,6 +639,63 @@ __global__ __launch_bounds__(256) void k_scatter_surv_scores(const double* __res
     if (i == 0 && over && *n_dev > (unsigned int)cap) *over = *n_dev - (unsigned int)cap;
 }
 
+// ---- every condensed survivor of a window as a candidate list, in slot order (mixed designs: the pick stage re-scores survivors with the SVR,
+// mipgen.cpp:1523-1527,1873-1877 - all of them are scored here in one list call and the selection stage looks the values up) ----
+__global__ __launch_bounds__(256) void k_surv_keep(const mipgen_survivor* __restrict__ surv, int64_t n, int64_t* __restrict__ keep, double* __restrict__ svr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    keep[i] = (i < n && surv[i].cand_index >= 0) ? 1 : 0;
+    if (i < n) svr[i] = __longlong_as_double(0x7ff8000000000000ll);         // NaN: no survivor in this slot
+}
+__global__ __launch_bounds__(256) void k_surv_candidates(const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, int r0, int r1,
+                                                         const mipgen_survivor* __restrict__ surv, int64_t n, int64_t cand0, const int64_t* __restrict__ offs,
+                                                         mipgen_candidate* __restrict__ out, int64_t* __restrict__ out_idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mipgen_survivor sv = surv[i];
+    if (sv.cand_index < 0) return;
+    const int64_t idx = sv.cand_index - cand0;                             // window-relative, like DevRegion::out_off
+    const int A = P->n_pairs;
+    int lo = r0, hi = r1 - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (regions[mid].out_off <= idx) lo = mid; else hi = mid - 1; }
+    const DevRegion& R = regions[lo];
+    const int64_t local = idx - R.out_off;
+    const int a_i = (int)(local % A);
+    const int64_t row = local / A;
+    const int64_t rest = row >> 1;
+    const int ki = (int)(rest % R.n_sizes), pi = (int)(rest / R.n_sizes);
+    mipgen_candidate c;
+    c.region = lo; c.scan_start = R.first_pos + pi; c.capture_size = P->max_capture - (R.k0 + ki) * P->inc;
+    c.ext_len = P->arm_ext[a_i]; c.lig_len = P->arm_lig[a_i]; c.strand = (int)(row & 1);
+    const int64_t at = offs[i];
+    out[at] = c; out_idx[at] = i;
+}
+__global__ __launch_bounds__(256) void k_scatter_f64(const double* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, double* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
+}
+extern "C" hipError_t mipgen_launch_surv_keep(hipStream_t stream, const mipgen_survivor* surv, int64_t n, int64_t* keep, double* svr)
+{
+    hipLaunchKernelGGL(k_surv_keep, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, surv, n, keep, svr);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_surv_candidates(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, const mipgen_survivor* surv,
+                                                    int64_t n, int64_t cand0, const int64_t* offs, mipgen_candidate* out, int64_t* out_idx)
+{
+    if (n <= 0 || r1 <= r0) return hipSuccess;
+    hipLaunchKernelGGL(k_surv_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P, regions, r0, r1, surv, n, cand0, offs, out, out_idx);
+    return hipGetLastError();
+}
+extern "C" hipError_t mipgen_launch_scatter_f64(hipStream_t stream, const double* src, const int64_t* idx, int64_t n, double* dst)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, idx, n, dst);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mipgen_launch_print_boundary_scan_surv(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, const mipgen_survivor* surv,
                                                              int64_t n, int64_t cand0, double tol_rel, double tol_abs, mipgen_candidate* out, int64_t* out_idx,
                                                              unsigned int* count, unsigned int cap)

@@ -20,6 +20,7 @@
 
 #include "../../include/mipgen_host.h"
 #include "mipgen_host.hpp"
+#include "gather.hpp"
 
 using namespace mipgen;
 
@@ -66,6 +67,8 @@ struct mipgen_design {
     std::mutex copies_mu;
     // front-end knobs (mipgen_design_set_*; the command line's -gpus / -gpu_window_candidates / -gpu_timing extension options): no environment
     int n_devices = 0;                           // device workers of mipgen_design_run (0 = every visible device)
+    int gather_rccl = 0;                         // -gpu_gather rccl: the workers' result windows travel to GPU 0 over RCCL / xGMI and come down ONE PCIe link
+                                                 // (gather.cpp); pcie (default): every device's windows come down its own link
     int64_t window_candidates = 0;               // cap on the candidates of one result window (0 = the default policy)
     bool timing = false;                         // stage timings on stderr
     // the per-region "[mipgen] feature #N" lines of stderr (mipgen.cpp:417): the same bytes in the same order, written a few KB at a time -
@@ -111,6 +114,7 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         finalize_options(o);
         d->timing = o.arg("-gpu_timing") == "on";
         d->n_devices = std::max(0, std::atoi(o.arg("-gpus").c_str()));
+        d->gather_rccl = o.arg("-gpu_gather") == "rccl" ? 1 : 0;
         d->window_candidates = std::max<int64_t>(0, std::atoll(o.arg("-gpu_window_candidates").c_str()));
         d->model_path = o.file_dir + "mipgen_svr.model";                                                              // mipgen.cpp:409
         Outputs& out = d->out;
@@ -393,6 +397,12 @@ int mipgen_design_set_devices(mipgen_design* d, int32_t n_devices)
     d->n_devices = n_devices;
     return 0;
 }
+int mipgen_design_set_gather(mipgen_design* d, int32_t rccl)
+{
+    if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
+    d->gather_rccl = rccl ? 1 : 0;
+    return 0;
+}
 int mipgen_design_set_window_candidates(mipgen_design* d, int64_t max_candidates)
 {
     if (!d || max_candidates < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad argument");
@@ -433,6 +443,18 @@ struct WindowResult {
     std::vector<uint64_t> records;
     std::vector<uint8_t> mask;
     std::vector<char> text;                      // the window's all_mips records, formatted on the device, numbered from the worker's own first record
+    // what the consumer reads: the vectors above (-gpu_gather pcie: the worker downloaded them) or the packed buffer of the RCCL gather
+    const int64_t* emitted_p = nullptr;
+    mipgen_survivor* surv_p = nullptr;
+    const double* svr_p = nullptr;
+    const int32_t* collapsed_p = nullptr;
+    const char* text_p = nullptr;
+    int64_t text_n = 0;
+    void point_at_own() { emitted_p = emitted.data(); surv_p = surv.data(); svr_p = svr.data(); collapsed_p = collapsed.data(); text_p = text.data(); text_n = (int64_t)text.size(); }
+    // -gpu_gather rccl: the window's arrays in the worker's HBM (nothing was downloaded), the window's first candidate (survivor indices are batch-wide there)
+    bool on_device = false;
+    mipgen_window_views views;
+    int64_t c0 = 0, n_surv = 0;
     int64_t n_rec = 0;                           // how far they advance the design-wide all_mip_counter
     bool has_text = false;
     bool last = false;
@@ -478,7 +500,21 @@ struct Channel {                                 // worker -> consumer, at most 
         cv.notify_all();
         return r;
     }
+    std::unique_ptr<WindowResult> try_pop()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (q.empty()) return nullptr;
+        auto r = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return r;
+    }
     void stop() { std::lock_guard<std::mutex> lk(m); abort = true; cv.notify_all(); }
+    // -gpu_gather rccl: windows of this worker whose arrays the consumer has finished reading from the worker's HBM (the worker must not overwrite
+    // its text buffer, nor destroy its handle, before)
+    int transferred = 0;
+    void mark_transferred() { std::lock_guard<std::mutex> lk(m); transferred++; cv.notify_all(); }
+    bool wait_transferred(int n) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return transferred >= n || abort; }); return transferred >= n; }
 };
 
 struct SurvivorRescorer {                        // the SVR scores the worker computed for every survivor of the region
@@ -489,11 +525,11 @@ struct SurvivorRescorer {                        // the SVR scores the worker co
     {
         auto* self = (SurvivorRescorer*)ctx;
         const int64_t k = 2 * (self->pos0 + (c->scan_start - self->g->first_pos)) + c->strand;
-        if (c->scan_start < self->g->first_pos || c->scan_start >= self->g->first_pos + self->g->n_pos || self->w->surv[(size_t)k].cand_index < 0) {
+        if (c->scan_start < self->g->first_pos || c->scan_start >= self->g->first_pos + self->g->n_pos || self->w->surv_p[(size_t)k].cand_index < 0) {
             std::cerr << "[mipgen] re-score of a candidate that did not survive condense" << std::endl;
             throw 20;
         }
-        return self->w->svr[(size_t)k];
+        return self->w->svr_p[(size_t)k];
     }
 };
 
@@ -584,6 +620,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     // records the workers before this one wrote - adds that base to the last column while it copies the text (write_renumbered).  No counting
     // pass: every window is scored once, with any number of workers.
     const bool text = !o.silent;
+    const bool rccl = d->gather_rccl != 0;       // -gpu_gather rccl: nothing is downloaded here; the consumer posts the window's arrays to GPU 0 (gather.cpp)
     for (int w = 0; w < nw; w++) {
         if (ch->aborted()) { mipgen_accel_destroy(h); return; }       // the selection stage failed: do not score what nobody will consume
         int32_t wr0 = 0, wn = 0;
@@ -593,7 +630,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
         res->r0 = r0 + wr0; res->r1 = r0 + wr0 + wn; res->last = w == nw - 1;
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
         for (auto& g : res->grids) g.offset -= c0;
-        res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np));
+        if (!rccl) { res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np)); }
         if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
         if (mipgen_accel_collapse(h)) { bail(19); return; }
         res->col_off.assign((size_t)wn + 1, 0);
@@ -602,13 +639,15 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
             mipgen_accel_region_bases(h, wr0 + bi, &fe, &nb);
             res->col_off[(size_t)bi + 1] = res->col_off[(size_t)bi] + 2 * (int64_t)nb;
         }
+        if (!rccl) {
         res->collapsed.resize((size_t)std::max<int64_t>(res->col_off[(size_t)wn], 1));
         if (mipgen_accel_download_collapsed(h, w, res->collapsed.data(), (int64_t)res->collapsed.size())) { bail(19); return; }
-        if (!o.silent && !text) {
+        }
+        if (!rccl && !o.silent && !text) {
             res->scores.resize((size_t)nc); res->records.resize((size_t)nc); res->mask.resize((size_t)nc);
             if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
         }
-        if (mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), (o.silent || text) ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
+        if (!rccl && mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), (o.silent || text) ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
         lap(3);
         if (text) {
             // print_details on the device: the records leave the GPU as text, the dense results never do
@@ -618,40 +657,38 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
                 names[(size_t)bi] = mipgen_record_names{r.chr.c_str(), r.label.c_str(), r.start - 1, r.stop};
             }
             int64_t n_rec = 0, n_bytes = 0;
+            // (rccl: the text buffer of the handle is scratch - the window before must have left it)
+            if (rccl && !ch->wait_transferred(w)) { mipgen_accel_destroy(h); return; }
             if (mipgen_accel_format_all_mips(h, names.data(), o.middle.c_str(), all_before, &n_rec, &n_bytes)) { bail(19); return; }
+            if (!rccl) {
             res->text.resize((size_t)n_bytes);
             if (mipgen_accel_download_text(h, res->text.data(), n_bytes)) { bail(19); return; }
+            }
             res->has_text = true;
             res->n_rec = n_rec;
             all_before += n_rec;
         }
         lap(4);
-        for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
+        if (!rccl) for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
         if (o.score_method == MIPGEN_SCORE_MIXED) {
-            // every survivor of the window through the SVR in one call (the pick stage re-scores a subset of them, mipgen.cpp:1523-1527,1873-1877)
-            std::vector<mipgen_candidate> cands;
-            std::vector<size_t> where;
-            int64_t q0 = 0;
-            for (int bi = 0; bi < wn; bi++) {
-                const mipgen_grid& g = res->grids[(size_t)bi];
-                for (int64_t q = 2 * q0; q < 2 * (q0 + g.n_pos); q++) {
-                    const mipgen_survivor& sv = res->surv[(size_t)q];
-                    if (sv.cand_index < 0) continue;
-                    const Cand c = make_cand(o, d->regions[(size_t)(res->r0 + bi)], g, sv.cand_index - g.offset, sv.score, sv.record);
-                    cands.push_back(mipgen_candidate{wr0 + bi, c.scan_start, c.capture, c.ext_len, c.lig_len, c.strand});
-                    where.push_back((size_t)q);
-                }
-                q0 += g.n_pos;
+            // every survivor of the window through the SVR in one list call ON THE DEVICE (the pick stage re-scores a subset of them, mipgen.cpp:1523-1527,
+            // 1873-1877): the candidate list is built from the survivor array in HBM, only the scores come down
+            if (mipgen_accel_rescore_survivors(h)) { bail(20); return; }
+            if (!rccl) {
+                res->svr.assign(res->surv.size(), std::numeric_limits<double>::quiet_NaN());
+                if (!res->svr.empty() && mipgen_accel_download_survivor_scores(h, w, res->svr.data(), (int64_t)res->svr.size())) { bail(20); return; }
             }
-            res->svr.assign(res->surv.size(), std::numeric_limits<double>::quiet_NaN());
-            std::vector<double> sc(cands.size());
-            if (!cands.empty() && mipgen_accel_score_candidates(h, cands.data(), (int32_t)cands.size(), MIPGEN_SCORE_SVR, sc.data(), nullptr, nullptr, nullptr)) { bail(20); return; }
-            for (size_t k = 0; k < cands.size(); k++) res->svr[where[k]] = sc[k];
         }
         lap(5);
+        if (rccl) {
+            // everything the handle has enqueued is done: the consumer's transfer stream may read the arrays
+            if (mipgen_accel_synchronize(h) || mipgen_accel_window_views(h, w, &res->views)) { bail(19); return; }
+            res->on_device = true; res->c0 = c0; res->n_surv = 2 * np;
+        } else res->point_at_own();
         ch->push(std::move(res));
         t_prev = std::chrono::steady_clock::now();                 // (time blocked on the consumer is not the worker's)
     }
+    if (rccl) (void)ch->wait_transferred(nw);                        // the consumer still reads this handle's arrays (or the run was aborted)
     mipgen_accel_destroy(h);
     if (timing) {
         std::ostringstream line;                                     // one write: the selection thread prints to stderr too
@@ -690,10 +727,10 @@ static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_c
 
 // all_mips text of a worker that numbered its records from 0: the last column is <label>_<index, at least four digits>[_SNP_a|_SNP_b] (print_details,
 // mipgen.cpp:792); every index is raised by `base`.  ~0.1 us per record on the consumer thread, instead of a second scoring pass on the device.
-static void write_renumbered(std::ostream& os, const std::vector<char>& text, int64_t base)
+static void write_renumbered(std::ostream& os, const char* text, size_t n_bytes, int64_t base)
 {
-    const char* p = text.data();
-    const char* const end = p + text.size();
+    const char* p = text;
+    const char* const end = p + n_bytes;
     std::string buf;
     buf.reserve((size_t)1 << 20);
     char num[32];
@@ -737,7 +774,7 @@ extern "C" int mipgen_design_write_all_mips(mipgen_design* d, const char* text, 
     if (!d || n_bytes < 0 || (n_bytes > 0 && !text) || renumber_base < 0) return fail(MIPGEN_HOST_E_USAGE, 0, "bad arguments");
     if (d->o.silent) return fail(MIPGEN_HOST_E_USAGE, 0, "a silent design has no all_mips records");
     if (n_bytes == 0) return 0;
-    if (renumber_base) { std::vector<char> v(text, text + n_bytes); write_renumbered(d->out.all, v, renumber_base); }
+    if (renumber_base) write_renumbered(d->out.all, text, (size_t)n_bytes, renumber_base);
     else d->out.all.write(text, (std::streamsize)n_bytes);
     return 0;
 }
@@ -785,6 +822,15 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             lo = hi;
         }
     }
+    // -gpu_gather rccl: one communicator rank per device worker, rank 0 = the root whose HBM the windows are gathered into
+    std::unique_ptr<RcclGather> gather;
+    if (d->gather_rccl) {
+        std::vector<int> devs;
+        for (int k = 0; k < n_devices; k++) devs.push_back(k % visible);
+        gather.reset(new RcclGather());
+        std::string gerr;
+        if (gather->init(devs, &gerr)) { std::cerr << "[mipgen] " << gerr << std::endl; d->failed = true; return fail(MIPGEN_HOST_E_ACCEL, 21, gerr); }
+    }
     std::vector<std::unique_ptr<Channel>> chans;
     std::vector<std::thread> threads;
     RecordOrder order(n_devices);
@@ -797,37 +843,108 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     if (d->selector) d->selector->fine_timing = d->timing;
     double t_wait = 0.0, t_select = 0.0;
     int64_t records_total = 0;                   // all_mips records written so far (the device text of all workers)
-    for (int k = 0; k < n_devices && rc == 0; k++) {
-        const int64_t records_before_worker = records_total;     // what worker k's own numbering (from 0) has to be shifted by
-        for (;;) {
-            const auto tw0 = std::chrono::steady_clock::now();
-            std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
-            const auto tw1 = std::chrono::steady_clock::now();
-            t_wait += std::chrono::duration<double>(tw1 - tw0).count();
-            if (w->error) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg); std::cerr << "[mipgen] " << g_err << std::endl; break; }
-            if (w->has_text) {
-                if (records_before_worker) write_renumbered(d->out.all, w->text, records_before_worker);
-                else d->out.all.write(w->text.data(), (std::streamsize)w->text.size());             // (the first worker's numbers are the design's)
-                records_total += w->n_rec;
-            }
-            int64_t pos0 = 0;
-            for (int bi = 0; bi < w->r1 - w->r0 && rc == 0; bi++) {
-                const mipgen_grid& g = w->grids[(size_t)bi];
-                SurvivorRescorer rs;
-                rs.w = w.get(); rs.pos0 = pos0; rs.g = &g;
-                const bool dense = !w->scores.empty();
-                try {
-                    rc = mipgen_design_select_region_collapsed(d, w->r0 + bi, &g, w->surv.data() + 2 * pos0, w->emitted[(size_t)bi],
-                                                     dense ? w->scores.data() + g.offset : nullptr, dense ? w->records.data() + g.offset : nullptr,
-                                                     dense ? w->mask.data() + g.offset : nullptr, w->collapsed.data() + w->col_off[(size_t)bi],
-                                                     (int32_t)((w->col_off[(size_t)bi + 1] - w->col_off[(size_t)bi]) / 2),
-                                                     d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
-                } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
-                pos0 += g.n_pos;
-            }
-            t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count();
-            if (w->last || rc) break;
+    // one result window through the selection stage: its all_mips text (a worker numbers its records from 0: shifted by what the workers before it
+    // wrote), then region after region (mipgen.cpp:503-515)
+    auto select_window = [&](WindowResult* w, int64_t records_before_worker) {
+        const auto ts0 = std::chrono::steady_clock::now();
+        if (w->has_text) {
+            if (records_before_worker) write_renumbered(d->out.all, w->text_p, (size_t)w->text_n, records_before_worker);
+            else d->out.all.write(w->text_p, (std::streamsize)w->text_n);                           // (the first worker's numbers are the design's)
+            records_total += w->n_rec;
         }
+        int64_t pos0 = 0;
+        for (int bi = 0; bi < w->r1 - w->r0 && rc == 0; bi++) {
+            const mipgen_grid& g = w->grids[(size_t)bi];
+            SurvivorRescorer rs;
+            rs.w = w; rs.pos0 = pos0; rs.g = &g;
+            const bool dense = !w->scores.empty();
+            try {
+                rc = mipgen_design_select_region_collapsed(d, w->r0 + bi, &g, w->surv_p + 2 * pos0, w->emitted_p[(size_t)bi],
+                                                 dense ? w->scores.data() + g.offset : nullptr, dense ? w->records.data() + g.offset : nullptr,
+                                                 dense ? w->mask.data() + g.offset : nullptr, w->collapsed_p + w->col_off[(size_t)bi],
+                                                 (int32_t)((w->col_off[(size_t)bi + 1] - w->col_off[(size_t)bi]) / 2),
+                                                 d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
+            } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
+            pos0 += g.n_pos;
+        }
+        t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+    };
+    auto worker_failed = [&](WindowResult* w) {
+        d->flush_err();
+        rc = fail(MIPGEN_HOST_E_ACCEL, w->error, "accelerator: " + w->msg);
+        std::cerr << "[mipgen] " << g_err << std::endl;
+    };
+    if (!d->gather_rccl) {
+        for (int k = 0; k < n_devices && rc == 0; k++) {
+            const int64_t records_before_worker = records_total;     // what worker k's own numbering (from 0) has to be shifted by
+            for (;;) {
+                const auto tw0 = std::chrono::steady_clock::now();
+                std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
+                t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+                if (w->error) { worker_failed(w.get()); break; }
+                select_window(w.get(), records_before_worker);
+                if (w->last || rc) break;
+            }
+        }
+    } else {
+        // -gpu_gather rccl: a window arrives as device pointers; its arrays are posted to GPU 0 with ONE grouped RCCL send / receive + one D2H copy
+        // (asynchronous), and the selection of the window BEFORE it runs while that transfer is in flight (two receive slots)
+        struct Pending { std::unique_ptr<WindowResult> w; int slot = 0; int worker = 0; int64_t rec_before = 0; size_t off[5] = {0, 0, 0, 0, 0}; };
+        std::unique_ptr<Pending> pending;
+        std::string gerr;
+        int next_slot = 0;
+        auto finish_pending = [&]() {
+            if (!pending) return;
+            std::unique_ptr<Pending> p = std::move(pending);
+            const auto tw0 = std::chrono::steady_clock::now();
+            const int grc = gather->wait(p->slot, &gerr);
+            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+            chans[(size_t)p->worker]->mark_transferred();               // the worker's arrays have been read
+            if (grc) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, 21, gerr); std::cerr << "[mipgen] " << g_err << std::endl; return; }
+            WindowResult* w = p->w.get();
+            char* hb = gather->host(p->slot);
+            w->emitted_p = (const int64_t*)(hb + p->off[0]);
+            w->surv_p = (mipgen_survivor*)(hb + p->off[1]);
+            w->collapsed_p = (const int32_t*)(hb + p->off[2]);
+            w->svr_p = (const double*)(hb + p->off[3]);
+            w->text_p = hb + p->off[4]; w->text_n = w->views.n_text_bytes;
+            for (int64_t q = 0; q < w->n_surv; q++) if (w->surv_p[q].cand_index >= 0) w->surv_p[q].cand_index -= w->c0;   // window-relative, like the grids
+            select_window(w, p->rec_before);
+        };
+        for (int k = 0; k < n_devices && rc == 0; k++) {
+            const int64_t records_before_worker = records_total + (pending && pending->w->has_text ? pending->w->n_rec : 0);
+            for (;;) {
+                std::unique_ptr<WindowResult> w = chans[(size_t)k]->try_pop();
+                if (!w) {
+                    if (pending) { finish_pending(); if (rc) break; continue; }   // nothing has arrived yet: the window in hand is selected meanwhile
+                    const auto tw0 = std::chrono::steady_clock::now();
+                    w = chans[(size_t)k]->pop();
+                    t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+                }
+                if (w->error) { worker_failed(w.get()); break; }
+                std::unique_ptr<Pending> p(new Pending());
+                const mipgen_window_views& v = w->views;
+                const bool mixed = d->o.score_method == MIPGEN_SCORE_MIXED;
+                GatherPiece pc[5] = {{v.emitted, (size_t)v.n_emitted * sizeof(int64_t), 0}, {v.survivors, (size_t)v.n_survivors * sizeof(mipgen_survivor), 0},
+                                     {v.collapsed, (size_t)v.n_collapsed * sizeof(int32_t), 0}, {mixed ? v.survivor_svr : nullptr, mixed ? (size_t)v.n_survivors * sizeof(double) : 0, 0},
+                                     {w->has_text ? v.text : nullptr, w->has_text ? (size_t)v.n_text_bytes : 0, 0}};
+                size_t total = 0;
+                for (int i = 0; i < 5; i++) { pc[i].offset = total; p->off[i] = total; total += (pc[i].bytes + 15) & ~(size_t)15; }
+                if ((mixed && v.n_survivors && !v.survivor_svr) || (v.n_collapsed && !v.collapsed) || v.n_survivors != w->n_surv) { rc = fail(MIPGEN_HOST_E_ACCEL, 21, "rccl gather: a window without its arrays"); break; }
+                p->slot = next_slot; next_slot ^= 1; p->worker = k; p->rec_before = records_before_worker;
+                if (gather->post(k, pc, 5, total, p->slot, &gerr)) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, 21, gerr); std::cerr << "[mipgen] " << g_err << std::endl; break; }
+                const bool last = w->last;
+                p->w = std::move(w);
+                finish_pending();                                      // the window before this one, while this one's transfer runs
+                pending = std::move(p);
+                if (last || rc) break;
+            }
+        }
+        if (rc == 0) finish_pending();
+        if (clk.on && gather) std::cerr << "[mipgen timing] rccl gather: " << gather->windows << " result windows, " << (double)gather->bytes_moved / 1e6
+                                        << " MB to GPU 0 (one grouped send / receive + one D2H copy each): posting " << gather->seconds_posting
+                                        << " s, waiting for a transfer that selection did not hide " << gather->seconds_waiting << " s\n";
+        gather->destroy();                                             // (waits for a transfer still in flight: the workers' arrays are read until then)
     }
     d->flush_err();
     if (clk.on) std::cerr << "[mipgen timing] tile_regions: waiting for the device workers " << t_wait << " s, selection stage " << t_select << " s\n";

@@ -1,0 +1,139 @@
+// gather.cpp — the exchange step of the multi-GPU front end (`-gpu_gather rccl`): per result window ONE grouped RCCL send / receive moves the
+// window's emitted counts, condensed survivors and collapse results (+ the SVR re-scores of a mixed design, + the all_mips text of a non-silent
+// one) from the HBM of the device that scored it into one packed buffer on GPU 0 - xGMI is point to point, every peer has its own link to the
+// root, nothing rings -, and one D2H copy hands the buffer to the sequential selection stage (the consumer of the reference's per-region tables:
+// /root/reference/mipgen.cpp:503-515 condense -> collapse -> pick in region order; rand() at :1863 and the used-arm sets of :1925-1938 couple
+// the regions, so the pick runs in ONE place).  Single process, one communicator per device (ncclCommInitAll), every RCCL call from the
+// consumer thread; rank 0's own windows take the same route (a self send / receive inside the group).
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstring>
+
+#include "gather.hpp"
+
+namespace mipgen {
+
+namespace {
+std::string hip_msg(const char* what, hipError_t e) { return std::string("rccl gather: ") + what + ": " + hipGetErrorString(e); }
+std::string nccl_msg(const char* what, ncclResult_t r) { return std::string("rccl gather: ") + what + ": " + ncclGetErrorString(r); }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+struct RcclGather::Impl {
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> send_streams;       // one per rank, on its device
+    hipStream_t recv_stream = nullptr;           // on the root device
+    struct Slot {
+        void* dev = nullptr; size_t dev_cap = 0;     // packed receive buffer on the root device
+        void* host = nullptr; size_t host_cap = 0;   // pinned: target of the one D2H copy
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+    } slot[kSlots];
+};
+
+RcclGather::RcclGather() : p_(new Impl()) {}
+RcclGather::~RcclGather() { destroy(); delete p_; }
+
+int RcclGather::init(const std::vector<int>& devices, std::string* err)
+{
+    Impl& P = *p_;
+    if (devices.empty()) { *err = "rccl gather: no devices"; return -1; }
+    for (size_t i = 0; i < devices.size(); i++)
+        for (size_t j = i + 1; j < devices.size(); j++)
+            if (devices[i] == devices[j]) { *err = "rccl gather: one communicator rank per device - more device workers than visible GPUs (use -gpu_gather pcie)"; return -1; }
+    P.devices = devices;
+    P.comms.assign(devices.size(), nullptr);
+    ncclResult_t r = ncclCommInitAll(P.comms.data(), (int)devices.size(), devices.data());
+    if (r != ncclSuccess) { P.comms.clear(); *err = nccl_msg("ncclCommInitAll", r); return -1; }
+    P.send_streams.assign(devices.size(), nullptr);
+    for (size_t k = 0; k < devices.size(); k++) {
+        hipError_t e = hipSetDevice(devices[k]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&P.send_streams[k], hipStreamNonBlocking);
+        if (e != hipSuccess) { *err = hip_msg("send stream", e); return -1; }
+    }
+    hipError_t e = hipSetDevice(devices[0]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&P.recv_stream, hipStreamNonBlocking);
+    for (int s = 0; s < kSlots && e == hipSuccess; s++) e = hipEventCreateWithFlags(&P.slot[s].done, hipEventDisableTiming);
+    if (e != hipSuccess) { *err = hip_msg("receive stream / events", e); return -1; }
+    return 0;
+}
+
+int RcclGather::post(int src, const GatherPiece* pieces, int n, size_t total, int s, std::string* err)
+{
+    Impl& P = *p_;
+    if (src < 0 || src >= (int)P.comms.size() || s < 0 || s >= kSlots || P.slot[s].in_flight) { *err = "rccl gather: bad post"; return -1; }
+    const double t0 = now_s();
+    Impl::Slot& S = P.slot[s];
+    hipError_t e = hipSetDevice(P.devices[0]);
+    if (e != hipSuccess) { *err = hip_msg("hipSetDevice", e); return -1; }
+    const size_t want = total + 256;
+    if (S.dev_cap < want) {
+        if (S.dev) (void)hipFree(S.dev);
+        S.dev = nullptr; S.dev_cap = 0;
+        e = hipMalloc(&S.dev, want + want / 4);
+        if (e != hipSuccess) { *err = hip_msg("receive buffer", e); return -1; }
+        S.dev_cap = want + want / 4;
+    }
+    if (S.host_cap < want) {
+        if (S.host) (void)hipHostFree(S.host);
+        S.host = nullptr; S.host_cap = 0;
+        e = hipHostMalloc(&S.host, want + want / 4, hipHostMallocDefault);
+        if (e != hipSuccess) { *err = hip_msg("pinned host buffer", e); return -1; }
+        S.host_cap = want + want / 4;
+    }
+    // one group = one fused transfer: every piece is a send on the source rank's communicator and a receive at its offset of the packed buffer
+    ncclResult_t r = ncclGroupStart();
+    for (int i = 0; i < n && r == ncclSuccess; i++) {
+        if (pieces[i].bytes == 0) continue;
+        r = ncclSend(pieces[i].dev, pieces[i].bytes, ncclUint8, 0, P.comms[(size_t)src], P.send_streams[(size_t)src]);
+        if (r == ncclSuccess) r = ncclRecv((char*)S.dev + pieces[i].offset, pieces[i].bytes, ncclUint8, src, P.comms[0], P.recv_stream);
+    }
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) { *err = nccl_msg("grouped send / receive", r != ncclSuccess ? r : r2); return -1; }
+    (void)hipSetDevice(P.devices[0]);
+    if (total) e = hipMemcpyAsync(S.host, S.dev, total, hipMemcpyDeviceToHost, P.recv_stream);
+    if (e == hipSuccess) e = hipEventRecord(S.done, P.recv_stream);
+    if (e != hipSuccess) { *err = hip_msg("D2H of the packed buffer", e); return -1; }
+    S.in_flight = true;
+    windows++; bytes_moved += total;
+    seconds_posting += now_s() - t0;
+    return 0;
+}
+
+int RcclGather::wait(int s, std::string* err)
+{
+    Impl& P = *p_;
+    if (s < 0 || s >= kSlots || !P.slot[s].in_flight) { *err = "rccl gather: bad wait"; return -1; }
+    const double t0 = now_s();
+    const hipError_t e = hipEventSynchronize(P.slot[s].done);
+    seconds_waiting += now_s() - t0;
+    if (e != hipSuccess) { *err = hip_msg("waiting for a window", e); return -1; }
+    P.slot[s].in_flight = false;
+    return 0;
+}
+
+char* RcclGather::host(int s) { return (char*)p_->slot[s].host; }
+
+void RcclGather::destroy()
+{
+    Impl& P = *p_;
+    for (int s = 0; s < kSlots; s++) {
+        Impl::Slot& S = P.slot[s];
+        if (S.in_flight && S.done) (void)hipEventSynchronize(S.done);
+        S.in_flight = false;
+        if (S.dev) { (void)hipSetDevice(P.devices.empty() ? 0 : P.devices[0]); (void)hipFree(S.dev); S.dev = nullptr; S.dev_cap = 0; }
+        if (S.host) { (void)hipHostFree(S.host); S.host = nullptr; S.host_cap = 0; }
+        if (S.done) { (void)hipEventDestroy(S.done); S.done = nullptr; }
+    }
+    for (size_t k = 0; k < P.send_streams.size(); k++) if (P.send_streams[k]) { (void)hipSetDevice(P.devices[k]); (void)hipStreamSynchronize(P.send_streams[k]); (void)hipStreamDestroy(P.send_streams[k]); }
+    P.send_streams.clear();
+    if (P.recv_stream) { (void)hipSetDevice(P.devices[0]); (void)hipStreamDestroy(P.recv_stream); P.recv_stream = nullptr; }
+    for (ncclComm_t c : P.comms) if (c) (void)ncclCommDestroy(c);
+    P.comms.clear();
+}
+
+}  // namespace mipgen

@@ -22,7 +22,8 @@ static const char* k_options[] = {
     "-score_method", "-logistic_heuristic", "-file_of_parameters", "-logistic_priority_score", "-svr_priority_score",
     "-logistic_optimal_score", "-svr_optimal_score", "-max_arm_copy_product", "-target_arm_copy",
     "-gpu_copy_counter",           // extension (not in the reference): "on" = exact oligo copy numbers by k-mer counting on the GPU, no bwa
-    "-gpus", "-gpu_window_candidates", "-gpu_timing"};   // extensions: device workers (0 = all visible), result-window cap (tests), stage timings on stderr
+    "-gpus", "-gpu_window_candidates", "-gpu_timing",    // extensions: device workers (0 = all visible), result-window cap (tests), stage timings on stderr
+    "-gpu_gather"};                                      // extension: pcie (default) | rccl - how the devices' result windows reach the selection stage
 
 static bool known(const std::string& p)
 {
@@ -65,7 +66,8 @@ static const char* k_doc =
     "  -silent_mode on   skip the all_mips / collapsed_mips files\n"
     "  -gpu_copy_counter on   (extension) arm copy numbers = exact occurrences in the whole -bwa_genome_index fasta (else every chr*.fa of -genome_dir),\n"
     "                         capture-window uniqueness (mapping flag) = no other locus within one substitution; both on the GPU, bwa is not run\n"
-    "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n";
+    "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n"
+    "  -gpu_gather pcie|rccl   (extension) result windows come down every GPU's own PCIe link (default), or travel to GPU 0 over RCCL / xGMI first\n";
 
 static void set_defaults(Options& o)
 {
@@ -77,7 +79,7 @@ static void set_defaults(Options& o)
     a["-capture_increment"] = "5"; a["-max_mip_overlap"] = "30"; a["-score_method"] = "logistic";
     a["-lig_min_length"] = "18"; a["-ext_min_length"] = "16"; a["-max_arm_copy_product"] = "75";
     a["-target_arm_copy"] = "20"; a["-bwa_threads"] = "1"; a["-gpu_copy_counter"] = "off";
-    a["-gpus"] = "0"; a["-gpu_window_candidates"] = "0"; a["-gpu_timing"] = "off";
+    a["-gpus"] = "0"; a["-gpu_window_candidates"] = "0"; a["-gpu_timing"] = "off"; a["-gpu_gather"] = "pcie";
 }
 
 std::string parse_command_line(int argc, char** argv, Options& o)

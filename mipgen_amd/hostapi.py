@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_design_long_range_seq", "mipgen_design_set_long_range_content", "mipgen_design_select_region",
     "mipgen_design_select_region_collapsed", "mipgen_design_select_regions", "mipgen_design_survivor_candidates", "mipgen_design_record_names", "mipgen_design_middle",
     "mipgen_design_write_all_mips", "mipgen_design_counters", "mipgen_design_region_weights",
-    "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_api_device", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_host_rand_stream",
+    "mipgen_design_run", "mipgen_design_set_devices", "mipgen_design_set_api_device", "mipgen_design_set_window_candidates", "mipgen_design_set_timing", "mipgen_design_set_gather", "mipgen_host_rand_stream",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library():
     lib.mipgen_design_set_api_device.argtypes = [vp, C.c_int32]
     lib.mipgen_design_set_window_candidates.argtypes = [vp, C.c_int64]
     lib.mipgen_design_set_timing.argtypes = [vp, C.c_int32]
+    lib.mipgen_design_set_gather.argtypes = [vp, C.c_int32]
     lib.mipgen_host_rand_stream.argtypes = [C.POINTER(C.c_int32), C.c_int32]
     _lib = lib
     return lib

@@ -41,7 +41,7 @@ def _split_args(argv: List[str]):
     ap.add_argument("--gpus", type=int, default=1, help="processes = GPUs of this node")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI; gloo + --share-gpus: tests on a one-GPU box")
     ap.add_argument("--share-gpus", action="store_true", help="ranks beyond the visible devices wrap around (never a measurement)")
-    ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched run (0 = a free one: concurrent runs on one node do not collide)")
     ap.add_argument("--force-dist", action="store_true", help="tests: the process-group code path with a world of one rank (under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--mipgen-path", default=os.path.join(HERE, "mipgen"), help="argv[0] of the design: mipgen_svr.model is looked for beside it (mipgen.cpp:409)")
     args = ap.parse_args(own)
@@ -52,8 +52,15 @@ def _split_args(argv: List[str]):
 
 def _launch(args, argv: List[str]) -> int:
     """--gpus N > 1 without a launcher: start torch.distributed.run as a CHILD (nothing here has touched a GPU; a GPU-initialised process never execs)."""
+    port = args.master_port
+    if not port:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(args.master_port), "-m", "mipgen_amd.mp_design"] + argv
+           "--master-port", str(port), "-m", "mipgen_amd.mp_design"] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
@@ -99,19 +106,23 @@ def main(argv: List[str]) -> int:
     flags = list(flags)
     project = flags[flags.index("-project_name") + 1] if "-project_name" in flags and flags.index("-project_name") + 1 < len(flags) else None
     scratch = None
-    if rank > 0:                                                           # the input stage writes files named after the project: ranks > 0 keep theirs out of the way
-        scratch = tempfile.mkdtemp(prefix=f"mipgen_rank{rank}_")
-        name = "mipgen_design"
-        if "-project_name" in flags:
-            k = flags.index("-project_name")
-            name = os.path.basename(flags[k + 1]) or name
-            flags[k + 1] = os.path.join(scratch, name)
-        else:
-            flags += ["-project_name", os.path.join(scratch, name)]
+    part_path = (project or "mipgen_design") + f".all_mips.rank{rank}.part"   # (rank 0's project path: one node, one file system)
     rc = 0
     d = None
-    reported = False                                                       # this rank has taken part in the "shard scored" exchange
+    reported = 0                                                           # status exchanges this rank has taken part in (1: shard scored, 2: selection done)
     try:
+        try:
+            os.remove(part_path)                                           # a part file left behind by a killed run must never be appended to this design
+        except OSError:
+            pass
+        if rank > 0:                                                       # the input stage writes files named after the project: ranks > 0 keep theirs out of the way
+            scratch = tempfile.mkdtemp(prefix=f"mipgen_rank{rank}_")
+            name = os.path.basename(project) if project else "mipgen_design"
+            hits = [k for k, f in enumerate(flags[:-1]) if f == "-project_name"]
+            for k in hits:                                                 # (every occurrence: the option map keeps the last one)
+                flags[k + 1] = os.path.join(scratch, name or "mipgen_design")
+            if not hits:
+                flags += ["-project_name", os.path.join(scratch, name)]
         d = hostapi.Design([args.mipgen_path] + flags)
         d.set_api_device(local_rank)                                       # (-gpu_copy_counter on: the shard's copy numbers are counted on this rank's GPU)
         P = d.params()
@@ -133,7 +144,6 @@ def main(argv: List[str]) -> int:
                 for k, i in enumerate(range(lo, hi)):
                     d.set_long_range_content(i, lrc[k])
         text_design = not d.silent                                         # all_mips records: formatted on the device, window by window
-        part_path = (project or "mipgen_design") + f".all_mips.rank{rank}.part"   # (rank 0's project path: one node, one file system)
         local_rec = 0
         if text_design:
             acc.set_window_candidates(64 << 20)                            # the front end's window policy for designs that fetch per-window results
@@ -177,9 +187,10 @@ def main(argv: List[str]) -> int:
                 svr[where] = acc.score_candidate_array(cands, m, capi.SCORE_SVR)
         t_scored = time.perf_counter()
         if distributed:
-            reported = True
+            reported = 1
             if not _all_ranks_ok(dist, torch, xdev, True):
-                raise SystemExit(1)
+                reported = 2                                                 # every rank leaves here: no second exchange
+                raise RuntimeError("another rank failed before the gather")
         if distributed:
             # the one exchange step of the path: condensed survivors (+ the per-region counts and grids) -> rank 0
             all_surv = mdist.gather_to_rank0(surv, xdev)
@@ -200,7 +211,7 @@ def main(argv: List[str]) -> int:
             # the all_mips file: rank after rank, every rank's own numbering shifted by what the ranks before it wrote (whole lines, 64 MB at a time)
             for r in range(world):
                 pp = (project or "mipgen_design") + f".all_mips.rank{r}.part"
-                if not os.path.exists(pp):
+                if shards[r][1] <= shards[r][0] or not os.path.exists(pp):     # (a rank with an empty shard wrote no part)
                     continue
                 base_r = int(rec_bases[r]) if rec_bases is not None else 0
                 with open(pp, "rb") as fh:
@@ -232,24 +243,33 @@ def main(argv: List[str]) -> int:
                               "survivors_gathered": int(all_surv.shape[0]), "emitted_candidates": int(all_emitted.sum()), "picked": c["picked"], "gaps": c["gaps"],
                               "seconds": {"inputs": round(t_inputs - t_start, 3), "score + condense (rank 0's shard)": round(t_scored - t_inputs, 3),
                                           "gather": round(t_gathered - t_scored, 3), "selection": round(t_end - t_gathered, 3)}}), flush=True)
-    except (hostapi.HostError, capi.AccelError) as e:
-        print(f"[mp_design] rank {rank}: {e}", file=sys.stderr)
+        if distributed:
+            reported = 2
+            if not _all_ranks_ok(dist, torch, xdev, True):                   # rank 0 has read every part file and finished the selection stage - or failed in it
+                raise RuntimeError("another rank failed after the gather")
+    except BaseException as e:                                               # ANY failure is reported through the status exchange: no rank is left waiting in a collective
+        print(f"[mp_design] rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
         rc = 1
-        if distributed and not reported:
-            _all_ranks_ok(dist, torch, xdev, False)                          # the other ranks learn of it instead of waiting in the gather
+        if distributed and reported < 2:
+            try:
+                # reported == 0: the "shard scored" exchange (the others stop before the gather); 1: the "selection done" exchange (the others are waiting in it)
+                _all_ranks_ok(dist, torch, xdev, False)
+            except BaseException:
+                pass                                                          # (the peers are gone already: the launcher ends the run)
     finally:
         if d is not None:
             d.close()
         if scratch:
             shutil.rmtree(scratch, ignore_errors=True)
+        try:
+            os.remove(part_path)
+        except OSError:
+            pass
     if distributed:
-        if rc == 0:
-            dist.barrier()                                                   # rank 0 has read every part file
-        dist.destroy_process_group()
-    try:
-        os.remove((project or "mipgen_design") + f".all_mips.rank{rank}.part")
-    except OSError:
-        pass
+        try:
+            dist.destroy_process_group()
+        except BaseException:
+            pass
     return rc
 
 

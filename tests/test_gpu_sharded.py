@@ -14,6 +14,15 @@ from tests import host_select_common as HS
 pytestmark = pytest.mark.gpu
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _run(meta, work, n_shards):
     os.makedirs(work)
     os.environ["FAKEBWA_MODE"] = meta["bwa"]
@@ -85,10 +94,10 @@ def test_sharded_survivors_through_rank0_pick(name, tmp_path):
     assert c1["picked"] == meta["lines"]["picked_mips"] - 1 and c1["all_mips"] == meta["lines"]["all_mips"] - 1
 
 
-def test_bench_two_ranks_strong_scaling_child_process():
-    """bench.py --gpus 2: the launcher path the driver's SCALE run takes (one process per GPU over RCCL, the exome BED cut two ways by the
-    region cost model, one gather of the condensed survivors per step).  Runs as a CHILD process - a GPU-initialised process never execs -
-    and only where two devices are visible."""
+def test_bench_two_ranks_child_process():
+    """bench.py --gpus 2: the launcher path the driver's SCALE run takes (one process per GPU over RCCL, the headline batch weak-scaled to two instances
+    and cut by the region cost model, one gather of the condensed survivors per step; the exome cut two ways beside it as `exome_strong`).  Runs as a
+    CHILD process - a GPU-initialised process never execs - and only where two devices are visible."""
     import json
     import subprocess
     import sys
@@ -96,44 +105,56 @@ def test_bench_two_ranks_strong_scaling_child_process():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two visible GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--regions", "2048", "--no-cpu-baseline"],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale-base-regions", "2048", "--no-cpu-baseline"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "exome200k" in line["config"]["workload"]
+    _check_two_rank_line(line, "nccl")
+
+
+def _check_two_rank_line(line, backend):
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == backend
+    assert line["scaling"] == "weak" and "practice62 x2" in line["config"]["workload"] and "weak" in line["scale_family"]
     assert line["parity_checked"] is True and line["value"] > 0
-    assert line["config"]["survivors_gathered_per_step"] > 0
-    # the process group itself reports two ranks, and both hold a share of the BED (cost-model shards: within a factor of 1.5 of each other)
-    assert line["rccl_ranks"] == 2
+    # both ranks hold a share of the BED (cost-model shards: within a factor of 1.5 of each other), and rank 1's survivors arrived too
     per = line["config"]["dense_candidates_per_rank"]
     assert len(per) == 2 and min(per) > 0 and sum(per) == line["config"]["dense_candidates_all_ranks"] and max(per) < 1.5 * min(per)
+    assert line["config"]["survivors_gathered_per_step"] > line["config"]["survivors_rank0"] > 0
+    # the metric's own multi-GPU config beside it: the same exome BED cut two ways, one timed pass with its gather
+    ex = line["exome_strong"]
+    assert ex["n_gpus"] == 2 and ex["scaling"] == "strong" and "first 2048" in ex["what"] and ex["value"] > 0
+    assert len(ex["dense_candidates_per_rank"]) == 2 and sum(ex["dense_candidates_per_rank"]) == ex["dense_candidates"]
+    assert ex["survivors_gathered"] > ex["survivors_rank0"] > 0
 
 
 def test_bench_two_ranks_logic_through_gloo_on_one_gpu():
     """The N > 1 path of bench.py on a box with ONE GPU: two ranks share the device and exchange through host memory (`--backend gloo --share-gpus`,
     tests only - never a measurement).  Everything but RCCL itself is the code the driver's SCALE run executes: the launcher, the cost-model shards,
-    the size exchange, the per-step gather of the condensed survivors to rank 0, the max-over-ranks clock, the per-rank candidate counts."""
+    the size exchange, the per-step gather of the condensed survivors to rank 0, the max-over-ranks clock, the per-rank candidate counts - for the
+    weak-scaled headline family and for the exome cut two ways (`exome_strong`)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpus", "--steps", "2", "--warmup", "1",
-                        "--regions", "1024", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+                        "--scale-base-regions", "2048", "--exome-regions", "0", "--sustain-seconds", "0", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["shared_gpus"] is True
-    assert line["scaling"] == "strong" and "exome200k" in line["config"]["workload"] and "first 1024" in line["config"]["workload"]
-    per = line["config"]["dense_candidates_per_rank"]
-    assert len(per) == 2 and min(per) > 0 and sum(per) == line["config"]["dense_candidates_all_ranks"] and max(per) < 1.5 * min(per)
-    assert line["config"]["survivors_gathered_per_step"] > line["config"]["survivors_rank0"] > 0      # rank 1's survivors arrived too
-    assert line["parity_checked"] is True and line["value"] > 0
-    # the same BED on one rank: the same dense-candidate total
-    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "exome", "--regions", "1024", "--scaling", "strong", "--steps", "1",
+    assert line["shared_gpus"] is True
+    _check_two_rank_line(line, "gloo")
+    # the same exome BED on one rank: the same dense-candidate total
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "exome", "--regions", "2048", "--scaling", "strong", "--steps", "1",
                         "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-parity-gate"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
     assert q.returncode == 0, q.stderr.decode()[-2000:]
     one = json.loads(q.stdout.decode().strip().splitlines()[-1])
-    assert one["config"]["dense_candidates_all_ranks"] == line["config"]["dense_candidates_all_ranks"]
-    assert one["config"]["emitted_candidates_rank0"] >= line["config"]["emitted_candidates_rank0"] > 0          # rank 0 of two holds a part of it
+    assert one["config"]["dense_candidates_all_ranks"] == line["exome_strong"]["dense_candidates"]
+    # an explicit strong-scaling run of the exome family (one BED cut two ways in `value` itself) still works
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpus", "--config", "exome", "--scaling", "strong",
+                        "--regions", "1024", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    two = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert two["scaling"] == "strong" and "first 1024" in two["config"]["workload"] and len(two["config"]["dense_candidates_per_rank"]) == 2
 
 
 def test_bench_scale_base_line_is_the_sharded_workload():
@@ -235,7 +256,7 @@ def test_rccl_collectives_of_the_multi_gpu_paths_with_one_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_one_rank_worker.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root, env=env)
@@ -252,7 +273,7 @@ def test_bench_and_mp_design_take_their_rccl_code_path_with_one_rank(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
-    p = subprocess.run(launch + ["--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    p = subprocess.run(launch + ["--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                                  "--no-extras", "--no-measure-traffic"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root, env=env)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
@@ -262,7 +283,7 @@ def test_bench_and_mp_design_take_their_rccl_code_path_with_one_rank(tmp_path):
     work = str(tmp_path / "mp1")
     os.makedirs(work)
     argv = H.prepare_cli_workdir(meta, work)
-    p = subprocess.run(launch + ["--master-port", "29562", "-m", "mipgen_amd.mp_design", "--gpus", "1", "--force-dist", "--mipgen-path", argv[0], "--"] + argv[1:],
+    p = subprocess.run(launch + ["--master-port", str(_free_port()), "-m", "mipgen_amd.mp_design", "--gpus", "1", "--force-dist", "--mipgen-path", argv[0], "--"] + argv[1:],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=work, env=dict(env, FAKEBWA_MODE=meta["bwa"]))
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
