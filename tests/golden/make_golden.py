@@ -176,7 +176,63 @@ DESIGNS2 = [
 ]
 
 
-def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -> None:
+# Designs over THREE chromosomes ("2", "10", "X": the reference sorts chromosome names as strings, mipgen.cpp:37-67 - "10" < "2" < "X"), BED files as
+# users write them: unsorted, with and without the `chr` prefix (:1017), extra columns, space-separated fields, duplicate starts (the stable sort keeps
+# their order; the later line's label wins the merge, :1019-1026), comment lines (:993).  The used-arm sets are per chromosome (:1925-1938).
+BED_MULTI_A = """# three chromosomes, as a user's BED comes
+chrX\t5200\t5290\txa\t0\t+
+2\t6000\t6080
+chr10\t7000\t7100\tten_a\t960
+10\t7000\t7060\tten_dup
+chr2\t5200\t5300\ttwo_a\t.\t-
+X 9000 9070 xb
+# a comment between the lines
+chr2\t6050\t6120\ttwo_merge
+10\t12000\t12090\tten_b\tx\ty\tz
+chrX\t5330\t5400\txa2
+"""
+BED_MULTI_B = """chrX\t4000\t4060\tsx
+10\t5000\t5055\tsten
+chr2\t3000\t3062\tstwo
+"""
+BED_MULTI_C = """X\t20000\t20075\tmx1
+chr2\t21000\t21060\tm2a
+chr10\t22000\t22090\tm10a
+2\t21100\t21160\tm2b
+chrX\t20600\t20650\tmx2
+10\t22400\t22470
+"""
+BED_MULTI_D = """chr10\t30000\t30400\td10
+X\t31000\t31350\tdx
+chr2\t32000\t32500\td2
+2\t32900\t33000\td2b
+"""
+DESIGNS3 = [
+    dict(name="multichr_logistic_snps", method="logistic", bed_text=BED_MULTI_A, minC=152, maxC=162, sums=[40, 41, 42, 43, 44, 45], flank=3, tags="4,4",
+         snps=True, trf=False, bwa="hashed", model=None, extra=[]),
+    dict(name="multichr_svr", method="svr", bed_text=BED_MULTI_B, minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="hashed",
+         model="svr_syn_64.model", extra=[]),
+    dict(name="multichr_mixed", method="mixed", bed_text=BED_MULTI_C, minC=125, maxC=135, sums=[42, 43], flank=2, tags="4,4", snps=True, trf=True, bwa="hashed",
+         model="svr_syn_64.model", extra=[]),
+    dict(name="multichr_double_tile_separately", method="logistic", bed_text=BED_MULTI_D, minC=152, maxC=162, sums=[41, 43, 45], flank=0, tags="5,0", snps=False,
+         trf=False, bwa="hashed", model=None, extra=["-double_tile_strands_separately", "on", "-seal_both_strands", "on"]),
+]
+MULTI_CHROMS = (("2", 40000, 302), ("10", 40000, 310), ("X", 40000, 388))       # (name, bases, seed)
+
+
+def parse_bed_text(text: str):
+    ivs = []
+    for line in text.split("\n"):
+        line = line.strip()
+        if len(line) <= 1 or line[0] == "#":
+            continue
+        f = line.split()
+        c = f[0][3:] if f[0].startswith("chr") else f[0]
+        ivs.append((c, int(f[1]), int(f[2]), f[3] if len(f) > 3 else ""))
+    return ivs
+
+
+def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz") -> None:
     out = os.path.join(HERE, "design_" + d["name"])
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
@@ -184,9 +240,18 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
     shutil.rmtree(w, ignore_errors=True)
     os.makedirs(w + "/genome")
     chrom = d.get("chrom", "1")
-    synth.write_fasta(w + f"/genome/chr{chrom}.fa", "chr" + chrom, genome)
-    ivs = [synth.Interval(*iv) for iv in d["ivs"]]
-    synth.write_bed(w + "/regions.bed", ivs)
+    multi = isinstance(genome, dict)                        # several chromosomes: {name: bases}; the BED is given as text
+    if multi:
+        for c, g in genome.items():
+            synth.write_fasta(w + f"/genome/chr{c}.fa", "chr" + c, g)
+        with open(w + "/regions.bed", "w") as fh:
+            fh.write(d["bed_text"])
+        d = dict(d, ivs=parse_bed_text(d["bed_text"]))
+        ivs = [synth.Interval(*iv) for iv in d["ivs"]]
+    else:
+        synth.write_fasta(w + f"/genome/chr{chrom}.fa", "chr" + chrom, genome)
+        ivs = [synth.Interval(*iv) for iv in d["ivs"]]
+        synth.write_bed(w + "/regions.bed", ivs)
     shutil.copy(w + "/regions.bed", out + "/regions.bed")
     extra = ["-feature_flank", str(d["flank"]), "-tag_sizes", d["tags"]]
     extra += ["-arm_lengths", d["arm_lengths"]] if d.get("arm_lengths") else ["-arm_length_sums", ",".join(map(str, d["sums"]))]
@@ -197,7 +262,16 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
         shutil.copy(w + "/params.txt", out + "/params.txt")
         extra += ["-file_of_parameters", w + "/params.txt"]
     snp_path = None
-    if d["snps"]:
+    if d["snps"] and multi:
+        snps = []
+        for k, (c, g) in enumerate(genome.items()):
+            mine = [iv for iv in ivs if iv.chrom == c]
+            if mine:
+                snps += synth.random_snps(c, g, min(iv.bed_start for iv in mine) - 400, max(iv.bed_end for iv in mine) + 400, seed=13 + k, per_bp=1 / 50.0)
+        snp_path = w + "/snps.vcf"
+        synth.write_vcf(snp_path, snps)
+        shutil.copy(snp_path, out + "/snps.vcf")
+    elif d["snps"]:
         lo = min(iv.bed_start for iv in ivs) - 1000
         hi = max(iv.bed_end for iv in ivs) + 1000
         snps = synth.random_snps("1", genome, 4000, 10000, seed=13, per_bp=1 / 40.0) if genome_name == "genome_chr1.fa.gz" else \
@@ -212,6 +286,9 @@ def gen_design(genome: bytes, d: dict, genome_name: str = "genome_chr1.fa.gz") -
     meta = {k: d[k] for k in ("name", "method", "minC", "maxC", "sums", "flank", "tags", "snps", "trf", "bwa", "model")}
     meta["intervals"] = d["ivs"]
     meta["genome"] = genome_name
+    if multi:
+        meta["genomes"] = {c: f"genome3_chr{c}.fa.gz" for c in genome}
+        meta["bed_as_given"] = True
     if genome_name != "genome_chr1.fa.gz":
         meta["extra"] = list(d.get("extra", []))
         meta["chrom"] = d.get("chrom", "1")
@@ -288,6 +365,16 @@ def main() -> None:
     d2 = dict(d1, name="practice62_config2_svr", method="svr", minC=140, maxC=180, model="svr_syn_64.model", extra=["-silent_mode", "on"])
     if not only or d2["name"] in only:
         gen_design(g7, d2, "genome_practice62_chr7.fa.gz")
+    # three chromosomes
+    multi = {c: synth.random_genome(n, seed, n_run_frac=0.002, n_run_len=7) for c, n, seed in MULTI_CHROMS}
+    for c, g in multi.items():
+        with gzip.GzipFile(os.path.join(HERE, f"genome3_chr{c}.fa.gz"), "wb", mtime=0) as gz:
+            gz.write(f">chr{c}\n".encode())
+            for i in range(0, len(g), 60):
+                gz.write(g[i:i + 60] + b"\n")
+    for d in DESIGNS3:
+        if not only or d["name"] in only:
+            gen_design(multi, d, "genome3")
 
 
 if __name__ == "__main__":

@@ -115,9 +115,15 @@ def prepare_cli_workdir(meta: dict, work: str, fai: bool = False) -> List[str]:
     """Lay out the inputs of a golden design in `work` and return the mipgen argument vector (argv[0] = work/mipgen, beside which the
     model is placed: mipgen.cpp:137-138,409).  fai=True: no -genome_dir; the region sequences come from <index>.fai instead."""
     os.makedirs(os.path.join(work, "genome"), exist_ok=True)
-    genome = golden_genome(meta.get("genome", "genome_chr1.fa.gz"))
-    chrom = meta.get("chrom", "1")
-    synth.write_fasta(os.path.join(work, "genome", f"chr{chrom}.fa"), "chr" + chrom, genome)
+    if meta.get("genomes"):                                   # several chromosomes (design_multichr_*): one chr<name>.fa each
+        assert not fai, "the multi-chromosome designs take the -genome_dir path"
+        for c, fn in meta["genomes"].items():
+            synth.write_fasta(os.path.join(work, "genome", f"chr{c}.fa"), "chr" + c, golden_genome(fn))
+        genome, chrom = None, None
+    else:
+        genome = golden_genome(meta.get("genome", "genome_chr1.fa.gz"))
+        chrom = meta.get("chrom", "1")
+        synth.write_fasta(os.path.join(work, "genome", f"chr{chrom}.fa"), "chr" + chrom, genome)
     shutil.copy(os.path.join(meta["dir"], "regions.bed"), os.path.join(work, "regions.bed"))
     exe = os.path.join(work, "mipgen")
     if not os.path.lexists(exe):
