@@ -110,6 +110,9 @@ def refdrv():
     lib.ref_parameters.restype = C.c_int
     lib.ref_oriented.argtypes = [C.c_int, cp, cp, cp, cp, cp, cp, cp]
     lib.ref_long_range_content.argtypes = [cp, C.c_int, C.c_int, dp]
+    if hasattr(lib, "ref_svm_train_save"):                        # (fixture generation only: svm_train + svm_save_model of the reference's libsvm)
+        lib.ref_svm_train_save.argtypes = [C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, cp]
+        lib.ref_svm_train_save.restype = C.c_int
     lib.ref_svm_load_model.argtypes = [cp]
     lib.ref_svm_load_model.restype = vp
     lib.ref_svm_nsv.argtypes = [vp]

@@ -142,4 +142,46 @@ double ref_predict_text(void* model, const double* x, int n)
     return s;
 }
 
+// A model trained AND written by the reference's own libsvm (svm_train, svm.cpp:2095; svm_save_model, svm.cpp:2644-2757): epsilon-SVR with an
+// RBF kernel on n dense 192-feature rows (zeros omitted from the sparse nodes, as libsvm's own file readers produce them).  The file it leaves is
+// genuine svm_save_model output - header keys, "%.8g"-style values, only the non-zero indices of every support vector - for pinning every
+// loader (svm_load_model's grammar, svm.cpp:2779-2962) against.  Returns the number of support vectors, -1 on failure.
+static void quiet_print(const char*) {}
+int ref_svm_train_save(int n, const double* x, const double* y, double gamma, double cost, double epsilon, const char* out_path)
+{
+    svm_set_print_string_function(&quiet_print);
+    svm_problem prob;
+    prob.l = n;
+    prob.y = (double*)malloc(sizeof(double) * n);
+    prob.x = (svm_node**)malloc(sizeof(svm_node*) * n);
+    std::vector<svm_node> pool;
+    pool.reserve((size_t)n * 193);
+    std::vector<size_t> first((size_t)n);
+    for (int i = 0; i < n; i++) {
+        prob.y[i] = y[i];
+        first[(size_t)i] = pool.size();
+        for (int j = 0; j < 192; j++) {
+            const double v = x[(size_t)i * 192 + j];
+            if (v != 0.0) { svm_node nd; nd.index = j + 1; nd.value = v; pool.push_back(nd); }
+        }
+        svm_node end; end.index = -1; end.value = 0.0; pool.push_back(end);
+    }
+    for (int i = 0; i < n; i++) prob.x[i] = &pool[first[(size_t)i]];
+    svm_parameter par;
+    memset(&par, 0, sizeof par);
+    par.svm_type = EPSILON_SVR; par.kernel_type = RBF; par.degree = 3; par.gamma = gamma; par.coef0 = 0;
+    par.cache_size = 100; par.eps = 1e-3; par.C = cost; par.nr_weight = 0; par.nu = 0.5; par.p = epsilon; par.shrinking = 1; par.probability = 0;
+    const char* err = svm_check_parameter(&prob, &par);
+    int nsv = -1;
+    if (!err) {
+        svm_model* m = svm_train(&prob, &par);
+        if (m) {
+            if (svm_save_model(out_path, m) == 0) nsv = m->l;
+            svm_free_and_destroy_model(&m);
+        }
+    }
+    free(prob.y); free(prob.x);
+    return nsv;
+}
+
 }  // extern "C"

@@ -113,6 +113,57 @@ def gen_candidates(genome: bytes) -> None:
     print(f"candidates: {n} known answers, {len(lr_in)} long-range vectors")
 
 
+def gen_libsvm_trained_model(genome: bytes) -> None:
+    """A model TRAINED and WRITTEN by the reference's own libsvm (svm_train, svm.cpp:2095; svm_save_model, svm.cpp:2644-2757) on the feature vectors
+    of 360 candidates of the golden genome (SVMipv4::get_parameters) with a smooth synthetic target, and the reference's predictions (svm_predict through
+    the text hop of mipgen.cpp:1948-2019) for 150 other candidates, edge cases included.  Every other model fixture is written by mipgen_amd/synth.py;
+    this one pins the loaders against genuine svm_save_model output (the trained mipgen_svr.model itself is absent upstream)."""
+    R = po.refdrv()
+    rng = np.random.default_rng(4242)
+    dp = C.POINTER(C.c_double)
+    g = genome
+
+    def cand(t, clean):
+        e = int(rng.integers(16, 31)); l = int(rng.integers(18, 31))
+        ss = int(rng.integers(75, 215))
+        p = int(rng.integers(400, len(g) - 700)); strand = int(rng.integers(0, 2))
+        ext = bytearray(g[p - 1 - e:p - 1] if strand == 0 else g[p - 1 + ss:p - 1 + ss + e])
+        ins = bytearray(g[p - 1:p - 1 + ss])
+        lig = bytearray(g[p - 1 + ss:p - 1 + ss + l] if strand == 0 else g[p - 1 - l:p - 1])
+        ec = int(rng.choice([1, 1, 1, 1, 2, 3, 7, 20])); lc = int(rng.choice([1, 1, 1, 1, 2, 5, 19]))
+        if not clean:
+            kind = t % 15
+            if kind == 3: ext[int(rng.integers(0, e))] = ord("N")          # guard: all-zero vector
+            if kind == 6: ins[int(rng.integers(0, ss))] = ord("N")
+            if kind == 9: ec = 0                                           # log10(0) = -inf
+            if kind == 12: lc = 101                                        # clamp to 2
+        lrc = rng.uniform(0, 0.3, 44)
+        x = np.empty(192)
+        R.ref_parameters(strand, bytes(ext), bytes(lig), bytes(ins), ec, lc, MIDDLE, lrc.ctypes.data_as(dp), x.ctypes.data_as(dp))
+        s = R.ref_logistic(strand, bytes(ext), bytes(lig), bytes(ins), ec, lc, MIDDLE)
+        return x, s
+
+    rows, ys = [], []
+    while len(rows) < 360:
+        x, s = cand(len(rows), True)
+        if not np.all(np.isfinite(x)) or not np.any(x):
+            continue
+        rows.append(x); ys.append(1.4 + 2.2 * (s - 0.5) + 0.08 * rng.standard_normal())
+    X = np.ascontiguousarray(np.array(rows)); y = np.ascontiguousarray(np.array(ys))
+    path = os.path.join(HERE, "models", "svr_libsvm_trained.model")
+    n_sv = R.ref_svm_train_save(X.shape[0], X.ctypes.data_as(dp), y.ctypes.data_as(dp), 2e-4, 8.0, 0.12, path.encode())
+    assert n_sv > 20, n_sv
+    m = R.ref_svm_load_model(path.encode())
+    tx, tv = [], []
+    for t in range(150):
+        x, _ = cand(t, False)
+        tx.append(x); tv.append(R.ref_predict_text(m, x.ctypes.data_as(dp), 192))
+    np.savez_compressed(os.path.join(HERE, "libsvm_trained.npz"), params=np.array(tx), svr=np.array(tv), n_sv=np.array([R.ref_svm_nsv(m)]),
+                        gamma=np.array([R.ref_svm_gamma(m)]), rho=np.array([R.ref_svm_rho(m)]))
+    print(f"libsvm-trained model: {n_sv} support vectors of {X.shape[0]} training candidates, gamma {R.ref_svm_gamma(m)}, rho {R.ref_svm_rho(m)}; "
+          f"{len(tv)} known answers in [{np.nanmin(tv):.3f}, {np.nanmax(tv):.3f}]")
+
+
 DESIGNS = [
     # name, method, intervals, minC, maxC, sums, flank, tags, snps, trf, bwa_mode, model, keep_all
     dict(name="logistic_snp_trf", method="logistic", ivs=[("1", 5000, 5070, "a"), ("1", 9000, 9046, "b")], minC=120, maxC=125,
@@ -173,6 +224,9 @@ DESIGNS2 = [
          tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_64.model", extra=["-svr_optimal_score", "2.8", "-svr_priority_score", "1.2"]),
     dict(name="svr_scan_size_2_increment_1", method="svr", ivs=[("1", 26000, 26045, "w")], minC=47, maxC=70, sums=[40, 41, 42, 43, 44, 45], flank=0,
          tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_short_48.model", extra=["-capture_increment", "1"]),
+    # the model libsvm itself trained and wrote (gen_libsvm_trained_model): genuine svm_save_model output through svm_load_model's grammar, end to end
+    dict(name="svr_libsvm_trained_model", method="svr", ivs=[("1", 46000, 46070, "lt"), ("1", 47200, 47290, "lu")], minC=135, maxC=150, sums=[43, 44, 45], flank=0,
+         tags="5,0", snps=True, trf=False, bwa="hashed", model="svr_libsvm_trained.model", extra=[]),
 ]
 
 
@@ -337,6 +391,8 @@ def main() -> None:
         gen_candidates(genome)
     elif not os.path.exists(os.path.join(HERE, "models", "svr_syn_short_48.model")):
         gen_short_model(genome)
+    if not only or "libsvm_trained" in only or not os.path.exists(os.path.join(HERE, "models", "svr_libsvm_trained.model")):
+        gen_libsvm_trained_model(genome)
     for d in DESIGNS:
         if not only or d["name"] in only:
             gen_design(genome, d)

@@ -632,6 +632,43 @@ def test_model_loader_paths(genome, tmp_path):
     acc.close()
 
 
+def test_model_written_by_libsvm_itself_through_the_accelerator(genome):
+    """The model the reference's own libsvm trained and wrote (tests/golden/models/svr_libsvm_trained.model: svm_train + svm_save_model, svm.cpp:2095,
+    2644-2757 - genuine output, 227 sparse SV lines at %.8g) through mipgen_accel_load_model_file: header as svm_load_model reads it, and the dense
+    grid of a region - tiled kernel and literal per-candidate kernel - within 1e-5 of the oracle, whose predictions are bit-exact against the
+    reference's svm_predict on that file (tests/test_oracle_golden.py)."""
+    z = np.load(os.path.join(H.GOLDEN, "libsvm_trained.npz"))
+    mp = os.path.join(H.GOLDEN, "models", "svr_libsvm_trained.model")
+    P = capi.make_params(135, 150, score_method=capi.SCORE_SVR, arm_pairs=synth.arm_pairs_from_sums([43, 44, 45]))
+    acc = capi.Accel(P)
+    acc.load_model_file(mp)
+    n_sv, gamma, rho = acc.model_info()
+    assert n_sv == int(z["n_sv"][0]) and gamma == float(z["gamma"][0]) and rho == float(z["rho"][0])
+    om = po.Model(mp)
+    rd = capi.build_region(genome, "1", 7000, 7080, P, bwa_mode="hashed", label="x", lrc=np.linspace(0.02, 0.3, 44))
+    grids, scores, records = acc.score_regions([rd], capi.SCORE_SVR)
+    _, os_, or_ = po.score_region_dense(P, rd, capi.SCORE_SVR, om)
+    assert np.array_equal(records, or_)
+    ok, mx = _close(scores, os_)
+    assert ok.all(), mx
+    # the literal per-candidate kernel (reference operation order) on a sample of the grid
+    g = grids[0]
+    rng = np.random.default_rng(5)
+    A = P.n_arm_pairs
+    cands, idxs = [], []
+    for idx in rng.choice(g.count, size=200, replace=False):
+        a = int(idx % A); row = int(idx // A); st = row & 1; rest = row >> 1
+        ki, pi = rest % g.n_sizes, rest // g.n_sizes
+        if not (int(capi.rec_flags(records[idx:idx + 1])[0]) & capi.FLAG_VALID):
+            continue
+        cands.append((0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(st)))
+        idxs.append(int(idx))
+    lit = acc.score_candidates(cands, capi.SCORE_SVR)[0]
+    ok, mx = _close(lit, os_[np.array(idxs)])
+    assert ok.all(), mx
+    acc.close()
+
+
 def _collapse_py(P, g, surv, target, max_product, thr):
     """collapse_mips (mipgen.cpp:1616-1649) restated as a plain loop over the survivors in scan-start order (test-side checker)."""
     A = P.n_arm_pairs

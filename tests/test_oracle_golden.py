@@ -47,6 +47,21 @@ def test_svr_predict_bit_exact(cands):
             assert got == z[key][i] or (np.isnan(got) and np.isnan(z[key][i])), (name, i)
 
 
+def test_model_written_by_libsvm_itself():
+    """tests/golden/models/svr_libsvm_trained.model was TRAINED and WRITTEN by the reference's own libsvm (svm_train, svm.cpp:2095; svm_save_model,
+    svm.cpp:2644-2757; oracle/ref_driver.cpp: ref_svm_train_save) - genuine svm_save_model output, not this repository's writer: the oracle's loader
+    reads the header svm_load_model read (svm.cpp:2779-2899) and its predictions equal the reference's svm_predict on 150 candidates, edge cases included."""
+    z = np.load(os.path.join(H.GOLDEN, "libsvm_trained.npz"))
+    m = po.Model(os.path.join(H.GOLDEN, "models", "svr_libsvm_trained.model"))
+    assert m.n_sv == int(z["n_sv"][0]) and m.gamma == float(z["gamma"][0]) and m.rho == float(z["rho"][0])
+    n_inf = 0
+    for i in range(z["params"].shape[0]):
+        got = m.predict(z["params"][i])
+        assert got == z["svr"][i] or (np.isnan(got) and np.isnan(z["svr"][i])), i
+        n_inf += bool(np.isinf(z["params"][i]).any())
+    assert n_inf >= 5 and (z["params"] == 0).all(axis=1).sum() >= 5       # log10(0) and all-zero guard vectors are among them
+
+
 def test_long_range_content_bit_exact(cands):
     meta, z = cands
     g = H.golden_genome()
