@@ -1,0 +1,89 @@
+"""CPU: the accelerated tile_regions driver of libmipgen_host.so (mipgen_amd/host/design.cpp: one worker thread + one accelerator handle per device,
+result windows through channels to the sequential selection thread, abort paths) under ThreadSanitizer and AddressSanitizer + UBSan on a machine
+without a GPU.  The product sources are compiled with the sanitizer where they lie (tests/stub_accel/Makefile) against a STUB of libmipgen_accel.so that
+hands out what the oracle computes (tests/stub_accel/stub_accel.cpp: test infrastructure) - so the whole command line runs, with 1, 2 and 4 device
+workers and forced result windows, its files are compared byte for byte with the reference's goldens, and an injected accelerator failure in every
+call position of every worker ends the run the way the reference ends (/root/reference/mipgen.cpp:2029-2035: message, exit status 1, no completion
+line) - without a hang, a race or a leak of a worker."""
+import os
+import subprocess
+
+import pytest
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "stub_accel")
+SAN_ENV = {"thread": {"TSAN_OPTIONS": "halt_on_error=1 exitcode=66 second_deadlock_stack=1"},
+           "address": {"ASAN_OPTIONS": "detect_leaks=1 exitcode=67 abort_on_error=0", "UBSAN_OPTIONS": "halt_on_error=1 print_stacktrace=1"}}
+
+
+@pytest.fixture(scope="module", params=["thread", "address"])
+def san(request):
+    import fcntl
+    os.makedirs(os.path.join(STUB, "_build"), exist_ok=True)
+    with open(os.path.join(STUB, "_build", ".lock"), "w") as lock:          # (pytest-xdist workers share the build directory)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-s", "-j4", "-C", STUB, f"SAN={request.param}"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    return request.param
+
+
+def _run(san, meta, work, workers, extra=(), env_extra=None, timeout=600):
+    os.makedirs(work, exist_ok=True)
+    argv = H.prepare_cli_workdir(meta, work)
+    exe = os.path.join(work, "mipgen")
+    os.remove(exe)                                                    # (prepare_cli_workdir links the product binary: this test runs the sanitizer build)
+    os.symlink(os.path.join(STUB, "_build", san, "mipgen"), exe)
+    env = dict(os.environ, FAKEBWA_MODE=meta["bwa"], STUB_ACCEL_DEVICES=str(max(workers, 1)))
+    env.update(SAN_ENV[san])
+    env.update(env_extra or {})
+    return subprocess.run(argv + ["-gpus", str(workers)] + list(extra), cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def _compare(meta, work):
+    if "-silent_mode" in meta.get("extra", []):
+        H.compare_outputs(meta, work, keys=("picked_mips", "snp_mips"), check_all=False)
+    else:
+        H.compare_outputs(meta, work)
+
+
+@pytest.mark.parametrize("name,workers", [("logistic_default_arms", 1), ("logistic_default_arms", 2), ("mixed_12_regions", 4), ("mixed_12_regions", 2),
+                                          ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_mixed", 4), ("multichr_logistic_snps", 2)])
+def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, workers, tmp_path):
+    if san == "address" and (name, workers) not in (("mixed_12_regions", 4), ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_logistic_snps", 2)):
+        pytest.skip("all eight under ThreadSanitizer, four under AddressSanitizer + UBSan")
+    meta = H.load_design(name)
+    biggest = max(r[2] - r[1] for r in meta["intervals"])
+    p = _run(san, meta, str(tmp_path), workers, extra=["-gpu_window_candidates", str(max(1000, biggest * 2000))])
+    err = p.stderr.decode()
+    assert p.returncode == 0, err[-3000:]
+    assert "ThreadSanitizer" not in err and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
+    _compare(meta, str(tmp_path))
+
+
+CALLS = ["create", "load_model_file", "long_range_content_batch", "upload_regions", "score_window", "replay_condense", "collapse", "download_collapsed",
+         "download_replay", "format_all_mips", "download_text", "rescore_survivors"]
+POSITIONS = [(0, 1), (3, 1), (1, 2)]                                   # (worker, n-th call): first / last worker's first call, a middle worker's second window
+# every call once, the positions in rotation (MIPGEN_SAN_FULL=1: every call in every position, ~4 minutes)
+SWEEP = [(c, d, n) for c in CALLS for d, n in POSITIONS] if os.environ.get("MIPGEN_SAN_FULL") else [(c,) + POSITIONS[i % 3] for i, c in enumerate(CALLS)]
+
+
+@pytest.mark.parametrize("call,device,nth", SWEEP)
+def test_injected_accelerator_failure_ends_the_run_cleanly(san, call, device, nth, tmp_path):
+    """An accelerator call of a worker (first / last worker, first / second result window) fails once: the run ends with the reference's error
+    convention - exit status 1, `unable to tile sequences due to circumstance N`, no `mip picking complete` -, no worker is left behind (the process
+    exits: no hang), and neither sanitizer reports anything on the abort paths."""
+    if san == "address" and not os.environ.get("MIPGEN_SAN_FULL") and CALLS.index(call) % 3 != 1:
+        pytest.skip("the abort paths are swept under ThreadSanitizer; AddressSanitizer takes every third")
+    meta = H.load_design("mixed_12_regions")                          # mixed + SNPs, 12 regions, non-silent: every call of the worker is on its path
+    p = _run(san, meta, str(tmp_path), 4, extra=["-gpu_window_candidates", "30000"], env_extra={"STUB_ACCEL_FAIL": f"{device}:{call}:{nth}"}, timeout=300)
+    err = p.stderr.decode()
+    assert "ThreadSanitizer" not in err and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
+    if f"injected failure of {call}" not in err:
+        # a call a handle makes once (create, model, long-range content, upload) has no second occurrence: the run completes
+        assert nth > 1 and call in ("create", "load_model_file", "long_range_content_batch", "upload_regions") and p.returncode == 0, err[-2000:]
+        return
+    assert p.returncode == 1, (p.returncode, err[-2000:])
+    assert "unable to tile sequences due to circumstance" in err and "mip picking complete" not in err
+    assert "mip picking complete" not in open(os.path.join(str(tmp_path), "out.progress.txt")).read()
