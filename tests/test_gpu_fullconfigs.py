@@ -334,3 +334,35 @@ def test_full_exome_snps_full_sweep_svr():
             so, _, oints = po.score_designed(dsg, capi.SCORE_SVR, lrc, om)
             assert abs(scores[idx] - so) <= TOL or (np.isnan(scores[idx]) and np.isnan(so)), (ri, int(idx), scores[idx], so)
     a.close()
+
+
+def test_full_config3_mixed_command_line_three_routes(tmp_path):
+    """BASELINE configs[2] as its COMMAND LINE at full size: `mipgen -score_method mixed -silent_mode on` over all 1,000 regions of 5,000 bp, capture
+    120-250 - 1.6e10 candidates scanned with the logistic score, ~1e7 condensed survivors re-scored with the 1,024-SV SVR on the device, the pick stage
+    on the host (mipgen.cpp:503-520, 1523-1527, 1873-1877).  Three independent routes of the product must write the same picked file: the in-process
+    front end with per-GPU PCIe downloads, the same with `-gpu_gather rccl` (one grouped RCCL send / receive per result window into GPU 0), and
+    mipgen_amd/mp_design.py with two ranks (one process per rank, torch.distributed gather; gloo on this one-GPU box)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = str(tmp_path / "c3")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "cli_exome.py"), "1000", work, "regions5k", "mixed"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, (p.stdout.decode()[-2000:], p.stderr.decode()[-2000:])
+    picked = open(os.path.join(work, "out.picked_mips.txt"), "rb").read()
+    lines = picked.split(b"\n")[1:-1]
+    assert len(lines) > 40_000                                                  # ~53,000 MIPs tile the 5 Mb of targets
+    sc = np.array([float(l.split(b"\t")[1]) for l in lines[:5000]])
+    assert np.isfinite(sc).all() and lines[0].split(b"\t")[2] == b"1"
+    argv = [os.path.join(work, "mipgen"), "-regions_to_scan", os.path.join(work, "exome.bed"), "-project_name", "out2", "-min_capture_size", "120", "-max_capture_size", "250",
+            "-bwa_genome_index", os.path.join(work, "genome", "index.fa"), "-genome_dir", os.path.join(work, "genome"), "-score_method", "mixed", "-silent_mode", "on",
+            "-gpu_copy_counter", "on"]
+    q = subprocess.run(argv + ["-gpus", "1", "-gpu_gather", "rccl", "-gpu_timing", "on"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert q.returncode == 0 and b"[mipgen timing] rccl gather:" in q.stderr, q.stderr.decode()[-2000:]
+    assert open(os.path.join(work, "out2.picked_mips.txt"), "rb").read() == picked
+    argv[argv.index("out2")] = "out3"
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "mipgen_amd.mp_design", "--gpus", "2", "--backend", "gloo", "--share-gpus", "--mipgen-path", argv[0], "--"] + argv[1:],
+                       cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert open(os.path.join(work, "out3.picked_mips.txt"), "rb").read() == picked
