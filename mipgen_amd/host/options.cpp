@@ -67,7 +67,9 @@ static const char* k_doc =
     "  -gpu_copy_counter on   (extension) arm copy numbers = exact occurrences in the whole -bwa_genome_index fasta (else every chr*.fa of -genome_dir),\n"
     "                         capture-window uniqueness (mapping flag) = no other locus within one substitution; both on the GPU, bwa is not run\n"
     "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n"
-    "  -gpu_gather pcie|rccl   (extension) result windows come down every GPU's own PCIe link (default), or travel to GPU 0 over RCCL / xGMI first\n";
+    "  -gpu_gather pcie|rccl   (extension) result windows come down every GPU's own PCIe link (default), or travel to GPU 0 over RCCL / xGMI first\n"
+    "limits of this build (the reference has none): arm lengths up to 64 bases, 256 arm-length pairs; svr / mixed scoring of scan targets\n"
+    "  (capture size - smallest arm length sum) above 1,024 bases is refused with an error\n";
 
 static void set_defaults(Options& o)
 {
