@@ -26,7 +26,7 @@ using namespace mipgen;
 
 namespace {
 
-thread_local char g_err[768] = "";
+thread_local char g_err[8192] = "";        // (holds the whole -doc text: the option documentation travels as the "usage" message, mipgen.cpp:140-145)
 thread_local int g_circumstance = 0;
 
 int fail(int code, int circumstance, const std::string& msg)

@@ -23,3 +23,12 @@ def test_failed_run_does_not_announce_completion(tmp_path):
     assert "unable to tile sequences due to circumstance 17" in err
     assert "mip picking complete" not in err
     assert "mip picking complete" not in open(os.path.join(work, "out.progress.txt")).read()
+
+
+def test_doc_is_printed_in_full():
+    """`mipgen -doc` prints the whole option documentation (the reference: mipgen.cpp:1291-1310), extensions and this build's limits included."""
+    p = subprocess.run([H.CLI_BIN, "-doc"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    out = p.stderr.decode() + p.stdout.decode()
+    assert p.returncode == 1
+    for needle in ("-feature_flank", "-score_method", "-gpu_gather pcie|rccl", "limits of this build"):
+        assert needle in out, needle
