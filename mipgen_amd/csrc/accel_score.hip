@@ -17,36 +17,38 @@ int mipgen_pb_check(mipgen_accel* h)
 // mipgen.cpp:774) are re-scored by k_candidates in the reference's own operation order and overwritten, so that the printed digit is the
 // reference's (its error against the reference's double is ~1e-16 relative: the libm exponential).  No host round trip: the list length
 // stays on the device, the re-scoring grid is the list's capacity.  list = nullptr: the dense results of regions [r0, r1).
-static int fix_print_boundaries(mipgen_accel* h, int r0, int r1, const mipgen_candidate* list, double* scores, const uint64_t* records, int64_t n)
+// Logistic scores (method = MIPGEN_SCORE_LOGISTIC; round 5) take the same route: the dense kernel regroups the 69 terms by window (error ~1e-14 on the
+// exponent), the re-score evaluates them in the reference's order with every operation rounded on its own (logistic_exponent_exact).
+static int fix_print_boundaries(mipgen_accel* h, int r0, int r1, const mipgen_candidate* list, double* scores, const uint64_t* records, int64_t n, int method = MIPGEN_SCORE_SVR)
 {
-    if (!h->print_exact || n <= 0 || h->n_sv <= 0) return MIPGEN_OK;
+    if (!h->print_exact || n <= 0 || (method == MIPGEN_SCORE_SVR && h->n_sv <= 0)) return MIPGEN_OK;
     const unsigned int cap = (unsigned int)std::min<int64_t>(n / 1024 + 4096, (int64_t)1 << 24);
     if (h->pb_cands.reserve(cap) || h->pb_idx.reserve(cap) || h->pb_scores.reserve(cap) || h->pb_count.reserve(1)) return MIPGEN_E_NOMEM;
-    const double tol_rel = 1e-10, tol_abs = 1e-13 * std::max(1.0, h->sum_abs_coef);
+    const double tol_rel = method == MIPGEN_SCORE_SVR ? 1e-10 : 1e-11, tol_abs = method == MIPGEN_SCORE_SVR ? 1e-13 * std::max(1.0, h->sum_abs_coef) : 1e-300;
     HIP_TRY(hipMemsetAsync(h->pb_count.p, 0, sizeof(unsigned int), h->stream));
     if (list) HIP_TRY(mipgen_launch_print_boundary_scan_list(h->stream, list, scores, records, (int)n, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap));
     else HIP_TRY(mipgen_launch_print_boundary_scan(h->stream, h->dp, h->regions.p, r0, r1, scores, records, n, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap, h->n_cu));
     HIP_TRY(mipgen_launch_candidates(h->stream, (int)cap, h->dp, h->regions.p, h->pb_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
-                                     h->gamma, h->rho, MIPGEN_SCORE_SVR, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
+                                     h->gamma, h->rho, method, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
     HIP_TRY(mipgen_launch_scatter_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, scores, h->pb_over));
     return MIPGEN_OK;
 }
 
 // the silent path (mipgen_accel_score_condense_all): only the condensed survivors of the window are ever printed, so only they are tested
 // and re-scored (2 per scan position instead of the whole dense grid); the value goes into the survivor's score field
-static int fix_print_boundaries_survivors(mipgen_accel* h, int w)
+static int fix_print_boundaries_survivors(mipgen_accel* h, int w, int method = MIPGEN_SCORE_SVR)
 {
     const Window& W = h->windows[(size_t)w];
     const int64_t n = 2 * W.n_pos;
-    if (!h->print_exact || n <= 0 || h->n_sv <= 0) return MIPGEN_OK;
+    if (!h->print_exact || n <= 0 || (method == MIPGEN_SCORE_SVR && h->n_sv <= 0)) return MIPGEN_OK;
     const unsigned int cap = (unsigned int)std::min<int64_t>(n / 256 + 1024, (int64_t)1 << 22);
     if (h->pb_cands.reserve(cap) || h->pb_idx.reserve(cap) || h->pb_scores.reserve(cap) || h->pb_count.reserve(1)) return MIPGEN_E_NOMEM;
-    const double tol_rel = 1e-10, tol_abs = 1e-13 * std::max(1.0, h->sum_abs_coef);
+    const double tol_rel = method == MIPGEN_SCORE_SVR ? 1e-10 : 1e-11, tol_abs = method == MIPGEN_SCORE_SVR ? 1e-13 * std::max(1.0, h->sum_abs_coef) : 1e-300;
     mipgen_survivor* surv = h->survivors.p + 2 * W.pos0;
     HIP_TRY(hipMemsetAsync(h->pb_count.p, 0, sizeof(unsigned int), h->stream));
     HIP_TRY(mipgen_launch_print_boundary_scan_surv(h->stream, h->dp, h->regions.p, W.r0, W.r1, surv, n, W.cand0, tol_rel, tol_abs, h->pb_cands.p, h->pb_idx.p, h->pb_count.p, cap));
     HIP_TRY(mipgen_launch_candidates(h->stream, (int)cap, h->dp, h->regions.p, h->pb_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
-                                     h->gamma, h->rho, MIPGEN_SCORE_SVR, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
+                                     h->gamma, h->rho, method, h->pb_scores.p, nullptr, nullptr, nullptr, 1, h->pb_count.p));
     HIP_TRY(mipgen_launch_scatter_surv_scores(h->stream, h->pb_scores.p, h->pb_idx.p, (int)cap, h->pb_count.p, surv, h->pb_over));
     return MIPGEN_OK;
 }
@@ -93,6 +95,9 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
         HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
                                                h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
     if (ev) HIP_TRY(hipEventRecord(ev[1], h->stream));
+    // logistic scores that sit on a rounding midpoint of the six printed digits: re-scored in the reference's term order (dense windows of non-silent
+    // designs; the silent path tests its survivors only)
+    if (method == MIPGEN_SCORE_LOGISTIC && fix_dense) { if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand, MIPGEN_SCORE_LOGISTIC)) return rc; }
     if (svr_via_list) {
         if (int rc = svr_window_via_list(h, W)) return rc;
         if (fix_dense) { if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand)) return rc; }
@@ -214,7 +219,7 @@ int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
     for (int w = 0; w < (int)h->windows.size(); w++) {
         if (int rc = score_window_impl(h, w, method, false)) return rc;
         if (int rc = replay_window_impl(h, false)) return rc;
-        if (method == MIPGEN_SCORE_SVR) { if (int rc = fix_print_boundaries_survivors(h, w)) return rc; }
+        if (int rc = fix_print_boundaries_survivors(h, w, method)) return rc;
         if (int rc = collapse_window_impl(h)) return rc;
     }
     return MIPGEN_OK;

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
                 x.v[MLV_EA] = (double)eA / dl; x.v[MLV_LA] = (double)lA / ll; x.v[MLV_TA] = (double)tA / dn;
                 x.v[MLV_JS] = jc < 16 ? c_junction_scores[jc] : 0.0;
                 x.v[MLV_LEC] = log_copy_dev(HC, ext_copy); x.v[MLV_LLC] = log_copy_dev(HC, lig_copy);
-                const double ex = logistic_exponent(x);
+                const double ex = logistic_exponent_exact(x);                     // every operation rounded on its own, as the reference's
                 const double y = pow(MIPGEN_LOGISTIC_BASE, ex);                 // SVMipv4.cpp:247
                 logistic = y / (1.0 + y);
             }
@@ -233,7 +233,10 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     if (literal) {
         // the reference's own operation order (svm.cpp:329-368 k_function: d = x - y, sum += d * d in index order; :2511-2515 svm_predict_values:
         // sum += coef * k in support-vector order, then - rho), every operation rounded on its own (g++ on x86-64 does not contract to FMA):
-        // what mipgen_accel prints for the scores that sit on a rounding boundary of the 6 printed digits (accel.hip: fix_print_boundaries)
+        // what mipgen_accel prints for the scores that sit on a rounding boundary of the 6 printed digits (accel_score.hip: fix_print_boundaries).
+        // Plain operators under `fp contract(off)`: HIP's __dmul_rn / __dadd_rn are plain operators compiled under contract(fast) - inlined, hipcc
+        // fuses them into FMAs whatever the caller says.
+#pragma clang fp contract(off)
         double total = 0.0;
         for (int base = 0; base < n_sv; base += CAND_THREADS) {
             const int i = base + tid;
@@ -242,18 +245,21 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
                 const double* sv = model + (int64_t)i * SV_ROW;
                 double sum = 0.0;
                 for (int j = 0; j < MIPGEN_N_FEATURES; j++) {
-                    const double d = __dsub_rn(s_x[j], sv[j]);
-                    sum = __dadd_rn(sum, __dmul_rn(d, d));
+                    const double d = s_x[j] - sv[j];
+                    const double dd = d * d;
+                    sum = sum + dd;
                 }
-                sum = __dadd_rn(sum, sv[SVR_N_EXTRA]);
-                term = __dmul_rn(sv[SVR_COEF], exp(__dmul_rn(-gamma, sum)));
+                sum = sum + sv[SVR_N_EXTRA];
+                const double arg = -gamma * sum;
+                const double k = exp(arg);
+                term = sv[SVR_COEF] * k;
             }
             s_term[tid] = term;
             __syncthreads();
-            if (tid == 0) { const int m = min(CAND_THREADS, n_sv - base); for (int q = 0; q < m; q++) total = __dadd_rn(total, s_term[q]); }
+            if (tid == 0) { const int m = min(CAND_THREADS, n_sv - base); for (int q = 0; q < m; q++) total = total + s_term[q]; }
             __syncthreads();
         }
-        if (tid == 0) scores[blockIdx.x] = __dsub_rn(total, rho);
+        if (tid == 0) scores[blockIdx.x] = total - rho;
         return;
     }
     // SVR: lanes own support vectors; 192-dimension walk in index order, then shuffle reduction

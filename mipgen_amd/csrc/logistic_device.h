@@ -69,6 +69,25 @@ __device__ __forceinline__ double logistic_exponent(const Vars& x)
     return ex;
 }
 
+// The same with every multiplication and addition rounded on its own, as g++ compiles the reference's expression on x86-64 (no FMA contraction):
+// the exponent of the print-exact re-score (k_candidates) equals the reference's double bit for bit.
+__device__ __forceinline__ double logistic_exponent_exact(const Vars& x)
+{
+    // Plain operators under `fp contract(off)`: HIP's __dmul_rn / __dadd_rn are plain operators compiled under the default contract(fast) - inlined, their
+    // instructions carry the contract flag and hipcc fuses them into FMAs whatever the caller says (measured: up to 98 ulp from the reference's score).
+#pragma clang fp contract(off)
+    double ex = MIPGEN_LOGISTIC_C0 - MIPGEN_LOGISTIC_C1;
+#pragma unroll
+    for (int i = 0; i < MIPGEN_LOGISTIC_NTERMS; i++) {
+        double t;
+        if (k_terms[i].kind == MLT_LIN) t = k_terms[i].coef * x.v[k_terms[i].v1];
+        else if (k_terms[i].kind == MLT_BIL) { t = k_terms[i].coef * x.v[k_terms[i].v1]; t = t * x.v[k_terms[i].v2]; }
+        else { t = x.v[k_terms[i].v1] * x.v[k_terms[i].v1]; t = k_terms[i].coef * t; }
+        ex = ex + t;
+    }
+    return ex;
+}
+
 // pow(2.71828, ex) / (1 + pow(2.71828, ex))   (SVMipv4.cpp:247), with pow(b, x) = exp(x * ln b)
 __device__ __forceinline__ double logistic_from_vars(const HostConsts* HC, const Vars& x)
 {

@@ -77,3 +77,40 @@ def test_planted_boundary_score_prints_the_reference_digits(tmp_path):
     sc, _, _, _ = acc.score_candidates(cands, capi.SCORE_SVR)
     assert format(sc[0], ".6g") == want and abs(sc[0] - ref) <= 2e-15 * max(1.0, abs(ref))
     acc.close()
+
+
+def test_logistic_scores_near_a_print_midpoint_are_rescored_in_the_reference_order():
+    """Round 5: the same guarantee for LOGISTIC scores.  k_logistic_dense regroups the 69 terms of the exponent by sequence window (error ~1e-14), so a
+    score within that distance of a 6-digit rounding midpoint could print another last digit (mipgen.cpp:774); those candidates are re-scored with
+    the terms in the reference's own order, every operation rounded on its own (SVMipv4.cpp:176-247), and overwritten.  A 5 kb region at 27 capture
+    sizes holds 1.6e7 candidates: a few dozen sit that close to a midpoint; exactly those move, and where they move to is the reference's double."""
+    from mipgen_amd import workloads
+    genome = workloads.regions5k_genome()
+    ivs = workloads.regions5k_intervals(1)
+    P = capi.make_params(120, 250, score_method=capi.SCORE_LOGISTIC)
+    regions = workloads.build_regions5k(None, genome, ivs, P, with_lrc=False)
+    acc = capi.Accel(P)
+    acc.set_print_exact(False)
+    grids, s_off, rec = acc.score_regions(regions, capi.SCORE_LOGISTIC)
+    acc.set_print_exact(True)
+    _, s_on, _ = acc.score_regions(regions, capi.SCORE_LOGISTIC)
+    g = grids[0]
+    moved = np.nonzero((s_on != s_off) & ~(np.isnan(s_on) & np.isnan(s_off)))[0]
+    assert 0 < moved.size < s_on.size // 10_000, moved.size
+    assert np.all(np.abs(s_on[moved] - s_off[moved]) < 1e-11)
+    A = P.n_arm_pairs
+    rd = regions[0]
+    n_exact = 0
+    for idx in moved[:60]:
+        a = int(idx % A); row = int(idx // A); strand = row & 1; rest = row >> 1
+        ki, pi = rest % g.n_sizes, rest // g.n_sizes
+        cand = (0, g.first_pos + pi, P.max_capture_size - (g.first_size_index + ki) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], int(strand))
+        sk, d = po.design(P, rd, cand)
+        assert not sk
+        ref, _, _ = po.score_designed(d, capi.SCORE_LOGISTIC, np.zeros(44), None)            # the reference's double (oracle: bit-exact, tests/test_oracle_golden.py)
+        # the re-scored value is the reference's to the last bits (pow of the device math library vs glibc's: < 4 ulp), the dense value was ~1e-14 off
+        assert abs(s_on[idx] - ref) <= 4 * np.spacing(abs(ref)), (s_on[idx], ref)
+        assert format(s_on[idx], ".6g") == format(ref, ".6g")
+        n_exact += s_on[idx] == ref
+    assert n_exact > 0
+    acc.close()
