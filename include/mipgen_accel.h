@@ -410,6 +410,7 @@ int mipgen_accel_set_sv_split(mipgen_accel* h, int32_t n_split);
  * (measurements, tests of the mechanism).  Dense windows and candidate lists (mixed designs) alike.  Should a window hold more such scores
  * than the re-score list (1/1024 of its candidates + 4096), the next download of its results fails with MIPGEN_E_STATE instead of handing
  * out digits that are not guaranteed. */
+/* (ABI 4: logistic scores take the same route - within 1e-11 of a midpoint they are re-scored with the 69 terms in the reference's order, SVMipv4.cpp:176-247.) */
 int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on);
 /* The reference stops constructing candidates at a scan position for good once a capture size starts with previous_best_score above the upper
  * score limit (mipgen.cpp:430).  A region of more than nine capture sizes is scored in runs of <= 9 sizes; with this switch on the runs are scored in
