@@ -568,9 +568,6 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     if (mipgen_accel_create(&ap, device, nullptr, &h)) { fail_out(17, mipgen_accel_last_error()); return; }
     auto bail = [&](int code) { std::string m = mipgen_accel_last_error(); mipgen_accel_destroy(h); fail_out(code, m); };
     if (o.score_method != MIPGEN_SCORE_LOGISTIC && mipgen_accel_load_model_file(h, d->model_path.c_str())) { bail(18); return; }
-    // svr designs: mipgen.cpp:430 between the capture-size runs of the dense scorer - the tiles of a later run whose positions have all stopped are
-    // never scored, exactly as the reference never constructs those candidates (nothing this front end reads lies behind a position's exit)
-    if (o.score_method == MIPGEN_SCORE_SVR) (void)mipgen_accel_set_dynamic_skip(h, 1);
     const int n = r1 - r0;
     lap(0);
     if (o.score_method != MIPGEN_SCORE_LOGISTIC) {                                                                   // mipgen.cpp:1171,1224
@@ -612,6 +609,15 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     // silent designs keep only survivors, so a window may fill the HBM; otherwise its dense results come to the host (17 B per candidate)
     mipgen_accel_set_window_candidates(h, d->window_candidates > 0 ? d->window_candidates : (o.silent ? 0 : (int64_t)64 << 20));   // (tests force several windows)
     if (mipgen_accel_upload_regions(h, batch.data(), n, grids.data())) { bail(19); return; }
+    // svr designs: mipgen.cpp:430 between the capture-size runs of the dense scorer - the tiles of a later run whose positions have all stopped are
+    // never scored, exactly as the reference never constructs those candidates (nothing this front end reads lies behind a position's exit).
+    // Only where it can pay: the runs are launches of their own (no split along the SV list, one small synchronisation per run), which a shard of
+    // fewer than ~3e7 candidates does not fill the chip with - small designs keep the one launch per window with the automatic split.
+    if (o.score_method == MIPGEN_SCORE_SVR) {
+        int64_t shard_cand = 0;
+        for (const mipgen_grid& g : grids) shard_cand += g.count;
+        (void)mipgen_accel_set_dynamic_skip(h, shard_cand >= 30000000 ? 1 : 0);
+    }
     lap(2);
     const int method = o.score_method == MIPGEN_SCORE_SVR ? MIPGEN_SCORE_SVR : MIPGEN_SCORE_LOGISTIC;               // mixed scans with logistic (:467)
     const int nw = mipgen_accel_window_count(h);

@@ -131,3 +131,33 @@ def test_dynamic_skip_random_configurations(cfg):
     left_out = np.isnan(b[0]) & ~np.isnan(a[0])
     assert not (left_out & emitted).any() and int(left_out.sum()) == b[5]
     print(f"SKIPSTAT sizes {b[6]} emitted {emitted.mean():.3f} skipped {b[5] / max(1, a[0].size):.3f}")
+
+
+def test_dynamic_skip_against_the_automatic_sv_split():
+    """What the command line did before the skip against what it does with it: one launch per window cut along the SV list by the library's own policy
+    (partial sums added in part order) versus one launch per capture-size run without a split.  The summation orders differ, so scores may differ in
+    their last bits - nothing else may: the same candidates are constructed, the same survivors chosen, the same records printed."""
+    P = capi.make_params(120, 250, score_method=capi.SCORE_SVR)
+    mp = workloads.svr_model_path(CACHE, workloads.practice62()[0], 1024, rho=-2.2)
+    out = {}
+    for on in (False, True):
+        acc = capi.Accel(P)
+        acc.load_model_file(mp)
+        acc.set_dynamic_skip(on)                              # (no set_sv_split: the automatic policy - this small batch is cut along the SV list when the skip is off)
+        regions = _batch(acc, P)
+        acc.upload(regions)
+        acc.score_window(0, capi.SCORE_SVR)
+        scores, records = acc.download()
+        acc.replay_condense()
+        em, surv, mask = acc.download_replay()
+        out[on] = dict(scores=scores, records=records, em=em.copy(), surv=surv.copy(), mask=mask.copy())
+        acc.close()
+    a, b = out[False], out[True]
+    assert np.array_equal(a["records"], b["records"]) and np.array_equal(a["mask"], b["mask"]) and np.array_equal(a["em"], b["em"])
+    assert np.array_equal(a["surv"]["cand_index"], b["surv"]["cand_index"]) and np.array_equal(a["surv"]["record"], b["surv"]["record"])
+    emitted = a["mask"] != 0
+    d = np.abs(a["scores"][emitted] - b["scores"][emitted])
+    assert np.nanmax(d) < 1e-11                               # another summation order, nothing more
+    fmt = np.frompyfunc(lambda x: format(x, ".6g"), 1, 1)
+    have = a["surv"]["cand_index"] >= 0
+    assert np.array_equal(fmt(a["surv"]["score"][have]), fmt(b["surv"]["score"][have]))      # what a front end would print for the survivors
