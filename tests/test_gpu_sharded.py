@@ -279,6 +279,14 @@ def test_bench_and_mp_design_take_their_rccl_code_path_with_one_rank(tmp_path):
     line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert line["rccl_ranks"] == 1 and line["backend"] == "nccl" and line["parity_checked"] is True
     assert line["config"]["survivors_gathered_per_step"] == line["config"]["survivors_rank0"] > 0        # the gather ran, on device memory
+    # the exome beside the headline family (`exome_strong`: shards, gather straight from HBM, max over ranks) takes its RCCL path too
+    p = subprocess.run(launch + ["--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                                 "--no-measure-traffic", "--no-parity-gate", "--scale-base-regions", "1024", "--exome-regions", "0", "--sustain-seconds", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    ex = line["exome_strong"]
+    assert ex["n_gpus"] == 1 and ex["survivors_gathered"] >= ex["survivors_rank0"] > 0 and "first 1024" in ex["what"]
     meta = H.load_design("logistic_snp_trf")
     work = str(tmp_path / "mp1")
     os.makedirs(work)
