@@ -830,12 +830,18 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     }
     // -gpu_gather rccl: one communicator rank per device worker, rank 0 = the root whose HBM the windows are gathered into
     std::unique_ptr<RcclGather> gather;
+    std::thread gather_init;
+    int gather_init_rc = 0;
+    std::string gather_init_err;
     if (d->gather_rccl) {
         std::vector<int> devs;
         for (int k = 0; k < n_devices; k++) devs.push_back(k % visible);
-        gather.reset(new RcclGather());
         std::string gerr;
-        if (gather->init(devs, &gerr)) { std::cerr << "[mipgen] " << gerr << std::endl; d->failed = true; return fail(MIPGEN_HOST_E_ACCEL, 21, gerr); }
+        if (RcclGather::check_devices(devs, &gerr)) { std::cerr << "[mipgen] " << gerr << std::endl; d->failed = true; return fail(MIPGEN_HOST_E_ACCEL, 21, gerr); }
+        gather.reset(new RcclGather());
+        // RCCL's own set-up takes seconds (5.4 s measured for one rank): it runs beside the workers' start-up (model, counters, upload, first window)
+        // and is waited for before the first transfer is posted
+        gather_init = std::thread([&gather, devs, &gather_init_rc, &gather_init_err] { gather_init_rc = gather->init(devs, &gather_init_err); });
     }
     std::vector<std::unique_ptr<Channel>> chans;
     std::vector<std::thread> threads;
@@ -899,6 +905,12 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
         std::unique_ptr<Pending> pending;
         std::string gerr;
         int next_slot = 0;
+        {
+            const auto tw0 = std::chrono::steady_clock::now();
+            gather_init.join();                                          // the communicators are needed from here on
+            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+            if (gather_init_rc) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, 21, gather_init_err); std::cerr << "[mipgen] " << g_err << std::endl; }
+        }
         auto finish_pending = [&]() {
             if (!pending) return;
             std::unique_ptr<Pending> p = std::move(pending);
@@ -951,6 +963,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                                         << " MB to GPU 0 (one grouped send / receive + one D2H copy each): posting " << gather->seconds_posting
                                         << " s, waiting for a transfer that selection did not hide " << gather->seconds_waiting << " s\n";
         gather->destroy();                                             // (waits for a transfer still in flight: the workers' arrays are read until then)
+        if (clk.on) std::cerr << "[mipgen timing] rccl gather: communicator set-up " << gather->seconds_init << " s, tear-down " << gather->seconds_destroy << " s\n";
     }
     d->flush_err();
     if (clk.on) std::cerr << "[mipgen timing] tile_regions: waiting for the device workers " << t_wait << " s, selection stage " << t_select << " s\n";

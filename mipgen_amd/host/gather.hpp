@@ -23,12 +23,13 @@ public:
     ~RcclGather();
     RcclGather(const RcclGather&) = delete;
     RcclGather& operator=(const RcclGather&) = delete;
-    int init(const std::vector<int>& devices, std::string* err);
+    static int check_devices(const std::vector<int>& devices, std::string* err);   // cheap: what init() would refuse
+    int init(const std::vector<int>& devices, std::string* err);                     // ncclCommInitAll: seconds (RCCL's own set-up) - callers overlap it
     int post(int src_rank, const GatherPiece* pieces, int n, size_t total_bytes, int slot, std::string* err);
     int wait(int slot, std::string* err);
     char* host(int slot);
     void destroy();
-    double seconds_posting = 0.0, seconds_waiting = 0.0;
+    double seconds_posting = 0.0, seconds_waiting = 0.0, seconds_init = 0.0, seconds_destroy = 0.0;
     size_t bytes_moved = 0;
     int64_t windows = 0;
 

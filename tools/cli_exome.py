@@ -7,7 +7,7 @@ chromosome FASTA files (300 Mb) and a BED with the first N of the 200,000 exon-l
 
 (no bwa: the arm copy numbers come from the GPU k-mer counter; a 1,024-SV synthetic model beside the executable).
 
-    python3 tools/cli_exome.py [N] [workdir] [exome|regions5k] [svr|logistic|mixed]
+    python3 tools/cli_exome.py [N] [workdir] [exome|regions5k] [svr|logistic|mixed] [extra mipgen flags ...]      e.g. -gpu_gather rccl
 """
 import os
 import shutil
@@ -52,7 +52,7 @@ def main() -> None:
             "-bwa_genome_index", os.path.join(work, "genome", "index.fa"), "-genome_dir", os.path.join(work, "genome"), "-score_method", method,
             "-silent_mode", "on", "-gpu_copy_counter", "on"]
     t1 = time.time()
-    p = subprocess.run(argv + ["-gpu_timing", "on"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.run(argv + ["-gpu_timing", "on"] + sys.argv[5:], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     dt = time.time() - t1
     print("rc", p.returncode, f"wall {dt:.1f} s")
     print("".join(l + "\n" for l in p.stderr.decode().split("\n") if "timing" in l or "[mipgen_accel]" in l))
