@@ -22,7 +22,10 @@ int mipgen_pb_check(mipgen_accel* h)
 static int fix_print_boundaries(mipgen_accel* h, int r0, int r1, const mipgen_candidate* list, double* scores, const uint64_t* records, int64_t n, int method = MIPGEN_SCORE_SVR)
 {
     if (!h->print_exact || n <= 0 || (method == MIPGEN_SCORE_SVR && h->n_sv <= 0)) return MIPGEN_OK;
-    const unsigned int cap = (unsigned int)std::min<int64_t>(n / 1024 + 4096, (int64_t)1 << 24);
+    // (the re-scoring grid is the list's capacity: logistic scores sit within 1e-11 of a midpoint with probability <= 2e-5 - a short list keeps the
+    // launch cheap beside the 0.1-ms kernels of small logistic batches)
+    const unsigned int cap = method == MIPGEN_SCORE_SVR ? (unsigned int)std::min<int64_t>(n / 1024 + 4096, (int64_t)1 << 24)
+                                                        : (unsigned int)std::min<int64_t>(n / 8192 + 256, (int64_t)1 << 22);
     if (h->pb_cands.reserve(cap) || h->pb_idx.reserve(cap) || h->pb_scores.reserve(cap) || h->pb_count.reserve(1)) return MIPGEN_E_NOMEM;
     const double tol_rel = method == MIPGEN_SCORE_SVR ? 1e-10 : 1e-11, tol_abs = method == MIPGEN_SCORE_SVR ? 1e-13 * std::max(1.0, h->sum_abs_coef) : 1e-300;
     HIP_TRY(hipMemsetAsync(h->pb_count.p, 0, sizeof(unsigned int), h->stream));
@@ -41,7 +44,8 @@ static int fix_print_boundaries_survivors(mipgen_accel* h, int w, int method = M
     const Window& W = h->windows[(size_t)w];
     const int64_t n = 2 * W.n_pos;
     if (!h->print_exact || n <= 0 || (method == MIPGEN_SCORE_SVR && h->n_sv <= 0)) return MIPGEN_OK;
-    const unsigned int cap = (unsigned int)std::min<int64_t>(n / 256 + 1024, (int64_t)1 << 22);
+    const unsigned int cap = method == MIPGEN_SCORE_SVR ? (unsigned int)std::min<int64_t>(n / 256 + 1024, (int64_t)1 << 22)
+                                                        : (unsigned int)std::min<int64_t>(n / 4096 + 64, (int64_t)1 << 20);
     if (h->pb_cands.reserve(cap) || h->pb_idx.reserve(cap) || h->pb_scores.reserve(cap) || h->pb_count.reserve(1)) return MIPGEN_E_NOMEM;
     const double tol_rel = method == MIPGEN_SCORE_SVR ? 1e-10 : 1e-11, tol_abs = method == MIPGEN_SCORE_SVR ? 1e-13 * std::max(1.0, h->sum_abs_coef) : 1e-300;
     mipgen_survivor* surv = h->survivors.p + 2 * W.pos0;
