@@ -191,8 +191,11 @@ def test_region_cost_weights_balance_the_svr_shards():
         acc.upload(workloads.build_exome(acc, chrom_len, ivs[lo:hi], P))
         acc.set_timing(True)
         acc.score_condense_all(capi.SCORE_SVR)
-        acc.score_condense_all(capi.SCORE_SVR)
-        ms.append(acc.last_kernel_ms(0))
+        best = float("inf")
+        for _ in range(5):                      # the minimum of five: other test workers (pytest -n) may be sharing the GPU
+            acc.score_condense_all(capi.SCORE_SVR)
+            best = min(best, acc.last_kernel_ms(0))
+        ms.append(best)
         acc.close()
     assert abs(ms[0] - ms[1]) <= 0.10 * max(ms), ms
 
