@@ -246,8 +246,8 @@ int mipgen_accel_window_info(const mipgen_accel* h, int32_t w, int32_t* first_re
  * Asynchronous on the handle's stream.
  * Every parameter set the reference accepts is scored (mipgen.cpp:222-261, 427-444: any -arm_lengths / -capture_increment / range): SVR
  * requests outside the tiled kernel's limits (scan sizes below 3, more than 240 arm pairs, a tile beyond 160 KiB of LDS) take the
- * list scorer over the window's dense index range - same results, a lower rate.  The one limit left: that route refuses scan sizes above 1,024 bases
- * (MIPGEN_E_INVALID). */
+ * list scorer over the window's dense index range - same results, a lower rate (any scan size: the list kernels pass an insert through LDS in
+ * pieces of 1,024 bases). */
 int mipgen_accel_score_resident(mipgen_accel* h, int32_t method);       /* single-window batches; else MIPGEN_E_STATE */
 /* the same for result window w of a larger batch; the window's results replace the previous window's */
 int mipgen_accel_score_window(mipgen_accel* h, int32_t w, int32_t method);

@@ -63,10 +63,6 @@ static int fix_print_boundaries_survivors(mipgen_accel* h, int w, int method = M
 // (k_features_batch builds all 192 features per candidate, k_svr_gemm contracts them with the model on the FP64 matrix cores).
 static int svr_window_via_list(mipgen_accel* h, const Window& W)
 {
-    // the list kernels stage an insert of at most 1,024 bases (kernels_misc.hip: MAX_INSERT): beyond that they would hand out the values of
-    // bounds-skipped candidates - fail loudly instead
-    if (h->hp.max_capture - h->hp.min_sum > 1024)
-        return fail(MIPGEN_E_INVALID, "dense SVR scoring of scan sizes above 1024 bases is not supported (capture size %d, smallest arm sum %d)", h->hp.max_capture, h->hp.min_sum);
     const int64_t CH = (int64_t)1 << 19;                                  // candidates per chunk: 0.8 GB of features
     const size_t n_max = (size_t)std::min<int64_t>(CH, std::max<int64_t>(W.n_cand, 1));
     if (h->cand_in.reserve(n_max) || h->cand_records.reserve(n_max) || h->cand_feats.reserve(n_max * MIPGEN_N_FEATURES)) return MIPGEN_E_NOMEM;

@@ -33,16 +33,29 @@ __device__ __forceinline__ void ins_mer(int idx, int& k, int& x, int& y, int& z)
     if (r2 == 0) { k = 2; return; }
     k = 3; z = r2 - 1;
 }
-__device__ int count_mer(const uint8_t* s, int n, int k, int x, int y, int z)
+// windows that START in s[0, n) and end inside s[0, nx)
+__device__ int count_mer(const uint8_t* s, int n, int nx, int k, int x, int y, int z)
 {
     int c = 0;
-    for (int i = 0; i + k <= n; i++) {
+    for (int i = 0; i < n && i + k <= nx; i++) {
         bool m = s[i] == x;
         if (k >= 2) m = m && s[i + 1] == y;
         if (k >= 3) m = m && s[i + 2] == z;
         c += m;
     }
     return c;
+}
+
+// one piece of the class-switch walk of run_count_slow (logistic_device.h; SVMipv4.cpp:118-142) over oriented codes: `last` < 0 before the first base
+__device__ void run_count_piece(const uint8_t* s, int n, int& last, int& run)
+{
+    for (int i = 0; i < n; i++) {
+        const int b = s[i];
+        const int c = (b == BASE_G || b == BASE_C) ? 0 : ((b == BASE_A || b == BASE_T) ? 1 : 2);
+        if (last < 0) last = c;
+        else if (c == 0) { if (last != 0) { run++; last = 0; } }
+        else if (last != 1) { run++; last = c; }
+    }
 }
 
 }  // namespace
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     const bool minus = c.strand != 0;
     const int ss = C - e - l;
     const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) &&
-                       ss > 0 && ss <= MAX_INSERT && e <= MIPGEN_MAX_OLIGO && l <= MIPGEN_MAX_OLIGO && e >= 2 && l >= 2;
+                       ss > 0 && e <= MIPGEN_MAX_OLIGO && l <= MIPGEN_MAX_OLIGO && e >= 2 && l >= 2;
     if (!valid) {
         if (tid == 0) {
             if (scores) scores[blockIdx.x] = 0.0;
@@ -100,10 +113,6 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
         s_raw[1][off] = raw;
         const int b = raw & BASE_CODE_MASK;
         s_lig[i] = (uint8_t)(minus ? comp_code(b) : b);
-    }
-    for (int i = tid; i < ss; i += CAND_THREADS) {
-        int b = base_at(minus ? p + ss - 1 - i : p + i) & BASE_CODE_MASK;
-        s_ins[i] = (uint8_t)(minus ? comp_code(b) : b);
     }
     __syncthreads();
     // integer record fields (design_mip, mipgen.cpp:606-760)
@@ -150,10 +159,25 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
     const int j0 = s_lig[0], j1 = s_lig[1];
     const int jc = (j0 < 4 && j1 < 4) ? 4 * j0 + j1 : 255;
 
-    // mer counts: one lane per mer
-    if (tid < 84) { int k, x, y, z; ins_mer(tid, k, x, y, z); s_cnt[tid] = count_mer(s_ins, ss, k, x, y, z); }
-    else if (tid < 104) { int k, x, y; arm_mer(tid - 84, k, x, y); s_cnt[tid] = count_mer(s_ext, e, k, x, y, 0); }
-    else if (tid < 124) { int k, x, y; arm_mer(tid - 104, k, x, y); s_cnt[tid] = count_mer(s_lig, l, k, x, y, 0); }
+    // mer counts: one lane per mer.  The oriented insert passes through LDS in pieces of MAX_INSERT bases (+ two of look-ahead for the 2- / 3-mers
+    // that start in a piece): one piece for every realistic capture size, no limit on the others; the class-switch walk (SVMipv4.cpp:118-142) of the
+    // logistic score carries its state across the pieces
+    const bool want_run = ints_out || method == MIPGEN_SCORE_LOGISTIC;
+    int ins_count = 0, run_last = -1, run_n = 0;
+    for (int c0 = 0; c0 < ss; c0 += MAX_INSERT) {
+        const int len = min(MAX_INSERT, ss - c0), lenx = min(len + 2, ss - c0);
+        if (c0) __syncthreads();
+        for (int i = tid; i < lenx; i += CAND_THREADS) {
+            const int b = base_at(minus ? p + ss - 1 - (c0 + i) : p + c0 + i) & BASE_CODE_MASK;
+            s_ins[i] = (uint8_t)(minus ? comp_code(b) : b);
+        }
+        __syncthreads();
+        if (tid < 84) { int k, x, y, z; ins_mer(tid, k, x, y, z); ins_count += count_mer(s_ins, len, lenx, k, x, y, z); }
+        if (tid == 0 && want_run) run_count_piece(s_ins, len, run_last, run_n);   // (a serial walk: only where it is used)
+    }
+    if (tid < 84) s_cnt[tid] = ins_count;
+    else if (tid < 104) { int k, x, y; arm_mer(tid - 84, k, x, y); s_cnt[tid] = count_mer(s_ext, e, e, k, x, y, 0); }
+    else if (tid < 124) { int k, x, y; arm_mer(tid - 104, k, x, y); s_cnt[tid] = count_mer(s_lig, l, l, k, x, y, 0); }
     __syncthreads();
 
     // 192 features, SVMipv4.cpp:72-112
@@ -193,7 +217,7 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
         const int eA = s_cnt[84 + 0], eC = s_cnt[84 + 5], eG = s_cnt[84 + 10], eT = s_cnt[84 + 15];
         const int lA = s_cnt[104 + 0], lC = s_cnt[104 + 5], lG = s_cnt[104 + 10], lT = s_cnt[104 + 15];
         const int tA = s_cnt[0], tC = s_cnt[21], tG = s_cnt[42], tT = s_cnt[63];
-        const int run = (ints_out || method == MIPGEN_SCORE_LOGISTIC) ? run_count_slow(s_ins, 0, ss, false) : 1;   // a serial walk of the insert: only where it is used
+        const int run = want_run ? run_n + 1 : 1;
         if (ints_out) {
             mipgen_candidate_ints o;
             o.ext_a = eA; o.ext_c = eC; o.ext_g = eG; o.ext_t = eT;
@@ -310,7 +334,7 @@ __global__ __launch_bounds__(FB_WAVES * 64) void k_features_batch(
     const bool minus = c.strand != 0;
     const int ss = C - e - l;
     const bool valid = !(p - e <= 0 || p - l <= 0) && !(p + C - e - 1 > R.seq_stop || p + C - l - 1 > R.seq_stop) &&
-                       ss > 0 && ss <= MAX_INSERT && e <= MIPGEN_MAX_OLIGO && l <= MIPGEN_MAX_OLIGO && e >= 2 && l >= 2;
+                       ss > 0 && e <= MIPGEN_MAX_OLIGO && l <= MIPGEN_MAX_OLIGO && e >= 2 && l >= 2;
     double* fo = features + (int64_t)ci * MIPGEN_N_FEATURES;
     if (!valid) {
         if (lane == 0) records[ci] = 0;
@@ -328,10 +352,6 @@ __global__ __launch_bounds__(FB_WAVES * 64) void k_features_batch(
     const uint8_t raw_e = lane < e ? base_at(ext_start + lane) : (uint8_t)0, raw_l = lane < l ? base_at(lig_start + lane) : (uint8_t)0;
     if (lane < e) { const int b = raw_e & BASE_CODE_MASK; s_ext[minus ? e - 1 - lane : lane] = (uint8_t)(minus ? comp_code(b) : b); }
     if (lane < l) { const int b = raw_l & BASE_CODE_MASK; s_lig[minus ? l - 1 - lane : lane] = (uint8_t)(minus ? comp_code(b) : b); }
-    for (int i = lane; i < ss; i += 64) {
-        const int b = base_at(minus ? p + ss - 1 - i : p + i) & BASE_CODE_MASK;
-        s_ins[i] = (uint8_t)(minus ? comp_code(b) : b);
-    }
     // integer record fields (design_mip, mipgen.cpp:606-760): counts over the arms' bytes by wave ballots
     const bool in_e = lane < e, in_l = lane < l;
     auto cnt2 = [&](bool pe, bool pl) -> int { return __builtin_popcountll(__ballot(in_e && pe)) + __builtin_popcountll(__ballot(in_l && pl)); };
@@ -374,16 +394,27 @@ __global__ __launch_bounds__(FB_WAVES * 64) void k_features_batch(
         records[ci] = (uint64_t)ec | ((uint64_t)lc << 16) | ((uint64_t)min(masked_n, 255) << 32) | ((uint64_t)min(snp_count, 255) << 40) |
                       ((uint64_t)flags << 48) | ((uint64_t)(uint32_t)jc << 56);
     }
-    // mer histogram: a lane per window start; windows touching a non-ACGT code count nowhere (count_mer compares codes 0..3)
-    for (int i = lane; i < ss; i += 64) {
-        const int x = s_ins[i];
-        if (x < 4) {
-            atomicAdd(&s_cnt[21 * x], 1);
-            if (i + 1 < ss) {
-                const int y = s_ins[i + 1];
-                if (y < 4) {
-                    atomicAdd(&s_cnt[21 * x + 1 + 5 * y], 1);
-                    if (i + 2 < ss) { const int z = s_ins[i + 2]; if (z < 4) atomicAdd(&s_cnt[21 * x + 1 + 5 * y + 1 + z], 1); }
+    // mer histogram: a lane per window start; windows touching a non-ACGT code count nowhere (count_mer compares codes 0..3).  The oriented insert
+    // passes through LDS in pieces of MAX_INSERT bases + two of look-ahead (one piece for every realistic capture size)
+    for (int c0 = 0; c0 < ss; c0 += MAX_INSERT) {
+        const int len = min(MAX_INSERT, ss - c0), lenx = min(len + 2, ss - c0);
+        if (c0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        for (int i = lane; i < lenx; i += 64) {
+            const int b = base_at(minus ? p + ss - 1 - (c0 + i) : p + c0 + i) & BASE_CODE_MASK;
+            s_ins[i] = (uint8_t)(minus ? comp_code(b) : b);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < len; i += 64) {
+            const int x = s_ins[i];
+            if (x < 4) {
+                atomicAdd(&s_cnt[21 * x], 1);
+                if (i + 1 < lenx) {
+                    const int y = s_ins[i + 1];
+                    if (y < 4) {
+                        atomicAdd(&s_cnt[21 * x + 1 + 5 * y], 1);
+                        if (i + 2 < lenx) { const int z = s_ins[i + 2]; if (z < 4) atomicAdd(&s_cnt[21 * x + 1 + 5 * y + 1 + z], 1); }
+                    }
                 }
             }
         }

@@ -68,8 +68,7 @@ static const char* k_doc =
     "                         capture-window uniqueness (mapping flag) = no other locus within one substitution; both on the GPU, bwa is not run\n"
     "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n"
     "  -gpu_gather pcie|rccl   (extension) result windows come down every GPU's own PCIe link (default), or travel to GPU 0 over RCCL / xGMI first\n"
-    "limits of this build (the reference has none): arm lengths up to 64 bases, 256 arm-length pairs; svr / mixed scoring of scan targets\n"
-    "  (capture size - smallest arm length sum) above 1,024 bases is refused with an error\n";
+    "limits of this build (the reference has none): arm lengths up to 64 bases, 256 arm-length pairs\n";
 
 static void set_defaults(Options& o)
 {

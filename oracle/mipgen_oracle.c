@@ -479,7 +479,7 @@ int mo_design(const mipgen_params* P, const mipgen_region* R, const mipgen_candi
     }
     d->mapping_failed = '0'; d->snp_failed = '0'; d->masking_failed = '0'; d->has_snp_mip = 0;
 
-    char tmp[1024];
+    char tmp[MO_MAX_INSERT];
     const char* masked = R->masked_seq ? R->masked_seq : R->seq;
     /* insert, mipgen.cpp:461-462 */
     if (d->scan_size >= (int)sizeof(tmp) || d->scan_size < 0) return 1;

@@ -55,6 +55,7 @@ int mo_svm_densify(const mo_model* m, double* sv, double* coef);
 double mo_predict_value(const mo_model* m, const double* x192);
 
 /* ---- level 2: one candidate of a region (tile_regions body + design_mip, mipgen.cpp:446-497,599-762) */
+#define MO_MAX_INSERT 8192
 typedef struct mo_designed {
     int32_t ext_start, ext_stop, lig_start, lig_stop, scan_start, scan_stop, scan_size;
     int32_t ext_copy, lig_copy, snp_count, masked_n;
@@ -63,7 +64,7 @@ typedef struct mo_designed {
     char ext_seq[MIPGEN_MAX_OLIGO + 1];
     char lig_seq[MIPGEN_MAX_OLIGO + 1];
     char junction[3];
-    char ins_seq[1024];
+    char ins_seq[MO_MAX_INSERT];   /* the reference holds std::strings (no limit); this restatement covers scan sizes below MO_MAX_INSERT */
     /* alternate-allele arms when has_snp_mip (mipgen.cpp:683-689,745-751); needs the allele table, see mo_design */
     char snp_ext_seq[MIPGEN_MAX_OLIGO + 1];
     char snp_lig_seq[MIPGEN_MAX_OLIGO + 1];

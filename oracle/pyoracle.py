@@ -34,7 +34,7 @@ class Designed(C.Structure):
                 ("arm_fraction_masked", C.c_double),
                 ("mapping_failed", C.c_char), ("snp_failed", C.c_char), ("masking_failed", C.c_char), ("has_snp_mip", C.c_char),
                 ("ext_seq", C.c_char * (capi.MAX_OLIGO + 1)), ("lig_seq", C.c_char * (capi.MAX_OLIGO + 1)),
-                ("junction", C.c_char * 3), ("ins_seq", C.c_char * 1024),
+                ("junction", C.c_char * 3), ("ins_seq", C.c_char * 8192),                      # MO_MAX_INSERT
                 ("snp_ext_seq", C.c_char * (capi.MAX_OLIGO + 1)), ("snp_lig_seq", C.c_char * (capi.MAX_OLIGO + 1))]
 
 
@@ -245,9 +245,9 @@ def score_designed(d: Designed, method: int, lrc: np.ndarray, model: Optional[Mo
 
 def print_details(region: capi.RegionData, strand: int, d: Designed, score: float, middle: bytes, mip_index: int,
                   minor: bool = False) -> bytes:
-    buf = C.create_string_buffer(4096)
+    buf = C.create_string_buffer(32768)
     n = oracle().mo_print_details(region.chrom.encode(), region.label.encode(), region.start, region.stop, strand,
-                                  C.byref(d), score, middle, mip_index, int(minor), buf, 4096)
+                                  C.byref(d), score, middle, mip_index, int(minor), buf, 32768)
     return buf.raw[:n]
 
 

@@ -212,6 +212,11 @@ DESIGNS2 = [
          tags="5,0", snps=False, trf=False, bwa="hashed", model=None,
          extra=["-ext_min_length", "18", "-lig_min_length", "20", "-logistic_priority_score", "0.8", "-logistic_optimal_score", "0.93",
                 "-max_arm_copy_product", "20", "-target_arm_copy", "5"]),
+    # capture sizes above 1,100 bases: scan sizes beyond the 1,024 bases the accelerator's list kernels stage at a time (the reference holds std::strings)
+    dict(name="long_capture_logistic", method="logistic", ivs=[("1", 10000, 10040, "L")], minC=1100, maxC=1110, sums=[40, 42, 44], flank=0, tags="5,0", snps=True,
+         trf=False, bwa="hashed", model=None, extra=[]),
+    dict(name="long_capture_svr", method="svr", ivs=[("1", 16000, 16030, "L")], minC=1100, maxC=1105, sums=[44, 45], flank=0, tags="5,0", snps=False,
+         trf=False, bwa="hashed", model="svr_syn_64.model", extra=[]),
     # the same kind of limits for the SVR, given through -file_of_parameters (mipgen.cpp:1445-1481)
     dict(name="limits_svr_parameter_file", method="svr", ivs=[("1", 77000, 77350, "s")], minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0", snps=False,
          trf=False, bwa="hashed", model="svr_syn_64.model", extra=[],

@@ -382,7 +382,7 @@ int mipgen_accel_format_all_mips(mipgen_accel* h, const mipgen_record_names* nam
     const Win& W = h->windows[(size_t)h->cur];
     h->text.clear();
     int64_t idx = first_index;
-    std::vector<char> buf(8192);
+    std::vector<char> buf(4 * MO_MAX_INSERT);
     for (int i = W.r0; i < W.r1; i++) {
         const mipgen_grid& g = h->grids[(size_t)i];
         const mipgen_record_names& nm = names[i - W.r0];

@@ -529,6 +529,44 @@ def test_parameter_sets_outside_the_dense_svr_limits(genome, tmp_path):
     em2, sv2 = acc.download_survivors()
     assert int(em2[0]) == n_emit and np.array_equal(sv2["cand_index"], osurv["cand_index"])
     acc.close()
+    # (c) capture sizes of 1,290-1,300 bases: scan sizes beyond the 1,024 bases the list kernels stage at a time (the insert's mers and class switches are
+    # counted piece by piece); both scoring methods, the dense grid and the literal single-candidate route
+    P = capi.make_params(1290, 1300, score_method=capi.SCORE_SVR)
+    acc = capi.Accel(P)
+    mpl = str(tmp_path / "long.model")                                      # support vectors drawn from captures of this length: kernel values of O(1)
+    synth.synthetic_svr_model(mpl, genome, 48, seed=9, gamma=2e-4, capture=(1285, 1300))
+    acc.load_model_file(mpl)
+    om = po.Model(mpl)
+    rd = capi.build_region(genome, "1", 9000, 9012, P, bwa_mode="hashed", label="long", lrc=np.linspace(0.02, 0.2, 44))
+    for method, model in ((capi.SCORE_SVR, om), (capi.SCORE_LOGISTIC, None)):
+        grids, scores, records = acc.score_regions([rd], method)
+        og, os_, or_ = po.score_region_dense(P, rd, method, model)
+        assert grids[0].count == og.count and np.array_equal(records, or_)
+        ok, mx = _close(scores, os_)
+        assert ok.all(), (method, mx)
+        valid = (capi.rec_flags(records) & capi.FLAG_VALID) != 0
+        assert valid.sum() > 1000 and np.unique(np.round(scores[valid], 6)).size > 500
+        acc.replay_condense()
+        em, sv, mask = acc.download_replay()
+        n_emit, omask = po.replay_region(P, rd, scores, records)
+        assert int(em[0]) == n_emit and np.array_equal(mask, omask)
+    g = grids[0]
+    pairs = capi.arm_pairs_of(P)
+    cands = [(0, g.first_pos + 3, 1300, pairs[0][0], pairs[0][1], 0), (0, g.first_pos + 5, 1295, pairs[-1][0], pairs[-1][1], 1),
+             (0, g.first_pos + 1, 1290, pairs[20][0], pairs[20][1], 1)]
+    lrc = np.array(rd.c.long_range_content[:])
+    for method, model in ((capi.SCORE_SVR, om), (capi.SCORE_LOGISTIC, None)):
+        s_lit, r_lit, _, ints = acc.score_candidates(cands, method, want_ints=True)
+        for i, c in enumerate(cands):
+            sk, d = po.design(P, rd, c)
+            assert not sk and d.scan_size == c[2] - c[3] - c[4] > 1024
+            want_s, _, want_ints = po.score_designed(d, method, lrc, model)
+            assert (capi.rec_flags(r_lit[i:i + 1]) & capi.FLAG_VALID).all()
+            for f in ("ins_a", "ins_c", "ins_g", "ins_t", "run_count", "junction", "scan_size"):
+                assert getattr(ints[i], f) == getattr(want_ints, f), (i, f)
+            ok, mx = _close(s_lit[i:i + 1], [want_s])
+            assert ok.all(), (method, i, mx)
+    acc.close()
 
 
 @pytest.mark.parametrize("n_sv", [1, 2, 4, 7])

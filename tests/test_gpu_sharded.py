@@ -184,18 +184,23 @@ def test_region_cost_weights_balance_the_svr_shards():
     ivs = all_iv[:1536]
     w = workloads.shard_weights(ivs, P, True)
     (lo0, hi0), (lo1, hi1) = mdist.shard_regions(w.tolist(), 2)
-    ms = []
+    accs = []
     for lo, hi in ((lo0, hi0), (lo1, hi1)):
         acc = capi.Accel(P)
         acc.load_model_file(workloads.svr_model_path("/tmp/mipgen_test_models", workloads.practice62()[0], 256))
         acc.upload(workloads.build_exome(acc, chrom_len, ivs[lo:hi], P))
         acc.set_timing(True)
         acc.score_condense_all(capi.SCORE_SVR)
-        best = float("inf")
-        for _ in range(5):                      # the minimum of five: other test workers (pytest -n) may be sharing the GPU
+        accs.append(acc)
+    # the minimum over alternating passes: other test workers (pytest -n) may be sharing the GPU, and a pass that ran beside their kernels says nothing
+    ms = [float("inf"), float("inf")]
+    for it in range(16):
+        for k, acc in enumerate(accs):
             acc.score_condense_all(capi.SCORE_SVR)
-            best = min(best, acc.last_kernel_ms(0))
-        ms.append(best)
+            ms[k] = min(ms[k], acc.last_kernel_ms(0))
+        if it >= 2 and abs(ms[0] - ms[1]) <= 0.10 * max(ms):
+            break
+    for acc in accs:
         acc.close()
     assert abs(ms[0] - ms[1]) <= 0.10 * max(ms), ms
 
