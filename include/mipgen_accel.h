@@ -102,7 +102,12 @@ typedef struct mipgen_params {
     double lower_score_limit;
     int32_t max_arm_copy_product;    /* -max_arm_copy_product (mipgen.cpp:197) */
     int32_t target_arm_copy;         /* -target_arm_copy (mipgen.cpp:198) */
-    int32_t reserved[6];
+    /* The reference keys its arm-length lists by sum and keeps a key whose list is EMPTY (-arm_length_sums 30,41,62 with the default minimum arm
+     * lengths: 30 < 16 + 18 and 62 > 30 + 30 hold no pair, mipgen.cpp:245-258); the first scan position uses the LARGEST key (:421) and the one list
+     * :434 never switches off is that of the SMALLEST key.  0 = the largest / smallest sum of the pairs above (every list non-empty). */
+    int32_t arm_sum_key_max;
+    int32_t arm_sum_key_min;
+    int32_t reserved[4];
 } mipgen_params;
 
 /*

@@ -35,7 +35,8 @@ class Params(C.Structure):
         ("arm_ext", C.c_int32 * MAX_ARM_PAIRS), ("arm_lig", C.c_int32 * MAX_ARM_PAIRS),
         ("check_copy_number", C.c_int32), ("logistic_heuristic", C.c_int32),
         ("masked_arm_threshold", C.c_double), ("upper_score_limit", C.c_double), ("lower_score_limit", C.c_double),
-        ("max_arm_copy_product", C.c_int32), ("target_arm_copy", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("max_arm_copy_product", C.c_int32), ("target_arm_copy", C.c_int32), ("arm_sum_key_max", C.c_int32), ("arm_sum_key_min", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -86,7 +87,8 @@ def make_params(min_capture: int, max_capture: int, score_method: int = SCORE_LO
                 max_mip_overlap: int = 30, arm_pairs: Optional[Sequence[Tuple[int, int]]] = None,
                 check_copy_number: bool = True, logistic_heuristic: bool = True, masked_arm_threshold: float = 0.5,
                 logistic_optimal: float = 0.98, logistic_priority: float = 0.9, svr_optimal: float = 2.2,
-                svr_priority: float = 1.5, max_arm_copy_product: int = 75, target_arm_copy: int = 20) -> Params:
+                svr_priority: float = 1.5, max_arm_copy_product: int = 75, target_arm_copy: int = 20,
+                arm_sum_keys: Optional[Tuple[int, int]] = None) -> Params:
     """Defaults as mipgen::set_default_args / parse_arg_values (/root/reference/mipgen.cpp:164-188,209-216,243,264-265)."""
     from .synth import arm_pairs_from_sums
     p = Params()
@@ -108,6 +110,8 @@ def make_params(min_capture: int, max_capture: int, score_method: int = SCORE_LO
     p.lower_score_limit = svr_priority if svr else logistic_priority
     p.max_arm_copy_product = max_arm_copy_product
     p.target_arm_copy = target_arm_copy
+    if arm_sum_keys is not None:                 # (largest, smallest) key of the reference's arm-sum map where such a key holds an empty list
+        p.arm_sum_key_max, p.arm_sum_key_min = arm_sum_keys
     return p
 
 

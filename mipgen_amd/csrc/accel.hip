@@ -58,6 +58,11 @@ int mipgen_accel_create(const mipgen_params* params, int device, void* stream, m
         D.len_slot[e] = 0; D.len_slot[l] = 0;
     }
     if (params->min_capture_size - D.max_sum < 1) { delete h; return fail(MIPGEN_E_INVALID, "min_capture_size leaves no scan target (capture size <= arm length sum)"); }
+    // keys of the reference's arm-sum map whose lists are empty (mipgen.cpp:245-258 -> :421, :434): they can only lie outside the pairs' own sums
+    if ((params->arm_sum_key_max > 0 && params->arm_sum_key_max < D.max_sum) || (params->arm_sum_key_min > 0 && params->arm_sum_key_min > D.min_sum)) {
+        delete h; return fail(MIPGEN_E_INVALID, "arm_sum_key_max / arm_sum_key_min inside the arm pairs' own sums [%d, %d]", D.min_sum, D.max_sum);
+    }
+    D.key_min_sum = params->arm_sum_key_min > 0 ? params->arm_sum_key_min : D.min_sum;
     // limits of the dense SVR kernel are reported when an SVR launch is requested: logistic designs are not bound by them
     if (params->min_capture_size - D.max_sum < 3) h->svr_geometry_error = "min_capture_size leaves a scan size < 3 (insert 3-mer frequencies are undefined)";
     int slot = 0;

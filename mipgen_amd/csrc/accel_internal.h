@@ -316,7 +316,7 @@ static inline int n_sizes_all(const mipgen_params& P)
 static inline void grid_of(const mipgen_params& P, const DevParams& D, const mipgen_region& R, mipgen_grid* g)
 {
     // positions: mipgen.cpp:421-425; static size skip: mipgen.cpp:429
-    int cur = R.start_flanked - P.max_capture_size + D.max_sum;
+    int cur = R.start_flanked - P.max_capture_size + (P.arm_sum_key_max > 0 ? P.arm_sum_key_max : D.max_sum);   // (:421 uses the largest KEY of the arm-sum map)
     if (cur < 0) cur = 0;
     g->first_pos = cur + 1;
     g->n_pos = std::max(0, R.stop_flanked - cur);

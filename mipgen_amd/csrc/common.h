@@ -74,7 +74,7 @@ struct DevParams {
     int32_t e_min, e_max, l_min, l_max;        // arm-length ranges over the pair list
     int32_t n_len_slots;                        // distinct oligo lengths (copy table slots)
     int32_t max_arm_copy_product, target_arm_copy;
-    int32_t pad0;
+    int32_t key_min_sum;                        // the smallest KEY of the reference's arm-sum map (mipgen.cpp:434; = min_sum unless a smaller sum holds no pair)
     double masked_arm_threshold, upper, lower;
     uint8_t arm_ext[MIPGEN_MAX_ARM_PAIRS];
     uint8_t arm_lig[MIPGEN_MAX_ARM_PAIRS];

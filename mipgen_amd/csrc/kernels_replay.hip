@@ -67,7 +67,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense(
     const int64_t base = R.out_off + (int64_t)pi * per_pos;
     const double upper = P->upper, lower = P->lower;
     const bool heuristic = P->score_method == MIPGEN_SCORE_LOGISTIC && P->logistic_heuristic;
-    const int min_sum = P->min_sum;
+    const int min_sum = P->key_min_sum;
     const uint64_t lane_bit = 1ull << lane, below_me = lane_bit - 1;
 
     // ---- replay, mipgen.cpp:426-497 ---------------------------------------------------------------------
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
     const bool in = lane < A;
     const int e = in ? P->arm_ext[lane] : 1, l = in ? P->arm_lig[lane] : 1, gend = in ? P->group_end[lane] : 0;
     const uint64_t list_ends = __ballot(in && lane + 1 == gend);           // the last pair of every list
-    const uint64_t min_lists = __ballot(in && e + l == P->min_sum);        // pairs of the list :434 never switches off
+    const uint64_t min_lists = __ballot(in && e + l == P->key_min_sum);        // pairs of the list :434 never switches off
     const uint64_t ends_below = list_ends & below_me;
     const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
     const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_carry(
     const bool in = lane < A;
     const int e = in ? P->arm_ext[lane] : 1, l = in ? P->arm_lig[lane] : 1, gend = in ? P->group_end[lane] : 0;
     const uint64_t list_ends = __ballot(in && lane + 1 == gend);
-    const uint64_t min_lists = __ballot(in && e + l == P->min_sum);
+    const uint64_t min_lists = __ballot(in && e + l == P->key_min_sum);
     const uint64_t ends_below = list_ends & below_me;
     const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
     const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_svr_run_state(int64_t n_pos, const DevP
     const int ki0 = (int)(rb & 0xFFFFu), kc = (int)(rb >> 16);
     if (kc == 0) return;
     const DevRegion& R = regions[ri];
-    const int A = P->n_pairs, nK = R.n_sizes, min_sum = P->min_sum;
+    const int A = P->n_pairs, nK = R.n_sizes, min_sum = P->key_min_sum;
     const double upper = P->upper;
     const int64_t base = R.out_off + (int64_t)pi * nK * A * 2;
     double pb = pbs_io[gp];                                            // previous_best_score (:426: 0 at the first size)

@@ -809,6 +809,24 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
     if (n_devices <= 0) n_devices = d->n_devices > 0 ? d->n_devices : visible;
     const int n = (int)d->regions.size();
+    if (d->o.arm_pairs.empty()) {
+        // every arm-sum list is empty (-arm_length_sums 39 -ext_min_length 18 -lig_min_length 22): the reference walks the scan positions, constructs
+        // nothing (mipgen.cpp:438) and hands empty tables to the selection stage region after region (:503-515) - no accelerator call to make
+        int rc0 = 0;
+        for (int i = 0; i < n && rc0 == 0; i++) {
+            const Region& r = d->regions[(size_t)i];
+            mipgen_grid g = {};
+            const int cur = std::max(0, r.start_fl - d->o.max_capture + d->o.max_arm_sum);                                  // :421-422
+            g.first_pos = cur + 1; g.n_pos = std::max(0, r.stop_fl - cur);
+            std::vector<mipgen_survivor> none(2 * (size_t)g.n_pos);
+            for (auto& s : none) { s.cand_index = -1; s.score = 0.0; s.record = 0; }
+            try { rc0 = mipgen_design_select_region_collapsed(d, i, &g, none.data(), 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr); }
+            catch (int e) { rc0 = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
+        }
+        d->flush_err();
+        if (rc0) d->failed = true;
+        return rc0;
+    }
     n_devices = std::max(1, std::min(n_devices, n));
     // contiguous region ranges balanced by dense-grid size (the reference's region order is the order of the selection stage)
     std::vector<int64_t> weight((size_t)n);

@@ -224,6 +224,8 @@ mipgen_params Options::accel_params() const
     p.upper_score_limit = svr ? svr_optimal : logistic_optimal;
     p.lower_score_limit = svr ? svr_priority : logistic_priority;
     p.max_arm_copy_product = max_arm_copy; p.target_arm_copy = target_arm_copy;
+    // the largest / smallest KEY of the arm-sum map, which may hold an empty list (-arm_length_sums 30,41,62: mipgen.cpp:245-258 -> :421, :434)
+    p.arm_sum_key_max = max_arm_sum; p.arm_sum_key_min = std::max(1, min_arm_sum);
     return p;
 }
 

@@ -607,14 +607,16 @@ static int n_sizes_all(const mipgen_params* P)
     return (P->max_capture_size - P->min_capture_size) / inc + 1;
 }
 
-static int max_arm_sum(const mipgen_params* P)
+static int max_arm_sum(const mipgen_params* P)          /* *arm_length_sum_set.rbegin(), mipgen.cpp:421 (a key may hold an empty list) */
 {
+    if (P->arm_sum_key_max > 0) return P->arm_sum_key_max;
     int m = 0;
     for (int i = 0; i < P->n_arm_pairs; i++) { int s = P->arm_ext[i] + P->arm_lig[i]; if (s > m) m = s; }
     return m;
 }
-static int min_arm_sum(const mipgen_params* P)
+static int min_arm_sum(const mipgen_params* P)          /* *arm_length_sum_set.begin(), mipgen.cpp:434 */
 {
+    if (P->arm_sum_key_min > 0) return P->arm_sum_key_min;
     int m = INT_MAX;
     for (int i = 0; i < P->n_arm_pairs; i++) { int s = P->arm_ext[i] + P->arm_lig[i]; if (s < m) m = s; }
     return m;

@@ -217,6 +217,15 @@ DESIGNS2 = [
          trf=False, bwa="hashed", model=None, extra=[]),
     dict(name="long_capture_svr", method="svr", ivs=[("1", 16000, 16030, "L")], minC=1100, maxC=1105, sums=[44, 45], flank=0, tags="5,0", snps=False,
          trf=False, bwa="hashed", model="svr_syn_64.model", extra=[]),
+    # arm-length sums whose lists are EMPTY (30 < 16 + 18, 62 > 30 + 30: mipgen.cpp:245-258): the first scan position still uses the largest key (:421), and
+    # the one list :434 never switches off is that of the smallest key - i.e. none; low optimal scores so that the switch-off happens
+    dict(name="empty_sum_lists", method="logistic", ivs=[("1", 11000, 11300, "e"), ("1", 11900, 11960, "f")], minC=150, maxC=160, sums=[30, 41, 43, 62], flank=0,
+         tags="5,0", snps=False, trf=False, bwa="hashed", model=None, extra=["-logistic_optimal_score", "0.9"]),
+    dict(name="empty_sum_lists_svr", method="svr", ivs=[("1", 17000, 17090, "e")], minC=150, maxC=155, sums=[30, 44, 45, 61], flank=0,
+         tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_64.model", extra=["-svr_optimal_score", "1.5"]),
+    # no arm pair at all (39 < 18 + 22): the reference completes with header-only files and the coverage gaps
+    dict(name="no_arm_pairs", method="logistic", ivs=[("1", 12000, 12150, "n"), ("1", 12400, 12420, "m")], minC=150, maxC=160, sums=[39], flank=3,
+         tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-ext_min_length", "18", "-lig_min_length", "22"]),
     # the same kind of limits for the SVR, given through -file_of_parameters (mipgen.cpp:1445-1481)
     dict(name="limits_svr_parameter_file", method="svr", ivs=[("1", 77000, 77350, "s")], minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0", snps=False,
          trf=False, bwa="hashed", model="svr_syn_64.model", extra=[],
@@ -291,8 +300,8 @@ def parse_bed_text(text: str):
     return ivs
 
 
-def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz") -> None:
-    out = os.path.join(HERE, "design_" + d["name"])
+def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz", out_root: str = HERE) -> None:
+    out = os.path.join(out_root, "design_" + d["name"])
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
     w = "/tmp/mipgen_golden_" + d["name"]
@@ -364,8 +373,11 @@ def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz") -> None:
         if key == "all_mips" and not d.get("keep_all", False):
             if genome_name != "genome_chr1.fa.gz":
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from helpers import normalise_flags
-                meta["sha256"]["all_mips_normalised"] = hashlib.sha256(b"\n".join(normalise_flags(l) for l in data.split(b"\n"))).hexdigest()
+                from helpers import normalise_all_mips
+                norm = normalise_all_mips(data)
+                meta["sha256"]["all_mips_normalised"] = hashlib.sha256(norm).hexdigest()
+                if norm.count(b"\n") != meta["lines"]["all_mips"]:          # (the reference's uninitialised flag byte was a newline somewhere)
+                    meta["lines"]["all_mips_normalised"] = norm.count(b"\n")
             continue
         with gzip.GzipFile(out + f"/ref.{key}.txt.gz", "wb", mtime=0) as gz:
             gz.write(data)

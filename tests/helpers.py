@@ -3,6 +3,7 @@ stage (/root/reference/mipgen.cpp:981-1043 sort/merge, :1180-1229 -genome_dir sl
 from __future__ import annotations
 
 import gzip
+import re
 import json
 import os
 from typing import Dict, List, Optional, Tuple
@@ -20,8 +21,8 @@ def golden_genome(name: str = "genome_chr1.fa.gz") -> bytes:
         return b"".join(l.strip() for l in fh.read().split(b"\n")[1:])
 
 
-def load_design(name: str) -> dict:
-    d = os.path.join(GOLDEN, "design_" + name)
+def load_design(name: str, root: str = GOLDEN) -> dict:
+    d = os.path.join(root, "design_" + name)
     with open(os.path.join(d, "meta.json")) as fh:
         meta = json.load(fh)
     meta["dir"] = d
@@ -94,13 +95,19 @@ def design_regions(meta: dict, genome: bytes, params: capi.Params, lrc_fn=None) 
     return out
 
 
+_FLAGS_RE = re.compile(rb"\t([+-])\t1([01])[\s\S]\t")
+
+
+def normalise_all_mips(data: bytes) -> bytes:
+    """The reference leaves masking_failed uninitialised when mapping fails (mipgen.cpp:615-625 returns before :626-633 assigns it) and prints whatever
+    byte the stack held as the third flag character - usually a digit, but tools/diff_probe.py has met a TAB (seed 1, design 50) and a NEWLINE (seed 3,
+    design 37: one record on two lines).  Compare such files with that byte forced to '0': the flags field follows the strand field."""
+    return _FLAGS_RE.sub(rb"\t\1\t1\g<2>0\t", data)
+
+
 def normalise_flags(line: bytes) -> bytes:
-    """The reference leaves masking_failed uninitialised when mapping fails (mipgen.cpp:615-625 returns before
-    :626-633 assigns it), printing an arbitrary byte; compare such records with that byte forced to '0'."""
-    f = line.split(b"\t")
-    if len(f) > 18 and len(f[18]) == 3 and f[18][0:1] == b"1":
-        f[18] = f[18][0:2] + b"0"
-    return b"\t".join(f)
+    """normalise_all_mips for one record."""
+    return normalise_all_mips(line)
 
 
 # ---- the drop-in command line on a golden design ------------------------------------------------------------------------------
@@ -176,15 +183,16 @@ def compare_outputs(meta: dict, work: str, keys=("collapsed_mips", "picked_mips"
     if not check_all:
         return
     got_all = open(os.path.join(work, "out.all_mips.txt"), "rb").read()
-    assert got_all.count(b"\n") == meta["lines"]["all_mips"], (got_all.count(b"\n"), meta["lines"]["all_mips"])
+    want_lines = meta["lines"].get("all_mips_normalised", meta["lines"]["all_mips"])
+    assert got_all.count(b"\n") == want_lines, (got_all.count(b"\n"), want_lines)
     if os.path.exists(os.path.join(meta["dir"], "ref.all_mips.txt.gz")):
         ref_all = gzip.open(os.path.join(meta["dir"], "ref.all_mips.txt.gz"), "rb").read()
         g = got_all.split(b"\n")
-        r = [normalise_flags(l) for l in ref_all.split(b"\n")]        # uninitialised masking byte of the reference, see normalise_flags
+        r = normalise_all_mips(ref_all).split(b"\n")                  # uninitialised masking byte of the reference
         bad = [i for i, (a, b) in enumerate(zip(g, r)) if a != b]
         assert not bad, (meta["name"], "all_mips first diff line", bad[0] + 1, g[bad[0]][:200], r[bad[0]][:200])
     elif meta["sha256"].get("all_mips_normalised"):
-        norm = b"\n".join(normalise_flags(l) for l in got_all.split(b"\n"))
+        norm = normalise_all_mips(got_all)
         assert hashlib.sha256(norm).hexdigest() == meta["sha256"]["all_mips_normalised"]
     else:
         assert hashlib.sha256(got_all).hexdigest() == meta["sha256"]["all_mips"]

@@ -931,3 +931,43 @@ def test_list_scorer_special_values(genome):
         so, _, _ = po.score_designed(d, capi.SCORE_SVR, lrc, om)
         assert abs(sc[int(k)] - so) <= 1e-5 or (np.isnan(so) and np.isnan(sc[int(k)])), (c, sc[int(k)], so)
     acc.close()
+
+
+@pytest.mark.parametrize("method", [capi.SCORE_LOGISTIC, capi.SCORE_SVR])
+def test_arm_sum_keys_with_empty_lists(genome, method):
+    """`-arm_length_sums 30,41,43,62` with the default minimum arm lengths: the lists of 30 and 62 are empty but their keys stay in the reference's map
+    (mipgen.cpp:245-258), so the first scan position is computed from 62 (:421) and no list is exempt from the switch-off of :434 (the exempt one is the
+    list of the smallest KEY).  The boundary carries the two keys (mipgen_params.arm_sum_key_max / _min); grid, replay mask, emitted count and survivors
+    against the oracle, with thresholds low enough for the switch-off to happen; the same pairs WITHOUT the keys must give a different grid and mask."""
+    pairs = synth_pairs = __import__("mipgen_amd.synth", fromlist=["x"]).arm_pairs_from_sums([41, 43])
+    kw = dict(score_method=method, arm_pairs=pairs, logistic_optimal=0.9, svr_optimal=1.5)
+    mp64 = os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
+    om = po.Model(mp64) if method == capi.SCORE_SVR else None
+    got = {}
+    for keys in ((62, 30), None):
+        P = capi.make_params(150, 160, arm_sum_keys=keys, **kw)
+        acc = capi.Accel(P)
+        if om is not None:
+            acc.load_model_file(mp64)
+        rd = capi.build_region(genome, "1", 9000, 9120, P, bwa_mode="hashed", label="keys", lrc=np.full(44, 0.03))
+        grids, scores, records = acc.score_regions([rd], method)
+        og, os_, or_ = po.score_region_dense(P, rd, method, om)
+        g = grids[0]
+        assert (g.first_pos, g.n_pos, g.count) == (og.first_pos, og.n_pos, og.count) and np.array_equal(records, or_)
+        acc.replay_condense()
+        em, sv, mask = acc.download_replay()
+        n_emit, omask = po.replay_region(P, rd, scores, records)
+        assert int(em[0]) == n_emit and np.array_equal(mask, omask)
+        osurv = po.condense_region(P, rd, scores, records, omask)
+        assert np.array_equal(sv["cand_index"], osurv["cand_index"])
+        acc.score_condense_all(method)
+        em2, sv2 = acc.download_survivors()
+        assert int(em2[0]) == n_emit and np.array_equal(sv2["cand_index"], osurv["cand_index"])
+        got[keys] = (g.first_pos, g.n_pos, n_emit)
+        acc.close()
+    assert got[(62, 30)][0] == got[None][0] + 19 and got[(62, 30)][1] == got[None][1] - 19            # 62 - 43 positions fewer
+    assert got[(62, 30)][2] != got[None][2]
+    # keys inside the pairs' own sums are refused
+    P = capi.make_params(150, 160, arm_sum_keys=(42, 0), **kw)
+    with pytest.raises(RuntimeError, match="arm_sum_key"):
+        capi.Accel(P)

@@ -1,0 +1,31 @@
+"""GPU: the differential probe (tools/diff_probe.py).  Where tests/golden_probe/ holds designs the real reference was run on in the build container
+(random parameter sets, BEDs and options; git-ignored scratch), the drop-in command line must write the same files - with one or two device workers,
+forced result windows and either gather route.  Skipped where the directory is absent (a fresh clone: the committed goldens are tests/golden/)."""
+import os
+import zlib
+
+import pytest
+
+from tests import helpers as H
+from tests.test_gpu_cli import run_cli
+
+pytestmark = pytest.mark.gpu
+PROBE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_probe")
+NAMES = sorted(d[len("design_"):] for d in os.listdir(PROBE) if d.startswith("design_")) if os.path.isdir(PROBE) else []
+
+
+@pytest.mark.skipif(not NAMES, reason="no probe designs (python3 tools/diff_probe.py generates them where the reference is built)")
+@pytest.mark.parametrize("name", NAMES or ["none"])
+def test_probe_design_matches_the_reference(name, tmp_path):
+    meta = H.load_design(name, root=PROBE)
+    h = zlib.crc32(name.encode())
+    extra = []
+    if h % 3 == 1:
+        extra += ["-gpus", "2", "-gpu_window_candidates", str(20000 + h % 50000)]
+    elif h % 3 == 2:
+        extra += ["-gpu_window_candidates", str(5000 + h % 100000), "-gpu_gather", "rccl"]
+    run_cli(meta, str(tmp_path), extra=extra)
+    if "-silent_mode" in meta.get("extra", []):
+        H.compare_outputs(meta, str(tmp_path), keys=("picked_mips", "snp_mips"), check_all=False)
+    else:
+        H.compare_outputs(meta, str(tmp_path))
