@@ -38,6 +38,16 @@ def random_design(rng: np.random.Generator, k: int, multi: bool) -> dict:
         rng.shuffle(pairs)
         sums, arm_lengths = None, ",".join(f"{e}:{l}" for e, l in pairs)
         n_pairs = len(pairs)
+    arm_extra = []
+    if arm_lengths is not None and rng.random() < 0.3:        # both options at once (the lists merge, mipgen.cpp:222-261), a pair given twice
+        more = sorted(int(x) for x in rng.choice(np.arange(38, 49), size=int(rng.integers(1, 3)), replace=False))
+        arm_extra = ["-arm_length_sums", ",".join(map(str, more))]
+        n_pairs += sum(max(0, min(s - 18, 30) - max(16, s - 30) + 1) for s in more)
+        if rng.random() < 0.5:
+            arm_lengths += "," + arm_lengths.split(",")[0]
+            n_pairs += 1
+    elif sums is not None and rng.random() < 0.2:             # sums whose lists are empty: keys below the minimum arm lengths / above 30 + 30
+        sums = sorted(set(sums) | {int(x) for x in rng.choice([20, 30, 33, 61, 62, 70], size=int(rng.integers(1, 3)), replace=False)})
     n_sizes = (hi - lo) // inc + 1
     # budget: the reference scores ~5e3 SVR candidates / s (64 SVs), ~1e5 logistic ones
     budget = 120000 if method != "logistic" else 1500000
@@ -67,7 +77,7 @@ def random_design(rng: np.random.Generator, k: int, multi: bool) -> dict:
         used += (length + hi) * per_base
     if not multi:
         ivs.sort(key=lambda t: t[1])
-    extra = []
+    extra = list(arm_extra)
     if inc != 5:
         extra += ["-capture_increment", str(inc)]
 
