@@ -1,6 +1,7 @@
 """GPU: the differential probe (tools/diff_probe.py).  Where tests/golden_probe/ holds designs the real reference was run on in the build container
 (random parameter sets, BEDs and options; git-ignored scratch), the drop-in command line must write the same files - with one or two device workers,
-forced result windows and either gather route.  Skipped where the directory is absent (a fresh clone: the committed goldens are tests/golden/)."""
+forced result windows and either gather route.  Runs with MIPGEN_PROBE=1 where the directory exists (a fresh clone has none: the committed goldens are
+tests/golden/)."""
 import os
 import zlib
 
@@ -11,10 +12,11 @@ from tests.test_gpu_cli import run_cli
 
 pytestmark = pytest.mark.gpu
 PROBE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_probe")
-NAMES = sorted(d[len("design_"):] for d in os.listdir(PROBE) if d.startswith("design_")) if os.path.isdir(PROBE) else []
+# opt-in (MIPGEN_PROBE=1): hundreds of designs - a campaign, not part of the default suite
+NAMES = sorted(d[len("design_"):] for d in os.listdir(PROBE) if d.startswith("design_")) if os.path.isdir(PROBE) and os.environ.get("MIPGEN_PROBE") == "1" else []
 
 
-@pytest.mark.skipif(not NAMES, reason="no probe designs (python3 tools/diff_probe.py generates them where the reference is built)")
+@pytest.mark.skipif(not NAMES, reason="no probe designs / MIPGEN_PROBE != 1 (python3 tools/diff_probe.py generates them where the reference is built)")
 @pytest.mark.parametrize("name", NAMES or ["none"])
 def test_probe_design_matches_the_reference(name, tmp_path):
     meta = H.load_design(name, root=PROBE)

@@ -5,7 +5,7 @@ box with the snapshot), where tests/test_gpu_probe.py runs the drop-in command l
 gather settings - and compares the files byte for byte.  A way to look for differences the fixed goldens do not reach; what it finds becomes a golden.
 
     python3 tools/diff_probe.py [N = 40] [seed = 1]          # ~ N x 10 s of reference time
-    gpurun -- python -m pytest tests/test_gpu_probe.py -q -n 4
+    gpurun -- 'MIPGEN_PROBE=1 python -m pytest tests/test_gpu_probe.py -q -n 6'
 """
 import os
 import shutil
