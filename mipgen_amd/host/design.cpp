@@ -123,8 +123,9 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         out.progress << "mipgen (MI355X accelerated hot path; libmipgen_accel ABI " << mipgen_accel_abi_version() << ")\n";
         for (auto& kv : o.args) out.progress << kv.first << " " << kv.second << std::endl;
         // ---- query_sequences ---------------------------------------------------------------------------------
-        d->regions = load_regions(o);
-        if (d->regions.empty()) { std::cerr << "[mipgen] region file could not be opened" << std::endl; throw 6; }
+        bool bed_opened = false;
+        d->regions = load_regions(o, &bed_opened);
+        if (!bed_opened) { std::cerr << "[mipgen] region file could not be opened" << std::endl; throw 6; }
         clk.lap("options + BED sort / merge");
         // -gpu_copy_counter: the genome behind the bwa index is read while the region sequences are sliced (it only looks at the regions' chromosome names)
         std::future<void> genome_ready;
@@ -805,13 +806,12 @@ extern "C" int mipgen_design_region_weights(const mipgen_design* d, int64_t* wei
 extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
 {
     if (!d) return fail(MIPGEN_HOST_E_USAGE, 0, "null argument");
-    const int visible = mipgen_accel_device_count();
-    if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
-    if (n_devices <= 0) n_devices = d->n_devices > 0 ? d->n_devices : visible;
     const int n = (int)d->regions.size();
-    if (d->o.arm_pairs.empty()) {
-        // every arm-sum list is empty (-arm_length_sums 39 -ext_min_length 18 -lig_min_length 22): the reference walks the scan positions, constructs
-        // nothing (mipgen.cpp:438) and hands empty tables to the selection stage region after region (:503-515) - no accelerator call to make
+    if (n == 0) return 0;                        // a BED without intervals: nothing to tile, the run completes with header-only files like the reference's
+    if (d->o.arm_pairs.empty() || d->o.max_capture < d->o.min_capture) {
+        // every arm-sum list is empty (-arm_length_sums 39 -ext_min_length 18 -lig_min_length 22), or no capture size at all (-min_capture_size above
+        // -max_capture_size: the loop of mipgen.cpp:427 has no iteration): the reference walks the scan positions, constructs nothing (:438) and hands
+        // empty tables to the selection stage region after region (:503-515) - no accelerator call to make
         int rc0 = 0;
         for (int i = 0; i < n && rc0 == 0; i++) {
             const Region& r = d->regions[(size_t)i];
@@ -827,6 +827,9 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
         if (rc0) d->failed = true;
         return rc0;
     }
+    const int visible = mipgen_accel_device_count();
+    if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
+    if (n_devices <= 0) n_devices = d->n_devices > 0 ? d->n_devices : visible;
     n_devices = std::max(1, std::min(n_devices, n));
     // contiguous region ranges balanced by dense-grid size (the reference's region order is the order of the selection stage)
     std::vector<int64_t> weight((size_t)n);

@@ -42,10 +42,11 @@ static std::vector<std::string> split_ws(const std::string& s)            // boo
 // (compare_regions_to_scan, mipgen.cpp:37-67: header lines first, then chromosome name as a string - without a leading "chr" -, then the integer start;
 // applied below from keys parsed once per line)
 
-std::vector<Region> load_regions(const Options& o)
+std::vector<Region> load_regions(const Options& o, bool* opened)
 {
     std::vector<Region> out;
     std::ifstream fh(o.regions_to_scan);
+    *opened = fh.is_open();                      // (a BED without intervals is not an error: the reference completes with header-only files, mipgen.cpp:986-987)
     if (!fh.is_open()) return out;
     std::cerr << "[mipgen] success on opening region file" << std::endl;
     std::vector<std::string> lines;
@@ -88,10 +89,14 @@ std::vector<Region> load_regions(const Options& o)
     for (const std::string& l : lines) {
         if (l[0] == '>' || l[0] == '#' || l.find_first_not_of(" \t\n") == std::string::npos) continue;
         std::vector<std::string> f = split_ws(l);
-        if (f.size() < 3) continue;
+        if (f.size() < 3) {
+            // bed_fields.at(1) / .at(2) of the reference (mipgen.cpp:1019,1021,1029): std::out_of_range with libstdc++'s text, reported by main()
+            const std::string n = std::to_string(f.size());
+            throw std::out_of_range("vector::_M_range_check: __n (which is " + n + ") >= this->size() (which is " + n + ")");
+        }
         const std::string label = f.size() > 3 ? f[3] : default_label;
         const std::string chr = f[0].substr(0, 3) == "chr" ? f[0].substr(3) : f[0];
-        const int bs = std::atoi(f[1].c_str()), be = std::atoi(f[2].c_str());
+        const int bs = lexical_int(f[1]), be = lexical_int(f[2]);                    // boost::lexical_cast<int>: strict
         if (!out.empty() && out.back().chr == chr && bs - out.back().stop - 2 * o.feature_flank < o.min_capture / 2) {   // :1019
             Region& p = out.back();
             p.stop = std::max(be, p.stop);

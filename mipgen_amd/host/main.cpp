@@ -13,6 +13,9 @@ int main(int argc, char** argv)
     if (rc) {
         if (rc == MIPGEN_HOST_E_USAGE && mipgen_host_last_circumstance() == 1) std::cerr << mipgen_host_last_error() << std::endl;   // usage / option errors (mipgen.cpp:140-145)
         else std::cerr << mipgen_host_last_error() << std::endl;                                                                  // mipgen.cpp:2029-2032
+        // a std::exception (a bad integer, a BED line with two fields, an option without its value ...) is reported and the reference's main() then falls
+        // off its end: exit status 0 (mipgen.cpp:2033-2036) - reproduced; `throw <int>` paths exit with 1 (:2029-2032)
+        if (mipgen_host_last_circumstance() == -1) return 0;
         return 1;
     }
     rc = mipgen_design_run(d, 0);

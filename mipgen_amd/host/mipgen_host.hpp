@@ -50,6 +50,11 @@ struct Options {
 
 // returns "" on success, else the message the reference would print before `throw 1` (mipgen.cpp:140-145)
 std::string parse_command_line(int argc, char** argv, Options& o);
+// what boost::lexical_cast throws in the reference (every integer / real option and BED field): main() prints its text after "unable to tile sequences"
+struct BadLexicalCast : std::exception {
+    const char* what() const noexcept override { return "bad lexical cast: source type value could not be interpreted as target"; }
+};
+int lexical_int(const std::string& s);
 // throws int (4 = invalid scoring method) exactly as parse_arg_values does
 void finalize_options(Options& o);
 
@@ -82,7 +87,7 @@ struct Tables {                                   // global lookup tables the in
 };
 
 // input stage; each throws int on the reference's error paths
-std::vector<Region> load_regions(const Options& o);                                         // may return empty -> caller throws 6
+std::vector<Region> load_regions(const Options& o, bool* opened);                           // *opened false -> caller throws 6; no interval at all is not an error
 bool load_sequences_from_genome_dir(const Options& o, std::vector<Region>& regs);
 bool load_sequences_from_indexed_fasta(const Options& o, std::vector<Region>& regs);       // native faidx, no samtools fork
 bool load_masks(const Options& o, std::vector<Region>& regs);

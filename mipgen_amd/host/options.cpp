@@ -2,6 +2,9 @@
 // Follows mipgen::set_default_args / parse_command_line / parse_arg_values (/root/reference/mipgen.cpp:164-276,1280-1501):
 // same option names, defaults, required set, -file_of_parameters handling and error strings; the usage texts are our own.
 #include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdint>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -83,6 +86,18 @@ static void set_defaults(Options& o)
     a["-gpus"] = "0"; a["-gpu_window_candidates"] = "0"; a["-gpu_timing"] = "off"; a["-gpu_gather"] = "pcie";
 }
 
+// boost::lexical_cast<int> as the reference uses it for every integer option and BED field: the WHOLE string must be a decimal integer that fits
+// (no white space, no trailing characters); a failure is a std::exception that main() reports as "unable to tile sequences" + this text (mipgen.cpp:2033-2035)
+int lexical_int(const std::string& s)
+{
+    if (s.empty() || std::isspace((unsigned char)s[0])) throw BadLexicalCast();
+    errno = 0;
+    char* end = nullptr;
+    const long v = std::strtol(s.c_str(), &end, 10);
+    if (end != s.c_str() + s.size() || errno == ERANGE || v < INT32_MIN || v > INT32_MAX) throw BadLexicalCast();
+    return (int)v;
+}
+
 std::string parse_command_line(int argc, char** argv, Options& o)
 {
     set_defaults(o);
@@ -98,7 +113,8 @@ std::string parse_command_line(int argc, char** argv, Options& o)
         if (argv[i][0] != '-') continue;
         std::string p(argv[i]);
         if (!known(p)) { std::cerr << "not found" << std::endl; return p + " not recognized as valid option\n"; }
-        if (i + 1 >= argc) return p + " needs a value\n";
+        // an option without its value: the reference builds a std::string from argv[argc] = NULL (mipgen.cpp:1297) - a std::logic_error with this text
+        if (i + 1 >= argc) throw std::logic_error("basic_string::_M_construct null not valid");
         o.args[p] = argv[i + 1];
         if (p == "-file_of_parameters") check_file = true;
         else if (p == "-arm_length_sums") o.has_arm_length_sums = true;
@@ -123,18 +139,15 @@ std::string parse_command_line(int argc, char** argv, Options& o)
     return "";
 }
 
-static int to_int(const std::string& s)
-{
-    size_t pos = 0;
-    int v = std::stoi(s, &pos);
-    if (pos != s.size()) throw std::invalid_argument("bad integer: " + s);     // lexical_cast is strict
-    return v;
-}
+static int to_int(const std::string& s) { return lexical_int(s); }
 static double to_double(const std::string& s)
 {
-    size_t pos = 0;
-    double v = std::stod(s, &pos);
-    if (pos != s.size()) throw std::invalid_argument("bad number: " + s);
+    // boost::lexical_cast<double>: the whole string, no leading white space
+    if (s.empty() || std::isspace((unsigned char)s[0])) throw BadLexicalCast();
+    errno = 0;
+    char* end = nullptr;
+    const double v = std::strtod(s.c_str(), &end);
+    if (end != s.c_str() + s.size() || errno == ERANGE) throw BadLexicalCast();
     return v;
 }
 static std::vector<std::string> split(const std::string& s, char c)

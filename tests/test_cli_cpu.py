@@ -32,3 +32,27 @@ def test_doc_is_printed_in_full():
     assert p.returncode == 1
     for needle in ("-feature_flank", "-score_method", "-gpu_gather pcie|rccl", "limits of this build"):
         assert needle in out, needle
+
+
+def _error_cases():
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    import error_probe as ep
+    with open(ep.STORE) as fh:
+        return ep, json.load(fh)
+
+
+@pytest.mark.parametrize("name", ["unknown_option", "bad_method", "min_gt_max", "no_bed_file", "bad_cols", "bad_num", "unknown_chromosome", "empty_bed",
+                                  "nonint_capture", "bad_bwa", "odd_args", "bad_arm_lengths"])
+def test_error_behaviour_matches_the_reference(name, tmp_path):
+    """Malformed command lines and inputs (tools/error_probe.py; expectations in tests/golden/error_cases.json = what the REAL reference did): the exit
+    status, the last lines of stderr and the files written are the reference's - `throw <int>` paths exit with 1 and a circumstance number
+    (mipgen.cpp:2029-2032); a std::exception (boost::lexical_cast on a bad integer, vector::at on a BED line of two fields, std::string(NULL) for an
+    option without its value) prints "unable to tile sequences" + the exception text and exits with 0 (:2033-2036, main() falls off its end); a BED
+    without intervals and -min_capture_size above -max_capture_size complete with header-only files.  None of these needs the device."""
+    ep, want = _error_cases()
+    work = str(tmp_path / "w")
+    base = ep.lay_out(work)
+    got = ep.run_one(H.CLI_BIN, ep.cases(base)[name], work)
+    assert got == want[name], (got, want[name])
