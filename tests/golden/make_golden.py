@@ -337,7 +337,7 @@ def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz", out_root
             if mine:
                 snps += synth.random_snps(c, g, min(iv.bed_start for iv in mine) - 400, max(iv.bed_end for iv in mine) + 400, seed=13 + k, per_bp=1 / 50.0)
         snp_path = w + "/snps.vcf"
-        synth.write_vcf(snp_path, snps)
+        synth.write_vcf(snp_path, d["snp_hook"](snps) if d.get("snp_hook") else snps)
         shutil.copy(snp_path, out + "/snps.vcf")
     elif d["snps"]:
         lo = min(iv.bed_start for iv in ivs) - 1000
@@ -345,7 +345,7 @@ def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz", out_root
         snps = synth.random_snps("1", genome, 4000, 10000, seed=13, per_bp=1 / 40.0) if genome_name == "genome_chr1.fa.gz" else \
             synth.random_snps("1", genome, lo, hi, seed=13, per_bp=1 / 60.0)
         snp_path = w + "/snps.vcf"
-        synth.write_vcf(snp_path, snps)
+        synth.write_vcf(snp_path, d["snp_hook"](snps) if d.get("snp_hook") else snps)
         shutil.copy(snp_path, out + "/snps.vcf")
     model = os.path.join(HERE, "models", d["model"]) if d["model"] else None
     r = run_reference(w, w + "/genome", w + "/regions.bed", "out", d["minC"], d["maxC"], score_method=d["method"],

@@ -112,6 +112,27 @@ def random_design(rng: np.random.Generator, k: int, multi: bool) -> dict:
         d["bed_text"] = "\n".join(bed_lines) + "\n"
     else:
         d["ivs"] = ivs
+    if d["snps"] and rng.random() < 0.5:
+        # VCF records beyond biallelic SNVs: insertions (ALT longer than REF), several ALT alleles, a position listed twice, a `chr` prefix on the
+        # chromosome column (parse_vcf keys its table by that column as it stands, mipgen.cpp:945-947)
+        wild_seed = int(rng.integers(0, 1 << 30))
+
+        def hook(snps, wild_seed=wild_seed):
+            r2 = np.random.default_rng(wild_seed)
+            out = []
+            for s in snps:
+                u = r2.random()
+                if u < 0.12:
+                    s = synth.Snp(s.chrom, s.pos, s.ref, s.alt + "ACGT"[int(r2.integers(0, 4))])
+                elif u < 0.24:
+                    s = synth.Snp(s.chrom, s.pos, s.ref, s.alt + "," + "ACGT"[int(r2.integers(0, 4))])
+                elif u < 0.30:
+                    out.append(synth.Snp(s.chrom, s.pos, s.ref, "ACGT"[int(r2.integers(0, 4))]))
+                elif u < 0.36:
+                    s = synth.Snp("chr" + s.chrom, s.pos, s.ref, s.alt)
+                out.append(s)
+            return out
+        d["snp_hook"] = hook
     return d
 
 
