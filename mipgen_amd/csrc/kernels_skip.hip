@@ -3,7 +3,7 @@
 //
 // The enumeration of a scan position walks the capture sizes from the largest down and stops constructing candidates for good once a size starts
 // with previous_best_score above the upper score limit (:430: `continue` for this and - nothing resets the score any more - every later size).  A
-// region with more than nine capture sizes is scored in runs of <= 9 sizes (accel.hip: build_svr_tiles).  When the runs are launched in order,
+// region with more than nine capture sizes is scored in runs of <= 9 sizes (accel_tiles.hip: build_svr_tiles).  When the runs are launched in order,
 // largest sizes first, the state of every position after run r is known before run r + 1 starts: a tile of run r + 1 whose positions have ALL
 // stopped constructs nothing the reference would have constructed - its 14,000 candidates x n_sv kernel values need not be computed.  The replay
 // of the early exits over the finished dense grid (kernels_replay.hip) stays the authority: it never consults rows behind the exit of a position,

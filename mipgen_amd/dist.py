@@ -19,7 +19,7 @@ def region_cost(dense_candidates: Sequence[int], n_pos: Sequence[int], n_sizes: 
                 svr: bool) -> np.ndarray:
     """Relative device time per region = the shard weights (the same rule as mipgen_amd/host/design.cpp: region_cost): the dense-grid
     candidates and, for the dense SVR scorer, the factor-table entries it builds per support vector at the kernel's instruction budget (~47 VALU
-    per table entry against ~2.7 per candidate: mipgen_amd/csrc/accel.hip: build_svr_tiles) - exons with few capture sizes cost more per
+    per table entry against ~2.7 per candidate: mipgen_amd/csrc/accel_tiles.hip: build_svr_tiles) - exons with few capture sizes cost more per
     candidate than their dense-grid size says.  sum_range = max arm sum - min arm sum."""
     cand = np.asarray(dense_candidates, dtype=np.float64)
     if not svr:

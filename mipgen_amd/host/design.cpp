@@ -711,7 +711,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
 
 // Relative device time of a region (the shard weights): the candidates of its dense grid - capture sizes after the static skip of
 // mipgen.cpp:429, positions of :421-425 - and, for the dense SVR scorer, the factor-table entries it builds per support vector, at the
-// kernel's instruction budget (~47 VALU per table entry against ~2.7 per candidate; mipgen_amd/csrc/accel.hip: build_svr_tiles).  Exons
+// kernel's instruction budget (~47 VALU per table entry against ~2.7 per candidate; mipgen_amd/csrc/accel_tiles.hip: build_svr_tiles).  Exons
 // with few capture sizes cost more per candidate than their dense-grid size says.  The same rule: mipgen_amd/dist.py: region_cost.
 static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_capture, int inc, int max_overlap, int n_pairs, int n_e, int n_l,
                            int max_sum, int min_sum, bool svr)

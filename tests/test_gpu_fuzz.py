@@ -78,7 +78,7 @@ def test_random_configuration(cfg):
 
 def _list_route_configs():
     """Parameter sets on and across the limits of the tiled SVR kernel (scan sizes 1..5, 230..256 arm pairs, increments 1..3): the same handle
-    takes the tiled kernel or the list route (accel.hip: svr_window_via_list) depending on which side of a limit it falls."""
+    takes the tiled kernel or the list route (accel_score.hip: svr_window_via_list) depending on which side of a limit it falls."""
     rng = np.random.default_rng(20260101)
     out = []
     for i in range(int(os.environ.get("MIPGEN_FUZZ_LIST_N", "6"))):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/exp/build_variant.sh NAME [-DMACRO=..]...: a scratch build of libmipgen_accel.so with extra macros on kernels_svr.hip / accel.hip
+# tools/exp/build_variant.sh NAME [-DMACRO=..]...: a scratch build of libmipgen_accel.so with extra macros on kernels_svr.hip / accel*.hip
 # (tools/exp/scratch/libmipgen_accel_NAME.so), for A/B timing with tools/exp/kernel_time.py.  The product objects are reused for the rest.
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd)
