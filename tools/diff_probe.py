@@ -4,7 +4,8 @@ their inputs + the reference's output files laid out like the committed goldens 
 box with the snapshot), where tests/test_gpu_probe.py runs the drop-in command line on every one of them - with random device-worker / result-window /
 gather settings - and compares the files byte for byte.  A way to look for differences the fixed goldens do not reach; what it finds becomes a golden.
 
-    python3 tools/diff_probe.py [N = 40] [seed = 1]          # ~ N x 10 s of reference time
+    python3 tools/diff_probe.py [N = 40] [seed = 1] [long]   # ~ N x 3 s of reference time; long = logistic designs of up to ten regions of 0.3-3 kb
+                                                             # (the selection stage at length), ~ N x 30 s
     gpurun -- 'MIPGEN_PROBE=1 python -m pytest tests/test_gpu_probe.py -q -n 6'
 """
 import os
@@ -23,8 +24,8 @@ from mipgen_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden_probe")
 
 
-def random_design(rng: np.random.Generator, k: int, multi: bool) -> dict:
-    method = str(rng.choice(["logistic", "logistic", "svr", "mixed"]))
+def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False) -> dict:
+    method = "logistic" if long_regions else str(rng.choice(["logistic", "logistic", "svr", "mixed"]))
     inc = int(rng.choice([1, 2, 3, 5, 5, 5, 10]))
     lo = int(rng.integers(100, 200))
     hi = lo + inc * int(rng.choice([0, 1, 2, 2, 4, 6, 10]))
@@ -50,9 +51,9 @@ def random_design(rng: np.random.Generator, k: int, multi: bool) -> dict:
         sums = sorted(set(sums) | {int(x) for x in rng.choice([20, 30, 33, 61, 62, 70], size=int(rng.integers(1, 3)), replace=False)})
     n_sizes = (hi - lo) // inc + 1
     # budget: the reference scores ~5e3 SVR candidates / s (64 SVs), ~1e5 logistic ones
-    budget = 120000 if method != "logistic" else 1500000
+    budget = 120000 if method != "logistic" else (6000000 if long_regions else 1500000)
     per_base = 2 * n_sizes * max(n_pairs, 1)
-    n_iv = int(rng.integers(1, 7))
+    n_iv = int(rng.integers(1, 11 if long_regions else 7))
     ivs = []
     bed_lines = []
     chroms = ["2", "10", "X"] if multi else ["1"]
@@ -62,7 +63,7 @@ def random_design(rng: np.random.Generator, k: int, multi: bool) -> dict:
         room = (budget - used) // per_base - hi
         if room < 2:
             break
-        length = int(min(room, rng.choice([1, 3, 20, 60, 150, 400, 1200])))
+        length = int(min(room, rng.choice([300, 700, 1500, 3000] if long_regions else [1, 3, 20, 60, 150, 400, 1200])))
         if length < 1:
             break
         c = str(rng.choice(chroms))
@@ -149,7 +150,7 @@ def main() -> None:
     made = 0
     for k in range(n):
         is_multi = bool(rng.random() < 0.4)
-        d = random_design(rng, seed * 1000 + k, is_multi)
+        d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and sys.argv[3] == "long")
         if not (d.get("ivs") or d.get("bed_text", "").strip()):
             continue
         try:
