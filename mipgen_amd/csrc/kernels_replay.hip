@@ -250,13 +250,19 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
     const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
     const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;
     const uint64_t seg_below = seg & below_me, seg_above = seg & ~below_me & ~lane_bit;
+    // :443-444, the bounds skips, from the geometry alone: a pair is constructed at scan start p and capture size C iff p > max(e, l) and
+    // p + C - 1 - min(e, l) <= seq_stop - exactly the VALID bit of the candidate's record (kernels_logistic_dense.hip, kernels_logistic.hip), which the
+    // replay therefore does not fetch: 16 instead of 24 bytes per pair and row
+    const int p_scan = R.first_pos + pi;
+    const bool ok_lo = in && p_scan > max(e, l);
+    const int c_lim = R.seq_stop - p_scan + 1 + min(e, l);                   // largest capture size that still fits
+    const int c_top = P->max_capture - R.k0 * P->inc, c_inc = P->inc;
 
     // ---- replay, mipgen.cpp:426-497 ---------------------------------------------------------------------
     unsigned long long n_emitted = 0;
     double pbs = 0.0;                                                        // previous_best_score (:426)
     for (int k0 = 0; k0 < nK; k0 += REPLAY_ROWS) {
         double bp[REPLAY_ROWS], bm[REPLAY_ROWS];
-        uint64_t br[REPLAY_ROWS];
         if (pbs > upper) {                                                   // :430 - nothing more is constructed at this position
             if (lane < REPLAY_ROWS && k0 + lane < nK) emask[k0 + lane] = 0;
             continue;
@@ -267,20 +273,19 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
         // capture sizes run faster that way, hence the two forms)
         {
             const double* srow = scores + base;
-            const uint64_t* rrow = records + base;
             const int la = min(lane, A - 1);
 #pragma unroll
             for (int q = 0; q < REPLAY_ROWS; q++) {
-                bp[q] = 0.0; bm[q] = 0.0; br[q] = 0;
+                bp[q] = 0.0; bm[q] = 0.0;
                 if (k0 + q < nK) {                                              // (wave-uniform: the rows behind the last capture size are not fetched)
                     const int off = ((k0 + q) * 2) * A + la;
-                    bp[q] = srow[off]; bm[q] = srow[off + A]; br[q] = rrow[off];
+                    bp[q] = srow[off]; bm[q] = srow[off + A];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < REPLAY_ROWS; q++) {
-                bp[q] = in ? bp[q] : 0.0; bm[q] = in ? bm[q] : 0.0; br[q] = in ? br[q] : 0;
+                bp[q] = in ? bp[q] : 0.0; bm[q] = in ? bm[q] : 0.0;
             }
         }
         } else {
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
         for (int q = 0; q < REPLAY_ROWS; q++) {
             const bool on = in && k0 + q < nK;
             const int64_t idx = base + ((int64_t)(k0 + q) * 2) * A + lane;
-            bp[q] = on ? scores[idx] : 0.0; bm[q] = on ? scores[idx + A] : 0.0; br[q] = on ? records[idx] : 0;
+            bp[q] = on ? scores[idx] : 0.0; bm[q] = on ? scores[idx + A] : 0.0;
         }
         }
 #pragma unroll
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
             uint64_t emit_all = 0;
             if (!(pbs > upper)) {                                            // :430
                 const double plus = bp[q], minus = bm[q];
-                const bool valid = (MIPGEN_REC_FLAGS(br[q]) & MIPGEN_FLAG_VALID) != 0;           // :443-444 (0 outside the row)
+                const bool valid = ok_lo && c_top - ki * c_inc <= c_lim;                         // :443-444 (false outside the row)
                 const uint64_t vmask = __ballot(valid);
                 bool mine = valid;
                 // (rows whose constructed pairs all score in [0, 1) cannot trigger :494 - every truncated score is 0: see k_replay_condense_carry)
