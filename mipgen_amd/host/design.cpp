@@ -822,6 +822,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             for (auto& s : none) { s.cand_index = -1; s.score = 0.0; s.record = 0; }
             try { rc0 = mipgen_design_select_region_collapsed(d, i, &g, none.data(), 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr); }
             catch (int e) { rc0 = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
+            catch (std::exception& e) { rc0 = fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what()); }
         }
         d->flush_err();
         if (rc0) d->failed = true;
@@ -898,6 +899,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                                                  (int32_t)((w->col_off[(size_t)bi + 1] - w->col_off[(size_t)bi]) / 2),
                                                  d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
             } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
+            catch (std::exception& e) { rc = fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what()); }   // (mipgen.cpp:2033-2035)
             pos0 += g.n_pos;
         }
         t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();

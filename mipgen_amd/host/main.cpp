@@ -19,7 +19,9 @@ int main(int argc, char** argv)
         return 1;
     }
     rc = mipgen_design_run(d, 0);
-    if (rc) std::cerr << "unable to tile sequences due to circumstance " << mipgen_host_last_circumstance() << std::endl;
+    const bool exception_path = rc && mipgen_host_last_circumstance() == -1;            // a std::exception inside the selection stage: as above
+    if (exception_path) std::cerr << mipgen_host_last_error() << std::endl;
+    else if (rc) std::cerr << "unable to tile sequences due to circumstance " << mipgen_host_last_circumstance() << std::endl;
     mipgen_design_close(d);
-    return rc ? 1 : 0;
+    return rc && !exception_path ? 1 : 0;
 }
