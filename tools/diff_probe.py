@@ -4,7 +4,7 @@ their inputs + the reference's output files laid out like the committed goldens 
 box with the snapshot), where tests/test_gpu_probe.py runs the drop-in command line on every one of them - with random device-worker / result-window /
 gather settings - and compares the files byte for byte.  A way to look for differences the fixed goldens do not reach; what it finds becomes a golden.
 
-    python3 tools/diff_probe.py [N = 40] [seed = 1] [long]   # ~ N x 3 s of reference time; long = logistic designs of up to ten regions of 0.3-3 kb
+    python3 tools/diff_probe.py [N = 40] [seed = 1] [long|extreme]   # ~ N x 3 s of reference time; extreme = option values at the edges; long = logistic designs of up to ten regions of 0.3-3 kb
                                                              # (the selection stage at length), ~ N x 30 s
     gpurun -- 'MIPGEN_PROBE=1 python -m pytest tests/test_gpu_probe.py -q -n 6'
 """
@@ -24,7 +24,7 @@ from mipgen_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden_probe")
 
 
-def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False) -> dict:
+def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False, extreme: bool = False) -> dict:
     method = "logistic" if long_regions else str(rng.choice(["logistic", "logistic", "svr", "mixed"]))
     inc = int(rng.choice([1, 2, 3, 5, 5, 5, 10]))
     lo = int(rng.integers(100, 200))
@@ -103,11 +103,29 @@ def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: b
     maybe(0.15, "-svr_priority_score", str(rng.choice(["1.0", "1.4", "1.8"])))
     maybe(0.15, "-svr_optimal_score", str(rng.choice(["1.9", "2.4", "3.0"])))
     maybe(0.10, "-stop_optimizing_scores_above", str(rng.choice(["0.9", "1.6"])))
+    if extreme:
+        # option values at and beyond the edges of what anybody would type
+        extra = list(arm_extra) + (["-capture_increment", str(inc)] if inc != 5 else [])
+        maybe(0.3, "-max_mip_overlap", str(int(rng.choice([0, 1, 200, 1000]))))
+        maybe(0.3, "-starting_mip_overlap", str(int(rng.choice([0, 60, 150]))))
+        maybe(0.3, "-masked_arm_threshold", str(rng.choice(["0", "-1", "0.01", "5"])))
+        maybe(0.3, "-target_arm_copy", str(int(rng.choice([0, 1, 1000000]))))
+        maybe(0.3, "-max_arm_copy_product", str(int(rng.choice([0, 1, 100000000]))))
+        maybe(0.3, "-logistic_priority_score", str(rng.choice(["0", "0.999", "1.5", "-3"])))
+        maybe(0.3, "-logistic_optimal_score", str(rng.choice(["0", "0.5", "1", "2"])))
+        maybe(0.3, "-svr_priority_score", str(rng.choice(["-10", "0", "1.49", "9"])))
+        maybe(0.3, "-svr_optimal_score", str(rng.choice(["-10", "0", "1.5", "9"])))
+        maybe(0.2, "-capture_increment", str(int(rng.choice([50, 1000]))))
+        maybe(0.2, "-seal_both_strands", "on")
+        maybe(0.2, "-half_seal_both_strands", "on")
+        maybe(0.15, "-logistic_heuristic", "off")
+        maybe(0.15, "-check_copy_number", "off")
     silent = rng.random() < 0.15
     if silent:
         extra += ["-silent_mode", "on"]
-    d = dict(name=f"probe{k:03d}", method=method, minC=lo, maxC=hi, sums=sums, arm_lengths=arm_lengths, flank=int(rng.choice([0, 0, 3, 25])),
-             tags=str(rng.choice(["5,0", "4,4", "0,8", "0,0"])), snps=bool(rng.random() < 0.5), trf=bool(rng.random() < 0.3),
+    d = dict(name=f"probe{k:03d}", method=method, minC=lo, maxC=hi, sums=sums, arm_lengths=arm_lengths,
+             flank=int(rng.choice([0, 200, 1000])) if extreme else int(rng.choice([0, 0, 3, 25])),
+             tags=str(rng.choice(["30,30", "0,0", "1,60"])) if extreme else str(rng.choice(["5,0", "4,4", "0,8", "0,0"])), snps=bool(rng.random() < 0.5), trf=bool(rng.random() < 0.3),
              bwa=str(rng.choice(["hashed", "hashed", "unique", "blocks"])), model="svr_syn_64.model" if method != "logistic" else None, extra=extra)
     if multi:
         d["bed_text"] = "\n".join(bed_lines) + "\n"
@@ -150,7 +168,8 @@ def main() -> None:
     made = 0
     for k in range(n):
         is_multi = bool(rng.random() < 0.4)
-        d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and sys.argv[3] == "long")
+        d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and sys.argv[3] == "long",
+                          extreme=len(sys.argv) > 3 and sys.argv[3] == "extreme")
         if not (d.get("ivs") or d.get("bed_text", "").strip()):
             continue
         try:
