@@ -226,6 +226,18 @@ DESIGNS2 = [
     # no arm pair at all (39 < 18 + 22): the reference completes with header-only files and the coverage gaps
     dict(name="no_arm_pairs", method="logistic", ivs=[("1", 12000, 12150, "n"), ("1", 12400, 12420, "m")], minC=150, maxC=160, sums=[39], flank=3,
          tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-ext_min_length", "18", "-lig_min_length", "22"]),
+    # what the differential probe (tools/diff_probe.py) covers at random, pinned as fixed designs: both arm options at once with a pair given twice
+    # (the lists merge, the pair is enumerated twice: mipgen.cpp:222-261); VCF records beyond biallelic SNVs; option values at the edges
+    dict(name="both_arm_options", method="logistic", ivs=[("1", 13000, 13200, "a"), ("1", 13190, 13260, "b")], minC=150, maxC=160, sums=None,
+         arm_lengths="20:22,25:20,20:22,18:27", flank=0, tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-arm_length_sums", "41,44"]),
+    dict(name="wild_vcf_mixed", method="mixed", ivs=[("1", 18000, 18120, "w")], minC=130, maxC=135, sums=[42, 43], flank=3, tags="4,4", snps=True, trf=False,
+         bwa="hashed", model="svr_syn_64.model", extra=[], snp_hook="wild"),
+    dict(name="edge_options", method="logistic", ivs=[("1", 19000, 19300, "x"), ("1", 21500, 21560, "y")], minC=150, maxC=160, sums=[40, 42, 44], flank=1000,
+         tags="30,30", snps=True, trf=True, bwa="hashed", model=None,
+         extra=["-target_arm_copy", "0", "-max_arm_copy_product", "100000000", "-masked_arm_threshold", "0", "-logistic_priority_score", "0.999",
+                "-logistic_optimal_score", "0.5", "-max_mip_overlap", "200", "-starting_mip_overlap", "60"]),
+    dict(name="edge_options_svr", method="svr", ivs=[("1", 23000, 23080, "x")], minC=150, maxC=160, sums=[44, 45], flank=0, tags="1,60", snps=False, trf=False,
+         bwa="hashed", model="svr_syn_64.model", extra=["-svr_priority_score", "9", "-svr_optimal_score", "0", "-capture_increment", "50", "-seal_both_strands", "on"]),
     # the same kind of limits for the SVR, given through -file_of_parameters (mipgen.cpp:1445-1481)
     dict(name="limits_svr_parameter_file", method="svr", ivs=[("1", 77000, 77350, "s")], minC=130, maxC=140, sums=[44, 45], flank=0, tags="5,0", snps=False,
          trf=False, bwa="hashed", model="svr_syn_64.model", extra=[],
@@ -300,7 +312,26 @@ def parse_bed_text(text: str):
     return ivs
 
 
+def wild_snps(snps):
+    """VCF records beyond biallelic SNVs, deterministically: every 5th record an insertion (ALT longer than REF), every 7th two ALT alleles, every 11th
+    position listed a second time with another ALT, every 13th with a `chr` prefix on the chromosome column (parse_vcf keys by that column as it stands)."""
+    out = []
+    for i, s in enumerate(snps):
+        if i % 5 == 1:
+            s = synth.Snp(s.chrom, s.pos, s.ref, s.alt + "ACGT"[i % 4])
+        elif i % 7 == 2:
+            s = synth.Snp(s.chrom, s.pos, s.ref, s.alt + "," + "ACGT"[(i + 1) % 4])
+        elif i % 13 == 3:
+            s = synth.Snp("chr" + s.chrom, s.pos, s.ref, s.alt)
+        if i % 11 == 4:
+            out.append(synth.Snp(s.chrom, s.pos, s.ref, "ACGT"[(i + 2) % 4]))
+        out.append(s)
+    return out
+
+
 def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz", out_root: str = HERE) -> None:
+    if d.get("snp_hook") == "wild":
+        d = dict(d, snp_hook=wild_snps)
     out = os.path.join(out_root, "design_" + d["name"])
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)

@@ -50,11 +50,14 @@ def _compare(meta, work):
 
 @pytest.mark.parametrize("name,workers", [("logistic_default_arms", 1), ("logistic_default_arms", 2), ("mixed_12_regions", 4), ("mixed_12_regions", 2),
                                           ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_mixed", 4), ("multichr_logistic_snps", 2),
-                                          ("long_capture_logistic", 1), ("long_capture_svr", 2), ("empty_sum_lists", 2), ("no_arm_pairs", 1)])
+                                          ("long_capture_logistic", 1), ("long_capture_svr", 2), ("empty_sum_lists", 2), ("no_arm_pairs", 1),
+                                          ("both_arm_options", 2), ("wild_vcf_mixed", 2), ("edge_options", 1), ("edge_options_svr", 1)])
 def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, workers, tmp_path):
     if san == "address" and (name, workers) not in (("mixed_12_regions", 4), ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_logistic_snps", 2),
-                                                    ("long_capture_logistic", 1), ("no_arm_pairs", 1)):
-        pytest.skip("ten under ThreadSanitizer, six under AddressSanitizer + UBSan")
+                                                    ("long_capture_logistic", 1), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2)):
+        pytest.skip("thirteen under ThreadSanitizer, eight under AddressSanitizer + UBSan")
+    if san == "thread" and name == "edge_options":
+        pytest.skip("190,000 records under ThreadSanitizer take a minute: AddressSanitizer only")
     if san == "thread" and name == "long_capture_logistic":
         pytest.skip("the 1,100-base captures (string lengths of the host side): AddressSanitizer; the SVR one under ThreadSanitizer")
     meta = H.load_design(name)
