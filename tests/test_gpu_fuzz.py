@@ -19,7 +19,7 @@ def _configs():
     rng = np.random.default_rng(20240607)
     grid = [(e, l) for e in range(16, 31) for l in range(18, 31) if 38 <= e + l <= 48]
     out = []
-    for i in range(int(os.environ.get("MIPGEN_FUZZ_N", "10"))):          # a longer soak: MIPGEN_FUZZ_N=200 python -m pytest tests/test_gpu_fuzz.py
+    for i in range(int(os.environ.get("MIPGEN_FUZZ_N", "24"))):          # a longer soak: MIPGEN_FUZZ_N=200 python -m pytest tests/test_gpu_fuzz.py
         inc = int(rng.choice([1, 2, 3, 5, 7, 10]))
         lo = int(rng.integers(110, 170))
         hi = lo + inc * int(rng.integers(0, 12))
@@ -49,8 +49,18 @@ def test_random_configuration(cfg):
         if method == capi.SCORE_SVR:
             acc.load_model_file(mp)
         acc.set_logistic_subruns(i % 5)                  # 0 = automatic (1 at this size); 1..4 position sub-runs per tile: the sliding-table paths
-        rd = capi.build_region(genome, "1", start, start + length, P, bwa_mode="hashed" if i % 2 else "unique", label=f"f{i}",
-                               lrc=np.full(44, 0.01 * (i + 1)))
+        # SNP tables (records' SNP counts and flags: classes 1 = usable allele pair, 2 = anything else, multi-base records), TRF-style masks (masked-base
+        # counts, the masking flag), the three copy-number modes of the bwa stand-in (hashed: copies up to 500 and unmappable windows; blocks: dead zones)
+        snp_tab = None
+        if i % 4 in (1, 2):
+            r3 = np.random.default_rng(3000 + i)
+            snp_tab = {}
+            for pos in r3.integers(max(1, start - 300), start + length + 300, size=int(r3.integers(1, 40))):
+                g = chr(genome[int(pos) - 1])
+                u = r3.random()
+                snp_tab[int(pos)] = (g + "ACGT"[int(r3.integers(0, 4))]) if u < 0.7 else ("ACGT"[int(r3.integers(0, 4))] + "T" if u < 0.85 else g + "AC")
+        rd = capi.build_region(genome, "1", start, start + length, P, bwa_mode=("unique", "hashed", "blocks")[i % 3], label=f"f{i}",
+                               lrc=np.full(44, 0.01 * (i + 1)), snp_tab=snp_tab, mask_record=i if i % 5 in (2, 3) else None, flank=(0, 0, 7)[i % 3])
         grids, scores, records = acc.score_regions([rd], method)
         g = grids[0]
         og, os_, or_ = po.score_region_dense(P, rd, method, om if method == capi.SCORE_SVR else None) if g.count <= 400000 else (None, None, None)
@@ -63,6 +73,13 @@ def test_random_configuration(cfg):
             with np.errstate(invalid="ignore"):
                 d = np.where(both_nan | (np.isinf(a) & (a == b)), 0.0, np.abs(a - b))
             assert np.nanmax(d) <= TOL and not np.isnan(d).any(), (cfg[:4], method, int(np.nanargmax(d)), float(np.nanmax(d)))
+            # the replay of the early exits and the condense fold on the same arrays (SNP counts, masked bases and copy numbers steer the fold)
+            acc.replay_condense()
+            em, sv, mask = acc.download_replay()
+            n_emit, omask = po.replay_region(P, rd, scores, records)
+            assert int(em[0]) == n_emit and np.array_equal(mask, omask), (cfg[:4], method, "replay")
+            osurv = po.condense_region(P, rd, scores, records, omask)
+            assert np.array_equal(sv["cand_index"], osurv["cand_index"]) and np.array_equal(sv["record"], osurv["record"]), (cfg[:4], method, "condense")
         else:                                        # large grids: sampled candidates through the per-candidate oracle
             valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
             A = P.n_arm_pairs
