@@ -54,8 +54,9 @@ extern "C" {
  * 3: SVR requests on parameter sets outside the tiled kernel's limits succeed (list route) instead of failing with MIPGEN_E_INVALID; a download may fail
  * with MIPGEN_E_STATE when a print-exact re-score list overflowed; new entry points (mipgen_accel_window_uniqueness_begin / _flags_region / _end,
  * mipgen_accel_set_dynamic_skip / _skipped_candidates / _skip_state).
- * 4: new entry points only (mipgen_accel_rescore_survivors / _download_survivor_scores, mipgen_accel_window_views, mipgen_accel_synchronize). */
-#define MIPGEN_ACCEL_ABI_VERSION 4
+ * 4: new entry points only (mipgen_accel_rescore_survivors / _download_survivor_scores, mipgen_accel_window_views, mipgen_accel_synchronize).
+ * 5: new entry point only (mipgen_accel_set_window_breaks: the multi-device front end deals its regions in blocks, a window never spans two). */
+#define MIPGEN_ACCEL_ABI_VERSION 5
 
 #define MIPGEN_MAX_ARM_PAIRS 256     /* flattened (ext,lig) list, enumeration order */
 #define MIPGEN_N_FEATURES 192        /* SVMipv4.cpp:14 TOTAL_FEATURES */
@@ -240,6 +241,10 @@ int64_t mipgen_accel_batch_candidates(const mipgen_accel* h);
 /* upper bound on the candidates of one result window for the following uploads (0 = automatic: what fits in free device memory, at most
  * 2^30 candidates unless a single region is larger) */
 int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates);
+/* regions of the following uploads at which a new result window must start whatever the candidate bound says (ascending batch indices; n = 0
+ * clears them): a front end that deals consecutive region blocks of one design to several devices in turn (the selection stage consumes the
+ * blocks in design order, /root/reference/mipgen.cpp:503-515) uploads its blocks as ONE batch and never gets a window that spans two of them */
+int mipgen_accel_set_window_breaks(mipgen_accel* h, const int32_t* first_regions, int32_t n);
 int32_t mipgen_accel_window_count(const mipgen_accel* h);
 /* regions [first_region, +n_regions), candidates [first_candidate, +n_candidates) and scan positions of window w; any output may be NULL */
 int mipgen_accel_window_info(const mipgen_accel* h, int32_t w, int32_t* first_region, int32_t* n_regions, int64_t* first_candidate,

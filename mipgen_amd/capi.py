@@ -23,7 +23,7 @@ MAX_OLIGO = 64
 
 SCORE_LOGISTIC, SCORE_SVR, SCORE_MIXED = 0, 1, 2
 
-ABI_VERSION = 4          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
+ABI_VERSION = 5          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
 FLAG_VALID, FLAG_GUARD, FLAG_MAPPING, FLAG_MASKING, FLAG_SNP, FLAG_HAS_SNP_MIP = 1, 2, 4, 8, 16, 32
 
 
@@ -355,7 +355,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_result_device_ptrs", "mipgen_accel_download_results", "mipgen_accel_score_regions",
     "mipgen_accel_score_candidates", "mipgen_accel_long_range_content", "mipgen_accel_replay_condense",
     "mipgen_accel_download_replay", "mipgen_accel_last_kernel_ms", "mipgen_accel_set_timing",
-    "mipgen_accel_set_window_candidates", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
+    "mipgen_accel_set_window_candidates", "mipgen_accel_set_window_breaks", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
     "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",

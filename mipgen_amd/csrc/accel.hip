@@ -322,6 +322,15 @@ int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t max_candidates)
     return MIPGEN_OK;
 }
 
+int mipgen_accel_set_window_breaks(mipgen_accel* h, const int32_t* first_regions, int32_t n)
+{
+    if (!h || n < 0 || (n > 0 && !first_regions)) return fail(MIPGEN_E_INVALID, "bad arguments");
+    for (int i = 0; i < n; i++)
+        if (first_regions[i] < 0 || (i > 0 && first_regions[i] <= first_regions[i - 1])) return fail(MIPGEN_E_INVALID, "window breaks must be ascending batch indices");
+    h->window_breaks.assign(first_regions, first_regions + n);
+    return MIPGEN_OK;
+}
+
 int mipgen_accel_set_print_exact(mipgen_accel* h, int32_t on)
 {
     if (!h) return fail(MIPGEN_E_INVALID, "null handle");
@@ -434,9 +443,12 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     if (cand_max > cap) return fail(MIPGEN_E_NOMEM, "a single region has %lld dense candidates; device memory holds %lld", (long long)cand_max, (long long)cap);
     {
         Window w;
+        size_t nb = 0;                                             // next forced break (mipgen_accel_set_window_breaks)
         for (int i = 0; i < n; i++) {
             const mipgen_grid& g = h->grids[i];
-            if (w.r1 > w.r0 && w.n_cand + g.count > cap) {
+            while (nb < h->window_breaks.size() && h->window_breaks[nb] < i) nb++;
+            const bool forced = nb < h->window_breaks.size() && h->window_breaks[nb] == i;
+            if (w.r1 > w.r0 && (forced || w.n_cand + g.count > cap)) {
                 h->windows.push_back(w);
                 Window nw; nw.r0 = nw.r1 = i; nw.cand0 = w.cand0 + w.n_cand; nw.pos0 = w.pos0 + w.n_pos;
                 w = nw;

@@ -240,6 +240,7 @@ struct mipgen_accel {
     // result windows: the inputs of every region stay resident; the dense result arrays (16 B per candidate) hold one window of
     // consecutive regions at a time
     int64_t window_cap = 0;          // max candidates per window; 0 = as many as fit in free device memory
+    std::vector<int32_t> window_breaks;   // batch indices at which a window must start (mipgen_accel_set_window_breaks), ascending
     std::vector<Window> windows;
     int cur_window = -1;
     DevBuf<double> scores, partials;

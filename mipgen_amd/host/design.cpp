@@ -457,7 +457,9 @@ struct WindowResult {
     mipgen_window_views views;
     int64_t c0 = 0, n_surv = 0;
     int64_t n_rec = 0;                           // how far they advance the design-wide all_mip_counter
+    int64_t own_before = 0;                      // records the worker had numbered before this window (it counts its own from 0)
     bool has_text = false;
+    bool block_end = false;                      // the last window of one of the worker's region blocks: the consumer moves on to the next device
     bool last = false;
     int error = 0;
     std::string msg;
@@ -534,13 +536,19 @@ struct SurvivorRescorer {                        // the SVR scores the worker co
     }
 };
 
-void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel* ch, RecordOrder* order);
+// A device worker scores BLOCKS of consecutive regions - block b of the design goes to worker b mod N - so that the order in which the devices
+// produce their result windows is the order in which the one selection thread consumes them (design order: mipgen.cpp:503-515, the rand() of :1863
+// and the used-arm sets of :1925-1938 couple the regions): with two windows in flight per device every device keeps scoring while the others are
+// being selected, whatever the number of windows.  (Contiguous shards did not: device k slept after three windows until devices 0..k-1 were consumed.)
+typedef std::vector<std::pair<int, int>> Blocks;
 
-void worker(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel* ch, RecordOrder* order)
+void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& blocks, Channel* ch, RecordOrder* order);
+
+void worker(mipgen_design* d, int device, int k_worker, Blocks blocks, Channel* ch, RecordOrder* order)
 {
     // nothing may leave a worker thread as an exception (std::terminate): a failed allocation of a multi-GB result vector ends the run
     // through the channel like any accelerator error
-    try { worker_body(d, device, k_worker, r0, r1, ch, order); }
+    try { worker_body(d, device, k_worker, blocks, ch, order); }
     catch (std::exception& e) {
         std::unique_ptr<WindowResult> r(new WindowResult());
         r->error = 19; r->msg = std::string("device worker: ") + e.what(); r->last = true;
@@ -549,8 +557,19 @@ void worker(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel*
     }
 }
 
-void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Channel* ch, RecordOrder* order)
+void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& blocks, Channel* ch, RecordOrder* order)
 {
+    // the worker's batch = its blocks one after the other; ridx[i] = the design-wide index of batch region i; a result window never spans two blocks
+    std::vector<int> ridx;
+    std::vector<int32_t> breaks;
+    std::vector<char> block_ends_at;             // [i + 1] set: batch region i is the last of a block
+    for (const auto& b : blocks) {
+        if (!ridx.empty()) breaks.push_back((int32_t)ridx.size());
+        for (int i = b.first; i < b.second; i++) ridx.push_back(i);
+    }
+    block_ends_at.assign(ridx.size() + 1, 0);
+    for (int32_t b : breaks) block_ends_at[(size_t)b] = 1;
+    block_ends_at[ridx.size()] = 1;
     int64_t all_before = 0;                      // all_mip_counter at the start of the next window
     auto fail_out = [&](int code, const std::string& msg) {
         std::unique_ptr<WindowResult> r(new WindowResult());
@@ -569,46 +588,47 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
     if (mipgen_accel_create(&ap, device, nullptr, &h)) { fail_out(17, mipgen_accel_last_error()); return; }
     auto bail = [&](int code) { std::string m = mipgen_accel_last_error(); mipgen_accel_destroy(h); fail_out(code, m); };
     if (o.score_method != MIPGEN_SCORE_LOGISTIC && mipgen_accel_load_model_file(h, d->model_path.c_str())) { bail(18); return; }
-    const int n = r1 - r0;
+    const int n = (int)ridx.size();
     lap(0);
     if (o.score_method != MIPGEN_SCORE_LOGISTIC) {                                                                   // mipgen.cpp:1171,1224
         std::vector<const char*> seqs((size_t)n);
         std::vector<int32_t> lens((size_t)n), starts((size_t)n), stops((size_t)n);
         std::vector<double> lrc((size_t)n * MIPGEN_N_LRC);
         for (int i = 0; i < n; i++) {
-            const Region& r = d->regions[(size_t)(r0 + i)];
+            const Region& r = d->regions[(size_t)ridx[(size_t)i]];
             seqs[(size_t)i] = r.long_range_seq.data(); lens[(size_t)i] = (int32_t)r.long_range_seq.size();
             starts[(size_t)i] = r.seq_start; stops[(size_t)i] = r.seq_stop;
         }
         if (mipgen_accel_long_range_content_batch(h, n, seqs.data(), lens.data(), starts.data(), stops.data(), lrc.data())) { bail(19); return; }
-        for (int i = 0; i < n; i++) memcpy(d->regions[(size_t)(r0 + i)].lrc, &lrc[(size_t)i * MIPGEN_N_LRC], sizeof(double) * MIPGEN_N_LRC);
+        for (int i = 0; i < n; i++) memcpy(d->regions[(size_t)ridx[(size_t)i]].lrc, &lrc[(size_t)i * MIPGEN_N_LRC], sizeof(double) * MIPGEN_N_LRC);
     }
     lap(1);
     // -gpu_copy_counter on: this handle counts the arm oligos of its own shard against the genome; the tables never leave its HBM
     // (host tables exist already if a caller asked for the regions before)
-    const bool resident = d->copies_deferred && n > 0 && !d->regions[(size_t)r0].copy_ready;
+    const bool resident = d->copies_deferred && n > 0 && !d->regions[(size_t)ridx[0]].copy_ready;
     if (resident) {
         std::vector<const char*> cs, rs;
         std::vector<int64_t> cl;
         std::vector<int32_t> rl;
         for (const std::string& c : d->genome) { cs.push_back(c.data()); cl.push_back((int64_t)c.size()); }
-        for (int i = 0; i < n; i++) { const Region& r = d->regions[(size_t)(r0 + i)]; rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size()); }
+        for (int i = 0; i < n; i++) { const Region& r = d->regions[(size_t)ridx[(size_t)i]]; rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size()); }
         int64_t n_big = 0;
         const mipgen_big_copy* big = nullptr;
         if (mipgen_accel_count_oligo_copies_resident(h, (int32_t)cs.size(), cs.data(), cl.data(), n, rs.data(), rl.data(), &n_big, &big)) { bail(11); return; }
-        for (int i = 0; i < n; i++) { Region& r = d->regions[(size_t)(r0 + i)]; r.copy_resident = true; r.big_copy.clear(); }
-        for (int64_t k = 0; k < n_big; k++) d->regions[(size_t)(r0 + big[k].region)].big_copy[{big[k].length, big[k].start}] = big[k].copies;
+        for (int i = 0; i < n; i++) { Region& r = d->regions[(size_t)ridx[(size_t)i]]; r.copy_resident = true; r.big_copy.clear(); }
+        for (int64_t k = 0; k < n_big; k++) d->regions[(size_t)ridx[(size_t)big[k].region]].big_copy[{big[k].length, big[k].start}] = big[k].copies;
         lap(6);
         // the capture-window half of check_copy_numbers (mapping_failed, mipgen.cpp:615-625, 841-868) for the same shard
-        try { gpu_window_flags(o, h, d->genome, d->regions, r0, r1); } catch (int) { bail(11); return; }
+        try { gpu_window_flags(o, h, d->genome, d->regions, ridx); } catch (int) { bail(11); return; }
         lap(7);
     }
     lap(6);
     std::vector<mipgen_region> batch((size_t)n);
-    for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)(r0 + i)], batch[(size_t)i], resident);
+    for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)ridx[(size_t)i]], batch[(size_t)i], resident);
     std::vector<mipgen_grid> grids((size_t)n);
     // silent designs keep only survivors, so a window may fill the HBM; otherwise its dense results come to the host (17 B per candidate)
     mipgen_accel_set_window_candidates(h, d->window_candidates > 0 ? d->window_candidates : (o.silent ? 0 : (int64_t)64 << 20));   // (tests force several windows)
+    if (mipgen_accel_set_window_breaks(h, breaks.data(), (int32_t)breaks.size())) { bail(19); return; }
     if (mipgen_accel_upload_regions(h, batch.data(), n, grids.data())) { bail(19); return; }
     // svr designs: mipgen.cpp:430 between the capture-size runs of the dense scorer - the tiles of a later run whose positions have all stopped are
     // never scored, exactly as the reference never constructs those candidates (nothing this front end reads lies behind a position's exit).
@@ -634,7 +654,9 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
         int64_t c0 = 0, nc = 0, p0 = 0, np = 0;
         mipgen_accel_window_info(h, w, &wr0, &wn, &c0, &nc, &p0, &np);
         std::unique_ptr<WindowResult> res(new WindowResult());
-        res->r0 = r0 + wr0; res->r1 = r0 + wr0 + wn; res->last = w == nw - 1;
+        res->r0 = wn > 0 ? ridx[(size_t)wr0] : 0; res->r1 = res->r0 + wn; res->last = w == nw - 1;
+        res->block_end = block_ends_at[(size_t)(wr0 + wn)] != 0;
+        if (wn > 0 && ridx[(size_t)(wr0 + wn - 1)] != res->r1 - 1) { mipgen_accel_destroy(h); fail_out(19, "internal: a result window spans two region blocks"); return; }
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
         for (auto& g : res->grids) g.offset -= c0;
         if (!rccl) { res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np)); }
@@ -660,7 +682,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
             // print_details on the device: the records leave the GPU as text, the dense results never do
             std::vector<mipgen_record_names> names((size_t)wn);
             for (int bi = 0; bi < wn; bi++) {
-                const Region& r = d->regions[(size_t)(r0 + wr0 + bi)];
+                const Region& r = d->regions[(size_t)(res->r0 + bi)];
                 names[(size_t)bi] = mipgen_record_names{r.chr.c_str(), r.label.c_str(), r.start - 1, r.stop};
             }
             int64_t n_rec = 0, n_bytes = 0;
@@ -673,6 +695,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
             }
             res->has_text = true;
             res->n_rec = n_rec;
+            res->own_before = all_before;
             all_before += n_rec;
         }
         lap(4);
@@ -714,7 +737,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, int r0, int r1, Cha
 // kernel's instruction budget (~47 VALU per table entry against ~2.7 per candidate; mipgen_amd/csrc/accel_tiles.hip: build_svr_tiles).  Exons
 // with few capture sizes cost more per candidate than their dense-grid size says.  The same rule: mipgen_amd/dist.py: region_cost.
 static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_capture, int inc, int max_overlap, int n_pairs, int n_e, int n_l,
-                           int max_sum, int min_sum, bool svr)
+                           int max_sum, int min_sum, bool svr, int64_t* candidates = nullptr)
 {
     const int K_all = (max_capture - min_capture) / inc + 1;
     int k0 = 0;
@@ -725,6 +748,7 @@ static int64_t region_cost(int start_fl, int stop_fl, int min_capture, int max_c
     const int64_t K = K_all - k0;
     const int64_t n_pos = std::max(0, stop_fl - std::max(0, start_fl - max_capture + max_sum));
     const int64_t cand = n_pos * K * n_pairs * 2;
+    if (candidates) *candidates = cand;
     if (!svr) return cand;
     const int64_t ssr = (std::min<int64_t>(K, 9) - 1) * inc + max_sum - min_sum + 1;            // scan sizes of one run of <= 9 capture sizes
     const int64_t runs = (K + 8) / 9;
@@ -786,14 +810,14 @@ extern "C" int mipgen_design_write_all_mips(mipgen_design* d, const char* text, 
     return 0;
 }
 
-static int64_t region_weight_of(const mipgen_design* d, int i)
+static int64_t region_weight_of(const mipgen_design* d, int i, int64_t* candidates = nullptr)
 {
     const Options& o = d->o;
     std::set<int> es, ls;
     for (auto& pr : o.arm_pairs) { es.insert(pr.first); ls.insert(pr.second); }
     const Region& r = d->regions[(size_t)i];
     return region_cost(r.start_fl, r.stop_fl, o.min_capture, o.max_capture, o.capture_increment, o.max_mip_overlap, (int)o.arm_pairs.size(), (int)es.size(),
-                       (int)ls.size(), o.max_arm_sum, o.min_arm_sum, o.score_method == MIPGEN_SCORE_SVR);
+                       (int)ls.size(), o.max_arm_sum, o.min_arm_sum, o.score_method == MIPGEN_SCORE_SVR, candidates);
 }
 
 extern "C" int mipgen_design_region_weights(const mipgen_design* d, int64_t* weights, int32_t capacity)
@@ -832,24 +856,35 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
     if (n_devices <= 0) n_devices = d->n_devices > 0 ? d->n_devices : visible;
     n_devices = std::max(1, std::min(n_devices, n));
-    // contiguous region ranges balanced by dense-grid size (the reference's region order is the order of the selection stage)
+    // Region blocks: consecutive regions of about equal device time (the kernels' cost model), dealt to the devices in turn - block b to device
+    // b mod N - and consumed by the selection stage in design order.  One device: one block (the handle cuts its own result windows).  Several:
+    // as many blocks per device as it has windows anyway (every window ends at a block's end), at least four where the design is large enough for
+    // blocks of 2^26 candidates - small blocks start the selection stage early and even out what the cost model misses.
     std::vector<int64_t> weight((size_t)n);
-    int64_t total = 0;
-    if (n > 0 && mipgen_design_region_weights(d, weight.data(), n)) return -1;
-    for (int i = 0; i < n; i++) total += weight[(size_t)i];
-    std::vector<std::pair<int, int>> shard;
+    int64_t total = 0, cand_total = 0;
+    for (int i = 0; i < n; i++) { int64_t c = 0; weight[(size_t)i] = region_weight_of(d, i, &c); total += weight[(size_t)i]; cand_total += c; }
+    int n_blocks = 1;
+    if (n_devices > 1) {
+        const int64_t cap = d->window_candidates > 0 ? d->window_candidates : (d->o.silent ? (int64_t)1 << 30 : (int64_t)64 << 20);
+        int64_t m = std::max<int64_t>(1, (cand_total + n_devices * cap - 1) / (n_devices * cap));
+        m = std::max(m, std::min<int64_t>(4, cand_total / ((int64_t)n_devices << 26)));
+        n_blocks = (int)std::min<int64_t>(n, (int64_t)n_devices * m);
+    }
+    std::vector<Blocks> blocks_of((size_t)n_devices);
     {
         int lo = 0;
         int64_t acc = 0;
-        for (int k = 0; k < n_devices; k++) {
-            const int64_t target = total * (k + 1) / n_devices;
+        for (int b = 0; b < n_blocks; b++) {
+            const int64_t target = (int64_t)((__int128)total * (b + 1) / n_blocks);
             int hi = lo;
-            while (hi < n && (acc + weight[(size_t)hi] <= target || hi == lo) && (n - hi) > (n_devices - 1 - k)) { acc += weight[(size_t)hi]; hi++; }
-            if (k == n_devices - 1) hi = n;
-            shard.push_back({lo, hi});
+            while (hi < n && (acc + weight[(size_t)hi] <= target || hi == lo) && (n - hi) > (n_blocks - 1 - b)) { acc += weight[(size_t)hi]; hi++; }
+            if (b == n_blocks - 1) hi = n;
+            blocks_of[(size_t)(b % n_devices)].push_back({lo, hi});
             lo = hi;
         }
     }
+    if (d->timing) std::cerr << "[mipgen timing] tile_regions: " << n << " regions, " << cand_total << " dense candidates in " << n_blocks << " region blocks on "
+                             << n_devices << " device worker(s)\n";
     // -gpu_gather rccl: one communicator rank per device worker, rank 0 = the root whose HBM the windows are gathered into
     std::unique_ptr<RcclGather> gather;
     std::thread gather_init;
@@ -870,7 +905,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     RecordOrder order(n_devices);
     for (int k = 0; k < n_devices; k++) {
         chans.emplace_back(new Channel());
-        threads.emplace_back(worker, d, k % visible, k, shard[(size_t)k].first, shard[(size_t)k].second, chans.back().get(), &order);
+        threads.emplace_back(worker, d, k % visible, k, blocks_of[(size_t)k], chans.back().get(), &order);
     }
     int rc = 0;
     StageClock clk(d->timing);
@@ -879,10 +914,12 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
     int64_t records_total = 0;                   // all_mips records written so far (the device text of all workers)
     // one result window through the selection stage: its all_mips text (a worker numbers its records from 0: shifted by what the workers before it
     // wrote), then region after region (mipgen.cpp:503-515)
-    auto select_window = [&](WindowResult* w, int64_t records_before_worker) {
+    auto select_window = [&](WindowResult* w) {
         const auto ts0 = std::chrono::steady_clock::now();
         if (w->has_text) {
-            if (records_before_worker) write_renumbered(d->out.all, w->text_p, (size_t)w->text_n, records_before_worker);
+            // the worker numbered this window's records from its own count; the design's count is what every device has written before it
+            const int64_t shift = records_total - w->own_before;
+            if (shift) write_renumbered(d->out.all, w->text_p, (size_t)w->text_n, shift);
             else d->out.all.write(w->text_p, (std::streamsize)w->text_n);                           // (the first worker's numbers are the design's)
             records_total += w->n_rec;
         }
@@ -910,21 +947,21 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
         std::cerr << "[mipgen] " << g_err << std::endl;
     };
     if (!d->gather_rccl) {
-        for (int k = 0; k < n_devices && rc == 0; k++) {
-            const int64_t records_before_worker = records_total;     // what worker k's own numbering (from 0) has to be shifted by
+        for (int b = 0; b < n_blocks && rc == 0; b++) {               // block after block = region after region; block b is device (b mod N)'s next
+            const int k = b % n_devices;
             for (;;) {
                 const auto tw0 = std::chrono::steady_clock::now();
                 std::unique_ptr<WindowResult> w = chans[(size_t)k]->pop();
                 t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
                 if (w->error) { worker_failed(w.get()); break; }
-                select_window(w.get(), records_before_worker);
-                if (w->last || rc) break;
+                select_window(w.get());
+                if (w->block_end || w->last || rc) break;
             }
         }
     } else {
         // -gpu_gather rccl: a window arrives as device pointers; its arrays are posted to GPU 0 with ONE grouped RCCL send / receive + one D2H copy
         // (asynchronous), and the selection of the window BEFORE it runs while that transfer is in flight (two receive slots)
-        struct Pending { std::unique_ptr<WindowResult> w; int slot = 0; int worker = 0; int64_t rec_before = 0; size_t off[5] = {0, 0, 0, 0, 0}; };
+        struct Pending { std::unique_ptr<WindowResult> w; int slot = 0; int worker = 0; size_t off[5] = {0, 0, 0, 0, 0}; };
         std::unique_ptr<Pending> pending;
         std::string gerr;
         int next_slot = 0;
@@ -950,10 +987,10 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             w->svr_p = (const double*)(hb + p->off[3]);
             w->text_p = hb + p->off[4]; w->text_n = w->views.n_text_bytes;
             for (int64_t q = 0; q < w->n_surv; q++) if (w->surv_p[q].cand_index >= 0) w->surv_p[q].cand_index -= w->c0;   // window-relative, like the grids
-            select_window(w, p->rec_before);
+            select_window(w);
         };
-        for (int k = 0; k < n_devices && rc == 0; k++) {
-            const int64_t records_before_worker = records_total + (pending && pending->w->has_text ? pending->w->n_rec : 0);
+        for (int b = 0; b < n_blocks && rc == 0; b++) {
+            const int k = b % n_devices;
             for (;;) {
                 std::unique_ptr<WindowResult> w = chans[(size_t)k]->try_pop();
                 if (!w) {
@@ -972,9 +1009,9 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                 size_t total = 0;
                 for (int i = 0; i < 5; i++) { pc[i].offset = total; p->off[i] = total; total += (pc[i].bytes + 15) & ~(size_t)15; }
                 if ((mixed && v.n_survivors && !v.survivor_svr) || (v.n_collapsed && !v.collapsed) || v.n_survivors != w->n_surv) { rc = fail(MIPGEN_HOST_E_ACCEL, 21, "rccl gather: a window without its arrays"); break; }
-                p->slot = next_slot; next_slot ^= 1; p->worker = k; p->rec_before = records_before_worker;
+                p->slot = next_slot; next_slot ^= 1; p->worker = k;
                 if (gather->post(k, pc, 5, total, p->slot, &gerr)) { d->flush_err(); rc = fail(MIPGEN_HOST_E_ACCEL, 21, gerr); std::cerr << "[mipgen] " << g_err << std::endl; break; }
-                const bool last = w->last;
+                const bool last = w->last || w->block_end;
                 p->w = std::move(w);
                 finish_pending();                                      // the window before this one, while this one's transfer runs
                 pending = std::move(p);

@@ -5,19 +5,98 @@
 // /root/reference/mipgen.cpp:503-515 condense -> collapse -> pick in region order; rand() at :1863 and the used-arm sets of :1925-1938 couple
 // the regions, so the pick runs in ONE place).  Single process, one communicator per device (ncclCommInitAll), every RCCL call from the
 // consumer thread; rank 0's own windows take the same route (a self send / receive inside the group).
+//
+// RCCL and the HIP runtime are bound at the first RcclGather::init, not at link time: only this opt-in route needs them, and every other run of
+// libmipgen_host.so (the default PCIe gather, designs that never reach the accelerator, usage errors, ranks of a multi-process harness) neither
+// pays RCCL's load time nor needs librccl on the machine.  Symbols already in the process are taken first (a program that links RCCL itself; the
+// memcpy-backed stand-ins of tests/stub_accel, which run this file with several ranks under ThreadSanitizer on a machine without a GPU).
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "gather.hpp"
 
 namespace mipgen {
 
 namespace {
+
+// the entry points this file calls, by their own prototypes (the headers above are used for the types only)
+#define GATHER_HIP_API(X) \
+    X(hipSetDevice) X(hipStreamCreateWithFlags) X(hipStreamSynchronize) X(hipStreamDestroy) X(hipEventCreateWithFlags) X(hipEventRecord) \
+    X(hipEventSynchronize) X(hipEventDestroy) X(hipFree) X(hipHostRegister) X(hipHostUnregister) X(hipMemcpyAsync) X(hipGetErrorString)
+#define GATHER_RCCL_API(X) X(ncclCommInitAll) X(ncclCommDestroy) X(ncclGroupStart) X(ncclGroupEnd) X(ncclSend) X(ncclRecv) X(ncclGetErrorString)
+
+struct Api {
+#define X(name) decltype(&::name) name = nullptr;
+    GATHER_HIP_API(X)
+    GATHER_RCCL_API(X)
+#undef X
+    // hipMalloc is an overload set in the C++ header: the plain (void**, size_t) form is the exported symbol
+    hipError_t (*hipMallocRaw)(void**, size_t) = nullptr;
+};
+Api g_api;
+std::once_flag g_api_once;
+std::string g_api_err;
+
+void* open_first(const char* const* names)
+{
+    for (; *names; names++) if (void* h = dlopen(*names, RTLD_NOW | RTLD_LOCAL)) return h;
+    return nullptr;
+}
+
+void bind_api()
+{
+    static const char* const rccl_names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", nullptr};
+    static const char* const hip_names[] = {"libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7", "libamdhip64.so", nullptr};
+    // (RTLD_DEFAULT is a null pointer: "found in the process" is a flag of its own)
+    auto why = [] { const char* e = dlerror(); return std::string(e ? e : "no loader message"); };
+    const bool rccl_here = dlsym(RTLD_DEFAULT, "ncclCommInitAll") != nullptr;
+    void* rccl = rccl_here ? RTLD_DEFAULT : open_first(rccl_names);
+    if (!rccl_here && !rccl) { g_api_err = "rccl gather: librccl not found (" + why() + ")"; return; }
+    const bool hip_here = dlsym(RTLD_DEFAULT, "hipStreamCreateWithFlags") != nullptr;
+    void* hip = hip_here ? RTLD_DEFAULT : open_first(hip_names);
+    if (!hip_here && !hip) { g_api_err = "rccl gather: libamdhip64 not found (" + why() + ")"; return; }
+    const char* missing = nullptr;
+#define X(name) if (!(g_api.name = (decltype(g_api.name))dlsym(hip, #name)) && !missing) missing = #name;
+    X(hipSetDevice) X(hipStreamCreateWithFlags) X(hipStreamSynchronize) X(hipStreamDestroy) X(hipEventCreateWithFlags) X(hipEventRecord)
+    X(hipEventSynchronize) X(hipEventDestroy) X(hipFree) X(hipHostRegister) X(hipHostUnregister) X(hipMemcpyAsync) X(hipGetErrorString)
+#undef X
+    if (!(g_api.hipMallocRaw = (hipError_t (*)(void**, size_t))dlsym(hip, "hipMalloc")) && !missing) missing = "hipMalloc";
+#define X(name) if (!(g_api.name = (decltype(g_api.name))dlsym(rccl, #name)) && !missing) missing = #name;
+    GATHER_RCCL_API(X)
+#undef X
+    if (missing) g_api_err = std::string("rccl gather: entry point ") + missing + " not found";
+}
+
+// (the names below shadow the headers' declarations inside this namespace: every call goes through the bound table)
+#define hipSetDevice g_api.hipSetDevice
+#define hipStreamCreateWithFlags g_api.hipStreamCreateWithFlags
+#define hipStreamSynchronize g_api.hipStreamSynchronize
+#define hipStreamDestroy g_api.hipStreamDestroy
+#define hipEventCreateWithFlags g_api.hipEventCreateWithFlags
+#define hipEventRecord g_api.hipEventRecord
+#define hipEventSynchronize g_api.hipEventSynchronize
+#define hipEventDestroy g_api.hipEventDestroy
+#define hipMalloc g_api.hipMallocRaw
+#define hipFree g_api.hipFree
+#define hipHostRegister g_api.hipHostRegister
+#define hipHostUnregister g_api.hipHostUnregister
+#define hipMemcpyAsync g_api.hipMemcpyAsync
+#define hipGetErrorString g_api.hipGetErrorString
+#define ncclCommInitAll g_api.ncclCommInitAll
+#define ncclCommDestroy g_api.ncclCommDestroy
+#define ncclGroupStart g_api.ncclGroupStart
+#define ncclGroupEnd g_api.ncclGroupEnd
+#define ncclSend g_api.ncclSend
+#define ncclRecv g_api.ncclRecv
+#define ncclGetErrorString g_api.ncclGetErrorString
+
 std::string hip_msg(const char* what, hipError_t e) { return std::string("rccl gather: ") + what + ": " + hipGetErrorString(e); }
 std::string nccl_msg(const char* what, ncclResult_t r) { return std::string("rccl gather: ") + what + ": " + ncclGetErrorString(r); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -27,6 +106,7 @@ struct RcclGather::Impl {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> send_streams;       // one per rank, on its device
+    bool bound = false;                          // the RCCL / HIP entry points are there (init got that far)
     hipStream_t recv_stream = nullptr;           // on the root device
     struct Slot {
         void* dev = nullptr; size_t dev_cap = 0;     // packed receive buffer on the root device
@@ -53,6 +133,9 @@ int RcclGather::init(const std::vector<int>& devices, std::string* err)
     Impl& P = *p_;
     const double t_init0 = now_s();
     if (check_devices(devices, err)) return -1;
+    std::call_once(g_api_once, bind_api);
+    if (!g_api_err.empty()) { *err = g_api_err; return -1; }
+    P.bound = true;
     P.devices = devices;
     P.comms.assign(devices.size(), nullptr);
     ncclResult_t r = ncclCommInitAll(P.comms.data(), (int)devices.size(), devices.data());
@@ -135,16 +218,20 @@ char* RcclGather::host(int s) { return (char*)p_->slot[s].host; }
 void RcclGather::destroy()
 {
     Impl& P = *p_;
+    if (!P.bound) return;                        // never initialised: nothing was created
     const double t0 = now_s();
+    // everything posted must have drained before a buffer goes: a post() that failed AFTER its group (the D2H copy, the event) leaves the receive
+    // of that group running into the slot's device buffer with no event to wait on - the streams themselves are waited for, senders first
+    for (size_t k = 0; k < P.send_streams.size(); k++) if (P.send_streams[k]) { (void)hipSetDevice(P.devices[k]); (void)hipStreamSynchronize(P.send_streams[k]); }
+    if (P.recv_stream) { (void)hipSetDevice(P.devices[0]); (void)hipStreamSynchronize(P.recv_stream); }
     for (int s = 0; s < kSlots; s++) {
         Impl::Slot& S = P.slot[s];
-        if (S.in_flight && S.done) (void)hipEventSynchronize(S.done);
         S.in_flight = false;
         if (S.dev) { (void)hipSetDevice(P.devices.empty() ? 0 : P.devices[0]); (void)hipFree(S.dev); S.dev = nullptr; S.dev_cap = 0; }
         if (S.host) { (void)hipHostUnregister(S.host); free(S.host); S.host = nullptr; S.host_cap = 0; }
         if (S.done) { (void)hipEventDestroy(S.done); S.done = nullptr; }
     }
-    for (size_t k = 0; k < P.send_streams.size(); k++) if (P.send_streams[k]) { (void)hipSetDevice(P.devices[k]); (void)hipStreamSynchronize(P.send_streams[k]); (void)hipStreamDestroy(P.send_streams[k]); }
+    for (size_t k = 0; k < P.send_streams.size(); k++) if (P.send_streams[k]) { (void)hipSetDevice(P.devices[k]); (void)hipStreamDestroy(P.send_streams[k]); }
     P.send_streams.clear();
     if (P.recv_stream) { (void)hipSetDevice(P.devices[0]); (void)hipStreamDestroy(P.recv_stream); P.recv_stream = nullptr; }
     for (ncclComm_t c : P.comms) if (c) (void)ncclCommDestroy(c);

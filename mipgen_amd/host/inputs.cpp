@@ -487,11 +487,12 @@ void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<
 }
 
 // -gpu_copy_counter on: the capture-window half of check_copy_numbers (mipgen.cpp:806-823, 841-868) through mipgen_accel_window_uniqueness, for the
-// regions [r0, r1): Region::unmappable = 1 for the window starts the reference enumerates ([start_fl - C, stop_fl), :808-813) whose window is
+// regions idx[] (design-wide indices, the order of the accelerator batch): Region::unmappable = 1 for the window starts the reference enumerates ([start_fl - C, stop_fl), :808-813) whose window is
 // not unique within one substitution.  Skipped with -check_copy_number off (the flag is then never consulted, :619).
-void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1)
+void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::string>& chroms, std::vector<Region>& regs, const std::vector<int>& idx)
 {
-    if (o.arg("-check_copy_number") == "off" || r1 <= r0) return;
+    const int nr = (int)idx.size();
+    if (o.arg("-check_copy_number") == "off" || nr <= 0) return;
     const int K = (o.max_capture - o.min_capture) / o.capture_increment + 1;
     std::vector<int32_t> sizes((size_t)K);
     for (int k = 0; k < K; k++) sizes[(size_t)k] = o.max_capture - k * o.capture_increment;
@@ -505,22 +506,22 @@ void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::
     // The restriction to the window starts the reference looks up (current_mip_start of mipgen.cpp:808-813) happens on the device, and only the
     // regions that have a flagged start at all (a few percent) get a table: the K x 112 M bytes of an exome's flag image stay in HBM
     std::vector<const char*> rs; std::vector<int32_t> rl; std::vector<mipgen_window_bounds> bounds;
-    for (int i = r0; i < r1; i++) {
+    for (int i : idx) {
         Region& r = regs[(size_t)i];
         rs.push_back(r.seq.data()); rl.push_back((int32_t)r.seq.size());
         bounds.push_back(mipgen_window_bounds{r.start_fl, r.stop_fl, r.seq_start, r.seq_stop});
         r.unmappable.clear();
     }
-    std::vector<uint8_t> any((size_t)(r1 - r0), 0);
-    if (mipgen_accel_window_uniqueness_begin(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(), bounds.data(), K, sizes.data(), seed, any.data())) {
+    std::vector<uint8_t> any((size_t)nr, 0);
+    if (mipgen_accel_window_uniqueness_begin(h, (int32_t)cs.size(), cs.data(), cl.data(), nr, rs.data(), rl.data(), bounds.data(), K, sizes.data(), seed, any.data())) {
         std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
         throw 11;
     }
-    for (int i = r0; i < r1; i++) {
-        if (!any[(size_t)(i - r0)]) continue;
-        Region& r = regs[(size_t)i];
+    for (int k = 0; k < nr; k++) {
+        if (!any[(size_t)k]) continue;
+        Region& r = regs[(size_t)idx[(size_t)k]];
         r.unmappable.assign((size_t)K * r.seq.size(), 0);
-        if (mipgen_accel_window_flags_region(h, i - r0, r.unmappable.data())) {
+        if (mipgen_accel_window_flags_region(h, k, r.unmappable.data())) {
             std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl;
             (void)mipgen_accel_window_uniqueness_end(h);
             throw 11;
@@ -550,7 +551,9 @@ void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, 
     const int rc = mipgen_accel_count_oligo_copies(h, (int32_t)cs.size(), cs.data(), cl.data(), r1 - r0, rs.data(), rl.data(),
                                                    (int32_t)lengths.size(), lengths.data(), outp.data());
     if (rc) { std::cerr << "[mipgen] accelerator: " << mipgen_accel_last_error() << std::endl; mipgen_accel_destroy(h); throw 11; }
-    try { gpu_window_flags(o, h, chroms, regs, r0, r1); } catch (...) { mipgen_accel_destroy(h); throw; }
+    std::vector<int> idx;
+    for (int i = r0; i < r1; i++) idx.push_back(i);
+    try { gpu_window_flags(o, h, chroms, regs, idx); } catch (...) { mipgen_accel_destroy(h); throw; }
     mipgen_accel_destroy(h);
     for (int i = r0; i < r1; i++) regs[(size_t)i].copy_ready = true;
 }

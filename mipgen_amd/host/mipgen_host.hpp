@@ -99,7 +99,7 @@ void attach_tables(const Options& o, const Tables& t, Region& r);               
 void load_genome(const Options& o, const std::vector<Region>& regs, std::vector<std::string>& chroms);   // the genome behind the bwa index
 void gpu_copy_numbers(const Options& o, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0 = 0, int r1 = -1, int device = 0);   // regions r0 .. r1 - 1 (r1 < 0: all), counted on `device`
 // -gpu_copy_counter on: Region::unmappable of regions [r0, r1) from the accelerator's window uniqueness test (mipgen.cpp:806-823, 841-868)
-void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::string>& chroms, std::vector<Region>& regs, int r0, int r1); // host tables (copy_flat)
+void gpu_window_flags(const Options& o, mipgen_accel* h, const std::vector<std::string>& chroms, std::vector<Region>& regs, const std::vector<int>& idx); // host tables (copy_flat)
 void attach_copy_tables(const Options& o, Region& r);                                                  // copy_ptr from copy_store / copy_flat
 void fill_accel_region(const Region& r, mipgen_region& out, bool resident_copies = false);
 

@@ -53,6 +53,7 @@ struct mipgen_accel {
     int device = 0;
     mo_model* model = nullptr;
     int64_t window_cap = 0;
+    std::vector<int32_t> window_breaks;
     std::vector<RegionStore> regions;
     std::vector<mipgen_grid> grids;
     std::vector<int64_t> region_pos0, region_base0;       // + totals at the end
@@ -160,6 +161,13 @@ int mipgen_accel_set_window_candidates(mipgen_accel* h, int64_t cap)
     return MIPGEN_OK;
 }
 
+int mipgen_accel_set_window_breaks(mipgen_accel* h, const int32_t* first_regions, int32_t n)
+{
+    if (!h || n < 0 || (n > 0 && !first_regions)) return fail(MIPGEN_E_INVALID, "bad arguments");
+    h->window_breaks.assign(first_regions, first_regions + n);
+    return MIPGEN_OK;
+}
+
 int mipgen_accel_long_range_content_batch(mipgen_accel* h, int32_t n, const char* const* seqs, const int32_t* lens, const int32_t* starts, const int32_t* stops, double* out)
 {
     if (!h || n < 0) return fail(MIPGEN_E_INVALID, "bad arguments");
@@ -220,7 +228,8 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
         w.r0 = i; w.cand0 = h->grids[(size_t)i].offset; w.pos0 = h->region_pos0[(size_t)i]; w.base0 = h->region_base0[(size_t)i];
         int64_t c = 0;
         int j = i;
-        while (j < n && (j == i || h->window_cap <= 0 || c + h->grids[(size_t)j].count <= h->window_cap)) { c += h->grids[(size_t)j].count; j++; }
+        auto forced = [&](int k) { return std::find(h->window_breaks.begin(), h->window_breaks.end(), k) != h->window_breaks.end(); };
+        while (j < n && (j == i || ((h->window_cap <= 0 || c + h->grids[(size_t)j].count <= h->window_cap) && !forced(j)))) { c += h->grids[(size_t)j].count; j++; }
         w.r1 = j; w.n_cand = c; w.n_pos = h->region_pos0[(size_t)j] - w.pos0; w.n_base = h->region_base0[(size_t)j] - w.base0;
         h->windows.push_back(w);
         i = j;
@@ -447,9 +456,31 @@ int mipgen_accel_download_survivor_scores(mipgen_accel* h, int32_t window, doubl
     return MIPGEN_OK;
 }
 
-// device-side entry points the RCCL gather and the GPU k-mer counter use: not in the stub (those paths need a GPU)
-int mipgen_accel_window_views(mipgen_accel*, int32_t, mipgen_window_views*) { return fail(MIPGEN_E_NODEVICE, "stub accelerator: no device memory"); }
-int mipgen_accel_synchronize(mipgen_accel* h) { return h ? MIPGEN_OK : fail(MIPGEN_E_INVALID, "null handle"); }
+// the "device-side" views of a window the RCCL gather posts from (host memory here; tests/stub_accel/stub_rccl.cpp moves it on stream threads):
+// the same fields as mipgen_amd/csrc/accel_score.hip hands out
+int mipgen_accel_window_views(mipgen_accel* h, int32_t window, mipgen_window_views* out)
+{
+    if (!h || !out || window < 0 || window >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "bad arguments");
+    INJECT(h, "window_views");
+    const uint8_t st = h->win_state[(size_t)window];
+    if (!(st & 1)) return fail(MIPGEN_E_STATE, "window %d holds no current survivors (replay + condense first)", window);
+    const Win& W = h->windows[(size_t)window];
+    memset(out, 0, sizeof *out);
+    out->emitted = h->emitted_per_region.data() + W.r0; out->n_emitted = W.r1 - W.r0;
+    out->survivors = h->survivors.data() + 2 * W.pos0; out->n_survivors = 2 * W.n_pos;
+    if (st & 2) { out->collapsed = h->collapsed.data() + W.base0; out->n_collapsed = W.n_base; }
+    if (st & 4) out->survivor_svr = h->surv_svr.data() + 2 * W.pos0;
+    if (window == h->cur && h->have_text && !h->text.empty()) { out->text = h->text.data(); out->n_text_bytes = (int64_t)h->text.size(); }
+    out->first_candidate = W.cand0;
+    return MIPGEN_OK;
+}
+int mipgen_accel_synchronize(mipgen_accel* h)
+{
+    if (!h) return fail(MIPGEN_E_INVALID, "null handle");
+    INJECT(h, "synchronize");
+    return MIPGEN_OK;
+}
+// the GPU k-mer counter: not in the stub (those paths need a GPU)
 int mipgen_accel_count_oligo_copies(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, int32_t, const int32_t*, int32_t* const*)
 { return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter"); }
 int mipgen_accel_count_oligo_copies_resident(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, int64_t*, const mipgen_big_copy**)

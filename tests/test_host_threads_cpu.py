@@ -52,7 +52,13 @@ def _compare(meta, work):
                                           ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_mixed", 4), ("multichr_logistic_snps", 2),
                                           ("long_capture_logistic", 1), ("long_capture_svr", 2), ("empty_sum_lists", 2), ("no_arm_pairs", 1),
                                           ("both_arm_options", 2), ("wild_vcf_mixed", 2), ("edge_options", 1), ("edge_options_svr", 1)])
-def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, workers, tmp_path):
+@pytest.mark.parametrize("gather", ["pcie", "rccl"])
+def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, workers, gather, tmp_path):
+    """gather = rccl: the same designs through `-gpu_gather rccl` (mipgen_amd/host/gather.cpp) with TWO and FOUR communicator ranks - its RCCL / HIP
+    entry points are the memcpy-backed, stream-threaded stand-ins of tests/stub_accel/stub_rccl.cpp, which the file binds at run time exactly as it
+    binds librccl on a GPU box: grouped send / receive per window into two receive slots, one D2H copy, selection of the window before meanwhile."""
+    if gather == "rccl":
+        workers = 4 if workers in (1, 4) else 2
     if san == "address" and (name, workers) not in (("mixed_12_regions", 4), ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_logistic_snps", 2),
                                                     ("long_capture_logistic", 1), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2)):
         pytest.skip("thirteen under ThreadSanitizer, eight under AddressSanitizer + UBSan")
@@ -62,7 +68,7 @@ def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, 
         pytest.skip("the 1,100-base captures (string lengths of the host side): AddressSanitizer; the SVR one under ThreadSanitizer")
     meta = H.load_design(name)
     biggest = max(r[2] - r[1] for r in meta["intervals"])
-    p = _run(san, meta, str(tmp_path), workers, extra=["-gpu_window_candidates", str(max(1000, biggest * 2000))])
+    p = _run(san, meta, str(tmp_path), workers, extra=["-gpu_window_candidates", str(max(1000, biggest * 2000)), "-gpu_gather", gather])
     err = p.stderr.decode()
     assert p.returncode == 0, err[-3000:]
     assert "ThreadSanitizer" not in err and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
@@ -94,3 +100,65 @@ def test_injected_accelerator_failure_ends_the_run_cleanly(san, call, device, nt
     assert p.returncode == 1, (p.returncode, err[-2000:])
     assert "unable to tile sequences due to circumstance" in err and "mip picking complete" not in err
     assert "mip picking complete" not in open(os.path.join(str(tmp_path), "out.progress.txt")).read()
+
+
+RCCL_SWEEP = [("accel", "window_views", 1, 2), ("accel", "synchronize", 3, 1), ("accel", "format_all_mips", 2, 2), ("rccl", "ncclCommInitAll", 0, 1),
+              ("rccl", "ncclGroupEnd", 0, 1), ("rccl", "ncclGroupEnd", 0, 5), ("rccl", "hipMemcpyAsync", 0, 3), ("rccl", "hipEventSynchronize", 0, 2),
+              ("rccl", "hipMalloc", 0, 2)]
+
+
+@pytest.mark.parametrize("where,call,device,nth", RCCL_SWEEP)
+def test_injected_failure_on_the_rccl_route_ends_the_run_cleanly(san, where, call, device, nth, tmp_path):
+    """The abort paths of `-gpu_gather rccl` with four ranks: an accelerator call of a worker on that route (the device views of a window, the
+    synchronisation before they are published, the text of a later window) or a call of the gather itself (communicator set-up, the n-th grouped
+    send / receive, the D2H copy, the wait for a slot, a receive buffer) fails once.  Same convention as on the PCIe route: exit status 1, the
+    reference's message, no completion line; no worker is left waiting for a transfer that will never be marked, nothing is freed under a copy."""
+    if san == "address" and RCCL_SWEEP.index((where, call, device, nth)) % 3 != 0 and not os.environ.get("MIPGEN_SAN_FULL"):
+        pytest.skip("swept under ThreadSanitizer; AddressSanitizer takes every third")
+    meta = H.load_design("mixed_12_regions")
+    env = {"STUB_ACCEL_FAIL": f"{device}:{call}:{nth}"} if where == "accel" else {"STUB_RCCL_FAIL": f"{call}:{nth}"}
+    p = _run(san, meta, str(tmp_path), 4, extra=["-gpu_window_candidates", "30000", "-gpu_gather", "rccl"], env_extra=env, timeout=300)
+    err = p.stderr.decode()
+    assert "ThreadSanitizer" not in err and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
+    assert p.returncode == 1, (p.returncode, err[-2000:])
+    assert ("injected" in err or "rccl gather" in err) and "unable to tile sequences due to circumstance" in err and "mip picking complete" not in err, err[-2000:]
+    assert "mip picking complete" not in open(os.path.join(str(tmp_path), "out.progress.txt")).read()
+
+
+def _waiting_seconds(err):
+    import re
+    m = re.search(r"waiting for the device workers ([0-9.e+-]+) s, selection stage ([0-9.e+-]+) s", err)
+    assert m, err[-2000:]
+    return float(m.group(1)), float(m.group(2))
+
+
+@pytest.mark.parametrize("gather", ["pcie", "rccl"])
+def test_device_workers_overlap_with_many_windows_per_worker(gather, tmp_path):
+    """`mipgen -gpus 4` with MANY result windows per device must overlap its device workers: the regions are dealt to the devices in blocks (block b
+    to device b mod N) and consumed in design order, so no device waits for the devices before it to be consumed completely (round 5 handed out
+    contiguous shards: a device slept after three windows; four workers x 15 windows measured 3.17 s against 2.98 s for one).  The time the selection
+    thread spends waiting for the device workers with four of them (>= 12 windows each) is at most 0.4 x the one-worker time.  The oracle-backed stub
+    is the 'device' (its scoring time per window is CPU time of the worker thread), so this needs four cores."""
+    if (os.cpu_count() or 1) < 4:
+        pytest.skip("needs four cores: the stub accelerator scores on the worker threads")
+    san = "address"
+    import fcntl
+    os.makedirs(os.path.join(STUB, "_build"), exist_ok=True)
+    with open(os.path.join(STUB, "_build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-s", "-j4", "-C", STUB, f"SAN={san}"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    meta = H.load_design("practice62_config1")                         # 62 regions, logistic, silent
+    extra = ["-gpu_window_candidates", "1", "-gpu_timing", "on", "-gpu_gather", gather]     # one region per window: 62 windows, 15-16 per worker of four
+    waits = {}
+    for workers in (1, 4):
+        work = str(tmp_path / f"w{workers}")
+        p = _run(san, meta, work, workers, extra=extra, timeout=900)
+        err = p.stderr.decode()
+        assert p.returncode == 0, err[-3000:]
+        assert "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
+        _compare(meta, work)
+        waits[workers] = _waiting_seconds(err)
+        m = __import__("re").search(r"in (\d+) region blocks on (\d+) device", err)
+        assert m and int(m.group(2)) == workers and (workers == 1 or int(m.group(1)) >= 12 * workers), err[-2000:]
+    assert waits[4][0] <= 0.4 * waits[1][0], f"device workers do not overlap: waiting {waits[4][0]:.2f} s with four workers, {waits[1][0]:.2f} s with one"
