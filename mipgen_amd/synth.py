@@ -37,6 +37,55 @@ def random_genome(length: int, seed: int, gc: float = 0.5, n_run_frac: float = 0
     return seq.tobytes()
 
 
+# zones of hard_genome (0-based half-open; the designs of tests/golden/make_golden.py: DESIGNS4 lay their intervals over them)
+HARD_ZONES = {"iupac": (4000, 9000), "lower": (10000, 14000), "lowcomplex": (16000, 22000), "gc20": (24000, 26000), "gc70": (28000, 30000),
+              "dash": (32000, 34000)}
+
+
+def hard_genome(length: int = 40000, seed: int = 404) -> bytes:
+    """A chromosome AS IT STANDS IN A FASTA FILE with everything the iid ACGT genomes lack (GRCh37 has all of it):
+      iupac       ambiguity codes R Y M K S W B D H V, one per ~120 bases (the reference guards on N only, SVMipv4.cpp:116; any other byte just is
+                  not A/C/G/T to its counters, :118-141, and passes through reverse_comp unchanged, MinusSVMipv4.cpp:24-25)
+      lower       soft-masked stretches of 40-300 lower-case bases, ambiguity codes and n included (the reference upper-cases what it reads,
+                  mipgen.cpp:1158,1168,1208)
+      lowcomplex  homopolymers of 30-70 bases, (CA)n / (AT)n / (GGC)n / (AAAG)n microsatellites of 40-140 bases, one every ~350 bases
+      gc20, gc70  blocks of 20 % and 70 % G+C
+      dash        '-' bytes, one per ~400 bases (a '-' in an arm is the other half of the guard of SVMipv4.cpp:116)
+    with the usual iid background and short runs of N everywhere."""
+    rng = np.random.default_rng(seed)
+    seq = np.frombuffer(random_genome(length, seed + 1, n_run_frac=0.002, n_run_len=7), dtype=np.uint8).copy()
+    lo, hi = HARD_ZONES["iupac"]
+    codes = np.frombuffer(b"RYMKSWBDHV", dtype=np.uint8)
+    for p in rng.choice(np.arange(lo, hi), size=(hi - lo) // 120, replace=False):
+        seq[p] = codes[rng.integers(0, len(codes))]
+    lo, hi = HARD_ZONES["gc20"]
+    seq[lo:hi] = np.frombuffer(random_genome(hi - lo, seed + 2, gc=0.2), dtype=np.uint8)
+    lo, hi = HARD_ZONES["gc70"]
+    seq[lo:hi] = np.frombuffer(random_genome(hi - lo, seed + 3, gc=0.7), dtype=np.uint8)
+    lo, hi = HARD_ZONES["lowcomplex"]
+    p = lo + 150
+    units = [b"A", b"T", b"G", b"C", b"CA", b"AT", b"GGC", b"AAAG", b"TG", b"CCG"]
+    k = 0
+    while p < hi - 200:
+        u = units[k % len(units)]
+        n = int(rng.integers(30, 71)) if len(u) == 1 else int(rng.integers(40, 141))
+        seq[p:p + n] = np.frombuffer((u * (n // len(u) + 1))[:n], dtype=np.uint8)
+        p += n + int(rng.integers(200, 420))
+        k += 1
+    lo, hi = HARD_ZONES["dash"]
+    for p in rng.choice(np.arange(lo, hi), size=(hi - lo) // 400, replace=False):
+        seq[p] = ord("-")
+    lo, hi = HARD_ZONES["lower"]
+    for p in rng.choice(np.arange(lo, hi), size=(hi - lo) // 200, replace=False):      # ambiguity codes here too (they come out of toupper as upper case)
+        seq[p] = codes[rng.integers(0, len(codes))]
+    p = lo + 60
+    while p < hi - 320:
+        n = int(rng.integers(40, 301))
+        seq[p:p + n] |= 0x20                                  # ASCII lower case
+        p += n + int(rng.integers(80, 500))
+    return seq.tobytes()
+
+
 def write_fasta(path: str, name: str, seq: bytes, width: int = 60) -> None:
     with open(path, "wb") as fh:
         fh.write(b">" + name.encode() + b"\n")

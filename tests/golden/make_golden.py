@@ -113,6 +113,63 @@ def gen_candidates(genome: bytes) -> None:
     print(f"candidates: {n} known answers, {len(lr_in)} long-range vectors")
 
 
+def gen_candidates_hard(genome4: bytes) -> None:
+    """Known answers on sequence that is NOT iid ACGT + N: candidates cut from the hard genome (mipgen_amd/synth.py: hard_genome - ambiguity
+    codes, '-' bytes, homopolymers, microsatellites, 20 % / 70 % GC), upper-cased as the reference's input stage hands them to its classes
+    (mipgen.cpp:1158) and - every fifth - left in LOWER case (what the classes do with bytes their input stage would never pass: nothing matches
+    'A'/'C'/'G'/'T', SVMipv4.cpp:118-141; reverse_comp leaves them, MinusSVMipv4.cpp:24-25).  Ambiguity codes and '-' in arms AND inserts."""
+    R = po.refdrv()
+    rng = np.random.default_rng(4321)
+    dp = C.POINTER(C.c_double)
+    m64 = R.ref_svm_load_model(os.path.join(HERE, "models", "svr_syn_64.model").encode())
+    m200 = R.ref_svm_load_model(os.path.join(HERE, "models", "svr_syn_200.model").encode())
+    zones = list(synth.HARD_ZONES.items())
+    recs, logistic, params, svr64, svr200, lrcs = [], [], [], [], [], []
+    n = 240
+    for t in range(n):
+        zname, (lo, hi) = zones[t % len(zones)]
+        e = int(rng.integers(16, 31)); l = int(rng.integers(16, 31))
+        ss = int(rng.integers(70, 200))
+        p = int(rng.integers(lo + 40, hi - 260)); strand = int(rng.integers(0, 2))
+        g = genome4 if t % 5 == 4 else genome4.upper()
+        ext = bytearray(g[p - 1 - e:p - 1] if strand == 0 else g[p - 1 + ss:p - 1 + ss + e])
+        ins = bytearray(g[p - 1:p - 1 + ss])
+        lig = bytearray(g[p - 1 + ss:p - 1 + ss + l] if strand == 0 else g[p - 1 - l:p - 1])
+        kind = t % 12
+        codes = b"RYMKSWBDHV"
+        if kind == 1: ext[int(rng.integers(0, e))] = codes[t % 10]               # an ambiguity code in the extension arm
+        if kind == 2: lig[int(rng.integers(0, l))] = codes[(t + 3) % 10]
+        if kind == 3: lig[0 if strand == 0 else l - 1] = codes[t % 10]           # ... at the ligation junction (no junction feature matches)
+        if kind == 4: ext[int(rng.integers(0, e))] = ord("-")                    # '-' in an arm: the guard of SVMipv4.cpp:116
+        if kind == 5: ins[int(rng.integers(0, ss))] = ord("-")                   # '-' in the insert only: no guard
+        if kind == 6: ins[0] = codes[t % 10]; ins[ss - 1] = codes[(t + 5) % 10]
+        if kind == 7: ext[e - 1] = codes[t % 10]; lig[l - 1] = codes[(t + 1) % 10]
+        ec = int(rng.choice([0, 1, 1, 1, 2, 20, 100, 101])); lc = int(rng.choice([1, 1, 1, 3, 19, 101]))
+        lrc = rng.uniform(0, 0.3, 44)
+        ext, lig, ins = bytes(ext), bytes(lig), bytes(ins)
+        s = R.ref_logistic(strand, ext, lig, ins, ec, lc, MIDDLE)
+        x = np.empty(192)
+        R.ref_parameters(strand, ext, lig, ins, ec, lc, MIDDLE, lrc.ctypes.data_as(dp), x.ctypes.data_as(dp))
+        recs.append({"strand": strand, "ext_fwd": ext.decode(), "lig_fwd": lig.decode(), "ins_fwd": ins.decode(), "ext_copy": ec, "lig_copy": lc, "zone": zname})
+        logistic.append(s); params.append(x); lrcs.append(lrc)
+        svr64.append(R.ref_predict_text(m64, x.ctypes.data_as(dp), 192))
+        svr200.append(R.ref_predict_text(m200, x.ctypes.data_as(dp), 192))
+    # long-range content (Featurev5.cpp:18-56) over every zone, on the upper-cased chromosome (mipgen.cpp:1208) and once on the bytes as they stand
+    lr_in, lr_out = [], []
+    for t, (zname, (lo, hi)) in enumerate(zones + [("lower_raw", synth.HARD_ZONES["lower"])]):
+        a = max(0, lo - 900); ln = min(len(genome4) - a, hi - lo + 1800)
+        seq = (genome4 if zname == "lower_raw" else genome4.upper())[a:a + ln]
+        cs = a + 1001; ce = a + ln - 1000
+        out = np.empty(44)
+        R.ref_long_range_content(seq, cs, ce, out.ctypes.data_as(dp))
+        lr_in.append({"offset": a, "len": ln, "chrom_seq_start": cs, "chrom_seq_stop": ce, "raw": zname == "lower_raw"}); lr_out.append(out)
+    np.savez_compressed(os.path.join(HERE, "candidates_hard.npz"), logistic=np.array(logistic), params=np.array(params),
+                        svr64=np.array(svr64), svr200=np.array(svr200), lrc=np.array(lrcs), lr_out=np.array(lr_out))
+    with open(os.path.join(HERE, "candidates_hard.json"), "w") as fh:
+        json.dump({"middle": MIDDLE.decode(), "candidates": recs, "long_range": lr_in}, fh)
+    print(f"candidates_hard: {n} known answers; guard (-1000) on {sum(1 for v in logistic if v == -1000.0)}")
+
+
 def gen_libsvm_trained_model(genome: bytes) -> None:
     """A model TRAINED and WRITTEN by the reference's own libsvm (svm_train, svm.cpp:2095; svm_save_model, svm.cpp:2644-2757) on the feature vectors
     of 360 candidates of the golden genome (SVMipv4::get_parameters) with a smooth synthetic target, and the reference's predictions (svm_predict through
@@ -299,6 +356,33 @@ DESIGNS3 = [
 ]
 MULTI_CHROMS = (("2", 40000, 302), ("10", 40000, 310), ("X", 40000, 388))       # (name, bases, seed)
 
+# Designs on the HARD genome (mipgen_amd/synth.py: hard_genome, chromosome "4"): ambiguity codes, lower case, '-' bytes, homopolymers,
+# microsatellites, 20 % / 70 % GC - in arms and inserts of emitted candidates, through every scorer; non-silent (all_mips compared record by record)
+_Z = synth.HARD_ZONES
+DESIGNS4 = [
+    dict(name="hard_logistic", method="logistic", chrom="4",
+         ivs=[("4", _Z["iupac"][0] + 600, _Z["iupac"][0] + 900, "iupac"), ("4", _Z["lower"][0] + 500, _Z["lower"][0] + 760, "lower"),
+              ("4", _Z["lowcomplex"][0] + 700, _Z["lowcomplex"][0] + 1500, "lowcx"), ("4", _Z["gc20"][0] + 500, _Z["gc20"][0] + 700, "gc20"),
+              ("4", _Z["gc70"][0] + 500, _Z["gc70"][0] + 700, "gc70"), ("4", _Z["dash"][0] + 300, _Z["dash"][0] + 900, "dash")],
+         minC=152, maxC=162, sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=[]),
+    dict(name="hard_svr", method="svr", chrom="4",
+         ivs=[("4", _Z["iupac"][0] + 2000, _Z["iupac"][0] + 2120, "iupac"), ("4", _Z["lower"][0] + 1800, _Z["lower"][0] + 1900, "lower"),
+              ("4", _Z["lowcomplex"][0] + 2600, _Z["lowcomplex"][0] + 2900, "lowcx"), ("4", _Z["gc20"][0] + 900, _Z["gc20"][0] + 1000, "gc20"),
+              ("4", _Z["gc70"][0] + 900, _Z["gc70"][0] + 1000, "gc70"), ("4", _Z["dash"][0] + 1100, _Z["dash"][0] + 1300, "dash")],
+         minC=140, maxC=160, sums=[43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_64.model", extra=[]),
+    dict(name="hard_mixed", method="mixed", chrom="4",
+         ivs=[("4", _Z["iupac"][0] + 3300, _Z["iupac"][0] + 3450, "iupac"), ("4", _Z["lower"][0] + 2700, _Z["lower"][0] + 2850, "lower"),
+              ("4", _Z["lowcomplex"][0] + 4000, _Z["lowcomplex"][0] + 4400, "lowcx"), ("4", _Z["gc70"][0] + 1300, _Z["gc70"][0] + 1420, "gc70"),
+              ("4", _Z["dash"][0] + 1500, _Z["dash"][0] + 1650, "dash")],
+         minC=125, maxC=135, sums=[42, 43], flank=4, tags="4,4", snps=True, trf=True, bwa="hashed", model="svr_syn_64.model", extra=[]),
+    # the low-complexity zone alone at the default capture range, every arm-length sum, silent mode like a whole-exome run
+    dict(name="hard_lowcomplexity_svr_silent", method="svr", chrom="4",
+         ivs=[("4", _Z["lowcomplex"][0] + 100, _Z["lowcomplex"][0] + 700, "lc1"), ("4", _Z["lowcomplex"][0] + 4700, _Z["lowcomplex"][0] + 5200, "lc2"),
+              ("4", _Z["gc20"][0] + 1200, _Z["gc20"][0] + 1500, "gc20"), ("4", _Z["gc70"][0] + 1500, _Z["gc70"][0] + 1800, "gc70")],
+         minC=152, maxC=162, sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_200.model",
+         extra=["-silent_mode", "on"]),
+]
+
 
 def parse_bed_text(text: str):
     ivs = []
@@ -374,7 +458,7 @@ def gen_design(genome, d: dict, genome_name: str = "genome_chr1.fa.gz", out_root
         lo = min(iv.bed_start for iv in ivs) - 1000
         hi = max(iv.bed_end for iv in ivs) + 1000
         snps = synth.random_snps("1", genome, 4000, 10000, seed=13, per_bp=1 / 40.0) if genome_name == "genome_chr1.fa.gz" else \
-            synth.random_snps("1", genome, lo, hi, seed=13, per_bp=1 / 60.0)
+            synth.random_snps(chrom, genome.upper(), lo, hi, seed=13, per_bp=1 / 60.0)
         snp_path = w + "/snps.vcf"
         synth.write_vcf(snp_path, d["snp_hook"](snps) if d.get("snp_hook") else snps)
         shutil.copy(snp_path, out + "/snps.vcf")
@@ -479,6 +563,17 @@ def main() -> None:
     for d in DESIGNS3:
         if not only or d["name"] in only:
             gen_design(multi, d, "genome3")
+    # the hard genome: chromosome "4", written with its lower case, ambiguity codes and '-' bytes as a FASTA file holds them
+    genome4 = synth.hard_genome()
+    with gzip.GzipFile(os.path.join(HERE, "genome4_chr4.fa.gz"), "wb", mtime=0) as gz:
+        gz.write(b">chr4\n")
+        for i in range(0, len(genome4), 60):
+            gz.write(genome4[i:i + 60] + b"\n")
+    if not only or "candidates_hard" in only:
+        gen_candidates_hard(genome4)
+    for d in DESIGNS4:
+        if not only or d["name"] in only:
+            gen_design(genome4, d, "genome4_chr4.fa.gz")
 
 
 if __name__ == "__main__":

@@ -33,17 +33,27 @@ def genome():
     return H.golden_genome()
 
 
+def _genome_of(meta, genome):
+    """The chromosome a golden design is laid on, as the reference's input stage hands it on (upper case, mipgen.cpp:1208); the hard genome's file
+    holds lower case, ambiguity codes and '-' bytes."""
+    name = meta.get("genome", "genome_chr1.fa.gz")
+    return genome if name == "genome_chr1.fa.gz" else H.golden_genome(name).upper()
+
+
+HARD = ["hard_logistic", "hard_svr", "hard_mixed"]     # the hard genome: ambiguity codes, lower case, '-', homopolymers, microsatellites, GC 20 / 70 %
+
+
 def _model_path(meta):
     return os.path.join(H.GOLDEN, "models", meta["model"]) if meta["model"] else os.path.join(H.GOLDEN, "models", "svr_syn_64.model")
 
 
-@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small", "logistic_default_arms"])
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small", "logistic_default_arms"] + HARD)
 @pytest.mark.parametrize("method", [capi.SCORE_LOGISTIC, capi.SCORE_SVR])
 def test_dense_grid_vs_oracle(name, method, genome):
     """Every dense-grid candidate of the golden designs: records bit-exact, scores within 1e-5."""
     meta = H.load_design(name)
     P = H.design_params(meta)
-    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    regions = H.design_regions(meta, _genome_of(meta, genome), P, lrc_fn=po.long_range_content)
     mp = _model_path(meta)
     acc = capi.Accel(P)
     acc.load_model_file(mp)
@@ -91,14 +101,25 @@ def _region_for_candidate(c, lrc, P):
 def test_sparse_candidates_vs_golden_known_answers():
     """mipgen_accel_score_candidates against the reference's own known answers (tests/golden/candidates.*):
     the 192 features bit-exact (integer counts / integer denominators), logistic and SVR within 1e-5."""
-    with open(os.path.join(H.GOLDEN, "candidates.json")) as fh:
+    _known_answers("candidates", 100)
+
+
+def test_sparse_candidates_vs_known_answers_on_hard_sequence():
+    """The same against tests/golden/candidates_hard.*: candidates cut from the hard genome - ambiguity codes (R Y M K S W B D H V) and '-' bytes in
+    arms AND inserts (at the ligation junction, at the arm ends), bytes left in lower case, homopolymers, microsatellites, 20 % / 70 % GC.  The
+    reference guards on N and '-' only (SVMipv4.cpp:116); any other byte simply is not A / C / G / T to its counters (:118-141) and passes through
+    reverse_comp (MinusSVMipv4.cpp:24-25)."""
+    _known_answers("candidates_hard", 200)
+
+
+def _known_answers(fixture, n_min):
+    with open(os.path.join(H.GOLDEN, fixture + ".json")) as fh:
         meta = json.load(fh)
-    z = np.load(os.path.join(H.GOLDEN, "candidates.npz"))
-    n_checked = 0
+    z = np.load(os.path.join(H.GOLDEN, fixture + ".npz"))
+    n_checked = n_odd = 0
     for model_name, key in (("svr_syn_64.model", "svr64"), ("svr_syn_200.model", "svr200")):
         for i, c in enumerate(meta["candidates"]):
-            if any(ch not in "ACGTN" for ch in c["ext_fwd"] + c["lig_fwd"]):
-                continue
+            n_odd += any(ch not in "ACGTN" for ch in c["ext_fwd"] + c["lig_fwd"])
             if i % 2 == (0 if key == "svr64" else 1) and i > 60:
                 continue                                    # alternate candidates between the two models to bound run time
             e, l = len(c["ext_fwd"]), len(c["lig_fwd"])
@@ -122,28 +143,30 @@ def test_sparse_candidates_vs_golden_known_answers():
                       "run_count", "junction", "ext_copy", "lig_copy", "scan_size"):
                 assert getattr(ints[0], f) == getattr(oints, f), (i, f)
             n_checked += 1
-    assert n_checked > 100
+    assert n_checked > n_min and (fixture == "candidates" or n_odd > 60)
 
 
-def test_long_range_content_vs_golden(genome):
-    with open(os.path.join(H.GOLDEN, "candidates.json")) as fh:
+@pytest.mark.parametrize("fixture", ["candidates", "candidates_hard"])
+def test_long_range_content_vs_golden(fixture, genome):
+    with open(os.path.join(H.GOLDEN, fixture + ".json")) as fh:
         meta = json.load(fh)
-    z = np.load(os.path.join(H.GOLDEN, "candidates.npz"))
+    z = np.load(os.path.join(H.GOLDEN, fixture + ".npz"))
+    g = genome if fixture == "candidates" else H.golden_genome("genome4_chr4.fa.gz")
     P = capi.make_params(120, 130)
     acc = capi.Accel(P)
     for i, lr in enumerate(meta["long_range"]):
-        seq = genome[lr["offset"]:lr["offset"] + lr["len"]]
+        seq = (g if fixture == "candidates" or lr["raw"] else g.upper())[lr["offset"]:lr["offset"] + lr["len"]]
         got = acc.long_range_content(seq, lr["chrom_seq_start"], lr["chrom_seq_stop"])
-        assert np.array_equal(got, z["lr_out"][i])       # integer counts / integer denominator: bit-exact
+        assert np.array_equal(got, z["lr_out"][i]), (fixture, i)       # integer counts / integer denominator: bit-exact
     acc.close()
 
 
-@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small", "logistic_default_arms"])
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small", "logistic_default_arms"] + HARD)
 def test_replay_condense_vs_oracle(name, genome):
     """Device replay of the early exits + condense fold == the oracle's, fed with the device's own scores."""
     meta = H.load_design(name)
     P = H.design_params(meta)
-    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    regions = H.design_regions(meta, _genome_of(meta, genome), P, lrc_fn=po.long_range_content)
     method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
     acc = capi.Accel(P)
     if meta["model"]:
@@ -172,14 +195,14 @@ def test_replay_condense_vs_oracle(name, genome):
     acc.close()
 
 
-@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small"])
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "svr_small", "mixed_small"] + HARD)
 def test_all_oracle_chain_vs_device_chain(name, genome):
     """The chain closed on BOTH sides: the oracle's own dense scores -> its replay -> its condense fold, against the device's scores -> replay ->
     fold.  (The test above feeds the oracle's control flow the device's scores; here nothing crosses.)  Candidate indices, records and emitted
     masks must be identical - the two score sets differ by ~1e-14, which flips a comparison only on an exact tie -, scores within 1e-5."""
     meta = H.load_design(name)
     P = H.design_params(meta)
-    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    regions = H.design_regions(meta, _genome_of(meta, genome), P, lrc_fn=po.long_range_content)
     method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
     om = po.Model(_model_path(meta)) if meta["model"] and method == capi.SCORE_SVR else None
     acc = capi.Accel(P)
@@ -738,14 +761,14 @@ def _collapse_py(P, g, surv, target, max_product, thr):
     return best
 
 
-@pytest.mark.parametrize("name", ["logistic_snp_trf", "mixed_small", "svr_small"])
+@pytest.mark.parametrize("name", ["logistic_snp_trf", "mixed_small", "svr_small", "hard_mixed"])
 def test_collapse_on_device(name, genome):
     """mipgen_accel_collapse: per base and strand the survivor the reference's collapse fold keeps (SNP count first, then strictly higher
     score, first come first kept), incl. the copy / masked-arm filters - against a plain restatement of the fold; window by window and
     through the fused silent path."""
     meta = H.load_design(name)
     P = H.design_params(meta)
-    regions = H.design_regions(meta, genome, P, lrc_fn=po.long_range_content)
+    regions = H.design_regions(meta, _genome_of(meta, genome), P, lrc_fn=po.long_range_content)
     method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
     acc = capi.Accel(P)
     if meta["model"]:

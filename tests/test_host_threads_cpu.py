@@ -51,7 +51,8 @@ def _compare(meta, work):
 @pytest.mark.parametrize("name,workers", [("logistic_default_arms", 1), ("logistic_default_arms", 2), ("mixed_12_regions", 4), ("mixed_12_regions", 2),
                                           ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_mixed", 4), ("multichr_logistic_snps", 2),
                                           ("long_capture_logistic", 1), ("long_capture_svr", 2), ("empty_sum_lists", 2), ("no_arm_pairs", 1),
-                                          ("both_arm_options", 2), ("wild_vcf_mixed", 2), ("edge_options", 1), ("edge_options_svr", 1)])
+                                          ("both_arm_options", 2), ("wild_vcf_mixed", 2), ("edge_options", 1), ("edge_options_svr", 1),
+                                          ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2)])
 @pytest.mark.parametrize("gather", ["pcie", "rccl"])
 def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, workers, gather, tmp_path):
     """gather = rccl: the same designs through `-gpu_gather rccl` (mipgen_amd/host/gather.cpp) with TWO and FOUR communicator ranks - its RCCL / HIP
@@ -60,8 +61,13 @@ def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, 
     if gather == "rccl":
         workers = 4 if workers in (1, 4) else 2
     if san == "address" and (name, workers) not in (("mixed_12_regions", 4), ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_logistic_snps", 2),
-                                                    ("long_capture_logistic", 1), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2)):
-        pytest.skip("thirteen under ThreadSanitizer, eight under AddressSanitizer + UBSan")
+                                                    ("long_capture_logistic", 1), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2),
+                                                    ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2)):
+        pytest.skip("fourteen under ThreadSanitizer, eleven under AddressSanitizer + UBSan")
+    if san == "thread" and name in ("hard_logistic", "hard_svr"):
+        pytest.skip("the hard genome's large designs (a million records): AddressSanitizer; hard_mixed under both")
+    if gather == "rccl" and name in ("hard_logistic", "hard_svr"):
+        pytest.skip("once is enough for the large hard designs")
     if san == "thread" and name == "edge_options":
         pytest.skip("190,000 records under ThreadSanitizer take a minute: AddressSanitizer only")
     if san == "thread" and name == "long_capture_logistic":

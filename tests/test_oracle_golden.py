@@ -11,11 +11,14 @@ from oracle import pyoracle as po
 from tests import helpers as H
 
 
-@pytest.fixture(scope="module")
-def cands():
-    with open(os.path.join(H.GOLDEN, "candidates.json")) as fh:
+@pytest.fixture(scope="module", params=["candidates", "candidates_hard"])
+def cands(request):
+    """candidates: iid ACGT + N from the first golden genome; candidates_hard: cut from the hard genome (ambiguity codes, '-' bytes, lower case left
+    as it is in every fifth, homopolymers, microsatellites, 20 % / 70 % GC) with ambiguity codes and '-' planted in arms and inserts."""
+    with open(os.path.join(H.GOLDEN, request.param + ".json")) as fh:
         meta = json.load(fh)
-    z = np.load(os.path.join(H.GOLDEN, "candidates.npz"))
+    z = np.load(os.path.join(H.GOLDEN, request.param + ".npz"))
+    meta["name"] = request.param
     return meta, z
 
 
@@ -35,7 +38,10 @@ def test_logistic_and_parameters_bit_exact(cands):
         if sc != -1000.0:
             assert x[0] * len(e) == pytest.approx(ints.ext_a, abs=1e-9)
             assert x[151] == ints.scan_size
-    assert n_guard > 20 and n_nan > 5      # the edge cases are really in the fixture
+    assert n_guard > 20 and (n_nan > 5 or meta["name"] == "candidates_hard")      # the edge cases are really in the fixture
+    if meta["name"] == "candidates_hard":
+        odd = sum(1 for c in meta["candidates"] if any(ch not in "ACGTN" for ch in c["ext_fwd"] + c["lig_fwd"]))
+        assert odd > 60, odd                                                       # arms with bytes other than A C G T N
 
 
 def test_svr_predict_bit_exact(cands):
@@ -64,9 +70,9 @@ def test_model_written_by_libsvm_itself():
 
 def test_long_range_content_bit_exact(cands):
     meta, z = cands
-    g = H.golden_genome()
+    g = H.golden_genome() if meta["name"] == "candidates" else H.golden_genome("genome4_chr4.fa.gz")
     for i, lr in enumerate(meta["long_range"]):
-        seq = g[lr["offset"]:lr["offset"] + lr["len"]]
+        seq = (g if meta["name"] == "candidates" or lr["raw"] else g.upper())[lr["offset"]:lr["offset"] + lr["len"]]
         got = po.long_range_content(seq, lr["chrom_seq_start"], lr["chrom_seq_stop"])
         assert np.array_equal(got, z["lr_out"][i])
 
