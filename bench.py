@@ -15,9 +15,10 @@ Workloads (mipgen_amd/workloads.py; no real genome / BED / trained model exists 
                         with the logistic score) or --method svr
   exome / exome_snp     configs[3] / [4] shape: --regions R of the 200,000 exon-like intervals, capture 150-170 / 120-250, SVR
 
-N = 1 (default): practice62 / SVR (configs[1], the config the 1-GPU metric is quoted on); `extra` carries a line for the metric's own
-multi-GPU config (exome200k, configs[3]) on this one GPU, a sustained (>= 2 s) run of the headline, the nSV sweep, the logistic scorer, the
-mixed-mode list re-scorer and the k-mer counter.  Before anything is timed an in-run PARITY GATE scores regions of the bench batch and
+N = 1 (default): practice62 / SVR (configs[1], the config the 1-GPU metric is quoted on); the metric's own multi-GPU config - ALL 200,000 exons of
+configs[3] - is timed in the same run on this one GPU (`exome_strong` = `scale_base`; its value and roofline also inside `config.exome_full` /
+`roofline.exome_full`, where the driver's record keeps them); `extra` carries the round-5 shard of 65,536 exons, a sustained (>= 2 s) run of the
+headline, the nSV sweep, the logistic scorer, the mixed-mode list re-scorer and the k-mer counter.  Before anything is timed an in-run PARITY GATE scores regions of the bench batch and
 compares records / scores / replay / condensed survivors with the oracle (the checker only: nothing the oracle computes is timed or reported
 as a rate) - SURVEY.md section 8d "correctness gate run with every measurement".
 
@@ -29,7 +30,7 @@ with ONE gather of the condensed survivors to rank 0 (RCCL over xGMI), where the
 
 The scaling curve (driver: `bench.py --gpus N` for N = 1, 2, 4, 8) is ONE workload family in `value`: the configs[1] headline batch, weak-scaled
 (`scale_family` names it in every line), so value(N) / (N value(1)) is a like-for-like efficiency.  The metric's own multi-GPU config (configs[3],
-the exome) rides along in every line as `exome_strong`: the first 65,536 exons cut N ways, one timed pass with its gather (at N = 1 the same
+the exome) rides along in every line as `exome_strong`: all 200,000 exons cut N ways, one timed pass with its gather (at N = 1 the same
 object is also printed as `scale_base`); divide exome_strong.value of an N-rank line by the one of the N = 1 line - never by `value`.
 Every line names `rccl_ranks` (the world size torch.distributed reports after init_process_group; 1 without a process group) and the dense
 candidates of every rank.
@@ -64,7 +65,7 @@ MODEL_RHO = -2.2                 # practice62 (the headline)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 ALG_BYTES_PER_CAND = 16          # 8 B score + 8 B integer record written per candidate
-SCALE_REGIONS = 65536            # exons of the strong-scaling BED (--gpus N > 1) and of the N = 1 line's `scale_base`
+SCALE_REGIONS = 200000           # exons of the strong-scaling BED (--gpus N > 1) and of the N = 1 line's `scale_base`: all of configs[3]
 
 CONFIGS = {
     #             capture      method      default regions
@@ -92,10 +93,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the nSV sweep and the logistic line")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the multi-core CPU baseline (0 = all physical host cores)")
-    ap.add_argument("--exome-regions", type=int, default=200000, help="exons of the exome200k line in `extra` (N = 1 default run; 0 = skip)")
+    ap.add_argument("--exome-regions", type=int, default=65536, help="exons of the round-5 exome shard kept in `extra` for continuity (N = 1 default run; 0 = skip)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained run of the headline in `extra` (0 = skip)")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the in-run oracle check (profiling runs)")
-    ap.add_argument("--scale-base-regions", type=int, default=65536, help="exons of the `scale_base` line (N = 1 default run; 0 = skip): what --gpus N > 1 shards")
+    ap.add_argument("--scale-base-regions", type=int, default=200000, help="exons of `exome_strong` / `scale_base` (0 = skip): ALL of BASELINE configs[3] by default - "
+                    "one timed pass on the one GPU at N = 1, cut N ways at --gpus N")
     ap.add_argument("--measure-traffic", action="store_true", help="measure the dominant kernel's HBM bytes in this run (child rocprofv3 --pmc passes); the default "
                     "N = 1 run (practice62, no --no-extras) does so by itself")
     ap.add_argument("--no-measure-traffic", action="store_true", help="never start the child rocprofv3 passes (the traffic then comes from profiles/)")
@@ -578,7 +580,7 @@ def exome_line(args, device: int, stream: int, model_path: str, n_regions: int =
                     f"kernels' cost model, one timed pass (rank 0: {acc.window_count()} result windows; wall clock around score_condense_all"
                     f"{' + the gather of the survivors to rank 0' if distributed else ''}, max over ranks)",
             "value": total / d1, "unit": "candidates/s", "seconds": d1, "dense_candidates": total, "dense_candidates_per_rank": per_rank, "regions": len(ivs),
-            "n_gpus": world, "scaling": "strong",
+            "n_gpus": world, "scaling": "strong", "result_windows_rank0": acc.window_count(),
             "emitted_candidates_rank0": int(emitted.sum()), "survivors_rank0": int((surv["cand_index"] >= 0).sum()), "build_and_upload_seconds": t_build}
     if gather:
         line["survivors_gathered"] = sum(gather.sizes) // 24
@@ -722,7 +724,7 @@ def main() -> None:
         cand_per_rank = [n_cand]
         skipped_per_rank = [skipped_per_step]
         rccl_ranks = 1
-    # the metric's own multi-GPU config beside the headline family, at every N: the first 65,536 exons cut `world` ways (collective calls: every rank)
+    # the metric's own multi-GPU config beside the headline family, at every N: all 200,000 exons of configs[3] cut `world` ways (collective calls: every rank)
     exome_strong = None
     if args.scale_base_regions > 0 and args.config == "practice62" and method == "svr" and not args.no_extras and not args.regions:
         exome_strong = exome_line(args, local_rank, stream, model_path, n_regions=args.scale_base_regions, rank=rank, world=world, distributed=distributed, xdev=xdev)
@@ -799,9 +801,20 @@ def main() -> None:
             "parity_checked": bool(gate), "parity_gate": gate,
             "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},
         }
+        out["roofline"]["kernels_ms"] = out["kernels_ms"]    # (the driver's record keeps the standard objects whole: the per-kernel times ride in one of them)
         if exome_strong:
             exome_strong["compare_with"] = "exome_strong.value of the --gpus 1 line (the same BED on one GPU) - never with `value`, which is another workload"
             out["exome_strong"] = exome_strong
+            # the same numbers inside `config` / `roofline`, short strings only: BASELINE configs[3] at full size, timed in this very run
+            out["config"]["exome_full"] = {"workload": f"configs[3]: {exome_strong['regions']} exons, capture 150-170, SVR n_sv={n_sv}, {world} way(s)",
+                                           "value": exome_strong["value"], "unit": "candidates/s", "seconds": exome_strong["seconds"],
+                                           "dense_candidates": exome_strong["dense_candidates"], "regions": exome_strong["regions"], "n_gpus": world,
+                                           "result_windows_rank0": exome_strong.get("result_windows_rank0")}
+            if "roofline" in exome_strong:
+                r = exome_strong["roofline"]
+                out["roofline"]["exome_full"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                                                 "table_entries_per_sv": r["table_entries_per_sv"], "hbm_frac": r["hbm"]["frac"],
+                                                 "clock": "wall around the whole pass (records + k_svr_dense + replay/condense)"}
         if method == "svr":
             out["fp64"] = {"pairs_per_launch": n_cand * n_sv, "pairs_per_s": n_cand * n_sv / (k_ms * 1e-3),
                            "naive_equiv_tflops": n_cand * n_sv * 600.0 / (k_ms * 1e-3) / 1e12, "peak_tflops": FP64_PEAK_TFLOPS}
@@ -824,8 +837,11 @@ def main() -> None:
                                      "dense_candidates": exome_strong["dense_candidates"], "regions": exome_strong["regions"], "n_gpus": 1, "scaling": "strong",
                                      "equivalent_command": f"python bench.py --gpus 1 --config exome --regions {args.scale_base_regions} --scaling strong",
                                      "roofline": exome_strong["roofline"]}
+                by_k = exome_rates_by_sizes(args, local_rank, stream, model_path)
                 extra.append({"what": "k_svr_dense on the exome regions that keep K capture sizes (mipgen.cpp:429), K by K: the first 4,096 exons",
-                              "by_capture_sizes": exome_rates_by_sizes(args, local_rank, stream, model_path)})
+                              "by_capture_sizes": by_k})
+                out["config"]["exome_by_capture_sizes"] = {k: {"candidates_per_s": v["candidates_per_s"], "candidates_share": v["candidates_share"],
+                                                               "regions": v["regions"]} for k, v in by_k.items()}
             if args.sustain_seconds > 0:
                 # the headline again, long enough for an outside observer (the driver's GPU-busy sampler) to see: same step, >= 2 s
                 reps = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)

@@ -42,7 +42,9 @@ extern "C" {
 typedef struct mipgen_design mipgen_design;
 
 const char* mipgen_host_last_error(void);
-/* the reference's `throw <int>` code of the last failure (mipgen.cpp:2029-2035), 0 if none */
+/* the reference's `throw <int>` code of the last failure (mipgen.cpp:2029-2035), 0 if none; -1 = a std::exception the reference raises on the same
+ * input (boost::bad_lexical_cast, vector::at, std::string(NULL)): its main() reports it and exits with 0, and so does the drop-in command line;
+ * -2 = a std::exception only this library can raise (allocation, internal error): reported the same way, exit status 1 */
 int mipgen_host_last_circumstance(void);
 
 /* argv as main() receives it (argv[0] locates mipgen_svr.model, mipgen.cpp:137-138,409).  Parses the options, runs the input stage

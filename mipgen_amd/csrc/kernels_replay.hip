@@ -250,13 +250,16 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
     const int lo = ends_below ? top_bit(ends_below) + 1 : 0;
     const uint64_t seg = in ? ((gend >= 64 ? ~0ull : (1ull << gend) - 1) & ~((1ull << lo) - 1)) : 0;
     const uint64_t seg_below = seg & below_me, seg_above = seg & ~below_me & ~lane_bit;
-    // :443-444, the bounds skips, from the geometry alone: a pair is constructed at scan start p and capture size C iff p > max(e, l) and
-    // p + C - 1 - min(e, l) <= seq_stop - exactly the VALID bit of the candidate's record (kernels_logistic_dense.hip, kernels_logistic.hip), which the
-    // replay therefore does not fetch: 16 instead of 24 bytes per pair and row
+    // :443-444, the bounds skips, from the geometry alone: a pair is constructed at scan start p and capture size C iff p > max(e, l),
+    // p + C - 1 - min(e, l) <= seq_stop and the scan target is not empty (C > e + l) - exactly the VALID bit of the candidate's record
+    // (kernels_logistic_dense.hip, kernels_logistic.hip: `ss > 0`; mipgen_accel_create refuses parameter sets with min_capture <= max arm sum, the
+    // test keeps this kernel in step with the other two replay kernels should that ever change), which the replay therefore does not fetch: 16 instead of
+    // 24 bytes per pair and row.  One unsigned compare per row: e + l < C <= c_lim  <=>  (unsigned)(C - e - l - 1) <= (unsigned)(c_lim - e - l - 1).
     const int p_scan = R.first_pos + pi;
-    const bool ok_lo = in && p_scan > max(e, l);
     const int c_lim = R.seq_stop - p_scan + 1 + min(e, l);                   // largest capture size that still fits
-    const int c_top = P->max_capture - R.k0 * P->inc, c_inc = P->inc;
+    const int c_span = c_lim - (e + l) - 1;
+    const bool ok_lo = in && p_scan > max(e, l) && c_span >= 0;
+    const int c_top = P->max_capture - R.k0 * P->inc - (e + l) - 1, c_inc = P->inc;   // (capture size of row ki) - e - l - 1 = c_top - ki * c_inc
 
     // ---- replay, mipgen.cpp:426-497 ---------------------------------------------------------------------
     unsigned long long n_emitted = 0;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(REPLAY_WAVES * 64) void k_replay_condense_narrow(
             uint64_t emit_all = 0;
             if (!(pbs > upper)) {                                            // :430
                 const double plus = bp[q], minus = bm[q];
-                const bool valid = ok_lo && c_top - ki * c_inc <= c_lim;                         // :443-444 (false outside the row)
+                const bool valid = ok_lo && (unsigned)(c_top - ki * c_inc) <= (unsigned)c_span;  // :443-444 (false outside the row)
                 const uint64_t vmask = __ballot(valid);
                 bool mine = valid;
                 // (rows whose constructed pairs all score in [0, 1) cannot trigger :494 - every truncated score is 0: see k_replay_condense_carry)

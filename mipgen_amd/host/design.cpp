@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <fstream>
 #include <iostream>
 #include <limits>
 #include <memory>
@@ -168,7 +169,7 @@ int mipgen_design_open(int argc, const char* const* argv, mipgen_design** out_d)
         snprintf(msg, sizeof msg, "unable to tile sequences due to circumstance %d", e);                             // mipgen.cpp:2029-2032
         return fail(e == 1 ? MIPGEN_HOST_E_USAGE : MIPGEN_HOST_E_INPUT, e, msg);
     } catch (std::exception& e) {
-        return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
+        return fail(MIPGEN_HOST_E_INPUT, exception_circumstance(e), std::string("unable to tile sequences\n") + e.what());
     }
     *out_d = d.release();
     return 0;
@@ -379,7 +380,7 @@ int mipgen_design_select_region_collapsed(mipgen_design* d, int32_t i, const mip
     } catch (std::exception& e) {
         d->flush_err();
         d->failed = true;
-        return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what());
+        return fail(MIPGEN_HOST_E_INPUT, exception_circumstance(e), std::string("unable to tile sequences\n") + e.what());
     }
     d->next_region = i + 1;
     if (d->next_region == (int)d->regions.size()) d->flush_err();
@@ -846,11 +847,24 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             for (auto& s : none) { s.cand_index = -1; s.score = 0.0; s.record = 0; }
             try { rc0 = mipgen_design_select_region_collapsed(d, i, &g, none.data(), 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr); }
             catch (int e) { rc0 = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
-            catch (std::exception& e) { rc0 = fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what()); }
+            catch (std::exception& e) { rc0 = fail(MIPGEN_HOST_E_INPUT, exception_circumstance(e), std::string("unable to tile sequences\n") + e.what()); }
         }
         d->flush_err();
         if (rc0) d->failed = true;
         return rc0;
+    }
+    if (d->o.masked_arm_threshold_bad) {
+        // -masked_arm_threshold is no number: the reference's first design_mip throws boost::bad_lexical_cast (mipgen.cpp:626) - after the output
+        // files were opened; their buffered headers never reach the disk (probed: four empty files, exit status 0)
+        d->out.progress << "designing all mips for feature #1\n";
+        d->err_lines += "[mipgen] feature #1\n";                        // mipgen.cpp:417: the first region's loop had started
+        d->flush_err();
+        Outputs& out = d->out;
+        const std::string pn = d->o.project_name;
+        out.all.close(); out.collapsed.close(); out.picked.close(); out.snp.close();
+        for (const char* f : {".all_mips.txt", ".collapsed_mips.txt", ".picked_mips.txt", ".snp_mips.txt"}) { std::ofstream t(pn + f, std::ios::trunc); }
+        d->failed = true;
+        return fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + BadLexicalCast().what());
     }
     const int visible = mipgen_accel_device_count();
     if (visible <= 0) return fail(MIPGEN_HOST_E_ACCEL, 17, "no HIP device: the accelerated front end has no CPU path");
@@ -936,7 +950,7 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                                                  (int32_t)((w->col_off[(size_t)bi + 1] - w->col_off[(size_t)bi]) / 2),
                                                  d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
             } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
-            catch (std::exception& e) { rc = fail(MIPGEN_HOST_E_INPUT, -1, std::string("unable to tile sequences\n") + e.what()); }   // (mipgen.cpp:2033-2035)
+            catch (std::exception& e) { rc = fail(MIPGEN_HOST_E_INPUT, exception_circumstance(e), std::string("unable to tile sequences\n") + e.what()); }   // (mipgen.cpp:2033-2035)
             pos0 += g.n_pos;
         }
         t_select += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();

@@ -92,7 +92,7 @@ std::vector<Region> load_regions(const Options& o, bool* opened)
         if (f.size() < 3) {
             // bed_fields.at(1) / .at(2) of the reference (mipgen.cpp:1019,1021,1029): std::out_of_range with libstdc++'s text, reported by main()
             const std::string n = std::to_string(f.size());
-            throw std::out_of_range("vector::_M_range_check: __n (which is " + n + ") >= this->size() (which is " + n + ")");
+            throw RefOutOfRange("vector::_M_range_check: __n (which is " + n + ") >= this->size() (which is " + n + ")");
         }
         const std::string label = f.size() > 3 ? f[3] : default_label;
         const std::string chr = f[0].substr(0, 3) == "chr" ? f[0].substr(3) : f[0];

@@ -15,12 +15,13 @@ int main(int argc, char** argv)
         else std::cerr << mipgen_host_last_error() << std::endl;                                                                  // mipgen.cpp:2029-2032
         // a std::exception (a bad integer, a BED line with two fields, an option without its value ...) is reported and the reference's main() then falls
         // off its end: exit status 0 (mipgen.cpp:2033-2036) - reproduced; `throw <int>` paths exit with 1 (:2029-2032)
-        if (mipgen_host_last_circumstance() == -1) return 0;
+        if (mipgen_host_last_circumstance() == -1) return 0;                  // (-2 = a std::exception the reference cannot raise: this port's own failure, exit status 1)
         return 1;
     }
     rc = mipgen_design_run(d, 0);
-    const bool exception_path = rc && mipgen_host_last_circumstance() == -1;            // a std::exception inside the selection stage: as above
-    if (exception_path) std::cerr << mipgen_host_last_error() << std::endl;
+    const int circ = rc ? mipgen_host_last_circumstance() : 0;
+    const bool exception_path = circ == -1;                                              // a std::exception the reference raises too: as above
+    if (circ == -1 || circ == -2) std::cerr << mipgen_host_last_error() << std::endl;
     else if (rc) std::cerr << "unable to tile sequences due to circumstance " << mipgen_host_last_circumstance() << std::endl;
     mipgen_design_close(d);
     return rc && !exception_path ? 1 : 0;

@@ -13,6 +13,7 @@
 // Candidate construction + scoring (tile_regions' loop body, design_mip, get_score, get_parameters, predict_value)
 // is NOT here: it is the accelerator's job (include/mipgen_accel.h).
 #pragma once
+#include <stdexcept>
 #include <algorithm>
 #include <cstdint>
 #include <fstream>
@@ -36,6 +37,7 @@ struct Options {
     bool double_tile = false, double_tile_strands_separately = false, silent = false;
     bool seal_both = false, half_seal_both = false;
     double masked_arm_threshold = 0.5;
+    bool masked_arm_threshold_bad = false;       // the option's text is no number: the reference only finds out at its first design_mip (mipgen.cpp:626)
     double logistic_priority = 0.9, logistic_optimal = 0.98, svr_priority = 1.5, svr_optimal = 2.2;
     int score_method = MIPGEN_SCORE_LOGISTIC;
     std::string middle;                          // universal_middle_mip_seq (mipgen.cpp:199-200)
@@ -51,9 +53,17 @@ struct Options {
 // returns "" on success, else the message the reference would print before `throw 1` (mipgen.cpp:140-145)
 std::string parse_command_line(int argc, char** argv, Options& o);
 // what boost::lexical_cast throws in the reference (every integer / real option and BED field): main() prints its text after "unable to tile sequences"
-struct BadLexicalCast : std::exception {
+// The std::exceptions the REFERENCE itself raises on malformed input (a boost::lexical_cast, vector::at on a short BED line, std::string(NULL) for an
+// option without its value): its main() prints their text and falls off its end - exit status 0 (mipgen.cpp:2033-2036).  Reproduced for exactly
+// these (circumstance -1); any other std::exception is this port's own failure (an allocation, a logic error in the selection or gather code) and
+// ends the run with circumstance -2 and exit status 1: a broken accelerated run must not look like a success to a pipeline.
+struct ReferenceEquivalent { virtual ~ReferenceEquivalent() = default; };
+struct BadLexicalCast : std::exception, ReferenceEquivalent {
     const char* what() const noexcept override { return "bad lexical cast: source type value could not be interpreted as target"; }
 };
+struct RefOutOfRange : std::out_of_range, ReferenceEquivalent { using std::out_of_range::out_of_range; };
+struct RefLogicError : std::logic_error, ReferenceEquivalent { using std::logic_error::logic_error; };
+inline int exception_circumstance(const std::exception& e) { return dynamic_cast<const ReferenceEquivalent*>(&e) ? -1 : -2; }
 int lexical_int(const std::string& s);
 // throws int (4 = invalid scoring method) exactly as parse_arg_values does
 void finalize_options(Options& o);

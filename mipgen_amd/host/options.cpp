@@ -1,6 +1,7 @@
 // options.cpp — flag-compatible command line of the drop-in `mipgen` front end.
 // Follows mipgen::set_default_args / parse_command_line / parse_arg_values (/root/reference/mipgen.cpp:164-276,1280-1501):
 // same option names, defaults, required set, -file_of_parameters handling and error strings; the usage texts are our own.
+#include <cmath>
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
@@ -114,7 +115,7 @@ std::string parse_command_line(int argc, char** argv, Options& o)
         std::string p(argv[i]);
         if (!known(p)) { std::cerr << "not found" << std::endl; return p + " not recognized as valid option\n"; }
         // an option without its value: the reference builds a std::string from argv[argc] = NULL (mipgen.cpp:1297) - a std::logic_error with this text
-        if (i + 1 >= argc) throw std::logic_error("basic_string::_M_construct null not valid");
+        if (i + 1 >= argc) throw RefLogicError("basic_string::_M_construct null not valid");
         o.args[p] = argv[i + 1];
         if (p == "-file_of_parameters") check_file = true;
         else if (p == "-arm_length_sums") o.has_arm_length_sums = true;
@@ -142,12 +143,16 @@ std::string parse_command_line(int argc, char** argv, Options& o)
 static int to_int(const std::string& s) { return lexical_int(s); }
 static double to_double(const std::string& s)
 {
-    // boost::lexical_cast<double>: the whole string, no leading white space
+    // boost::lexical_cast<double> as the reference's Boost behaves (probed on the real binary, tests/golden/error_cases.json): the whole string, no
+    // leading white space, decimal only (strtod would take 0x1p-1), "inf" / "nan" / "infinity" in any case and a leading '+' accepted, a value
+    // that overflows rejected, one that underflows (1e-320) accepted
     if (s.empty() || std::isspace((unsigned char)s[0])) throw BadLexicalCast();
+    const size_t d0 = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+    if (s.size() > d0 + 1 && s[d0] == '0' && (s[d0 + 1] == 'x' || s[d0 + 1] == 'X')) throw BadLexicalCast();
     errno = 0;
     char* end = nullptr;
     const double v = std::strtod(s.c_str(), &end);
-    if (end != s.c_str() + s.size() || errno == ERANGE) throw BadLexicalCast();
+    if (end != s.c_str() + s.size() || (errno == ERANGE && std::fabs(v) > 1.0)) throw BadLexicalCast();
     return v;
 }
 static std::vector<std::string> split(const std::string& s, char c)
@@ -214,7 +219,9 @@ void finalize_options(Options& o)
     o.max_capture = to_int(a["-max_capture_size"]); o.min_capture = to_int(a["-min_capture_size"]);
     o.capture_increment = to_int(a["-capture_increment"]);
     if (o.capture_increment == 0) o.capture_increment = 1;                      // mipgen.cpp:274
-    o.masked_arm_threshold = to_double(a["-masked_arm_threshold"]);
+    // (the reference casts this option where it uses it - first in design_mip, mipgen.cpp:626 - so a malformed value ends the run THERE, with the
+    // output files open: mipgen_design_run raises it at that point)
+    try { o.masked_arm_threshold = to_double(a["-masked_arm_threshold"]); } catch (BadLexicalCast&) { o.masked_arm_threshold_bad = true; }
     o.silent = a["-silent_mode"] == "on";
     o.seal_both = a["-seal_both_strands"] == "on";
     o.half_seal_both = a["-half_seal_both_strands"] == "on";

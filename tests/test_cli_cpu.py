@@ -44,13 +44,16 @@ def _error_cases():
 
 
 @pytest.mark.parametrize("name", ["unknown_option", "bad_method", "min_gt_max", "no_bed_file", "bad_cols", "bad_num", "unknown_chromosome", "empty_bed",
-                                  "nonint_capture", "bad_bwa", "odd_args", "bad_arm_lengths"])
+                                  "nonint_capture", "bad_bwa", "odd_args", "bad_arm_lengths", "hex_float_score", "overflow_score", "hex_float_threshold",
+                                  "threshold_trailing_space", "hex_int"])
 def test_error_behaviour_matches_the_reference(name, tmp_path):
     """Malformed command lines and inputs (tools/error_probe.py; expectations in tests/golden/error_cases.json = what the REAL reference did): the exit
     status, the last lines of stderr and the files written are the reference's - `throw <int>` paths exit with 1 and a circumstance number
     (mipgen.cpp:2029-2032); a std::exception (boost::lexical_cast on a bad integer, vector::at on a BED line of two fields, std::string(NULL) for an
     option without its value) prints "unable to tile sequences" + the exception text and exits with 0 (:2033-2036, main() falls off its end); a BED
-    without intervals and -min_capture_size above -max_capture_size complete with header-only files.  None of these needs the device."""
+    without intervals and -min_capture_size above -max_capture_size complete with header-only files.  Real-valued options follow the reference's
+    boost::lexical_cast<double> (no hex floats, overflow refused); a malformed -masked_arm_threshold is only met at the first design_mip (:626): the
+    four output files exist by then and stay empty.  None of these needs the device."""
     ep, want = _error_cases()
     work = str(tmp_path / "w")
     base = ep.lay_out(work)

@@ -42,6 +42,15 @@ def cases(base):
         "capture_below_arms": base + ["-regions_to_scan", "ok.bed", "-min_capture_size", "40", "-max_capture_size", "44"],
         "no_snp_file": base + ok + ["-snp_file", "nope.vcf.gz", "-tabix", os.path.join(ROOT, "oracle", "faketabix.sh")],
         "no_params_file": base + ok + ["-file_of_parameters", "nope.txt"],
+        # real-valued options through boost::lexical_cast<double>: no hex floats, overflow refused, underflow / inf / a leading '+' taken; the masked-arm
+        # threshold is only cast at the first design_mip (mipgen.cpp:626): the output files exist by then and stay empty
+        "hex_float_score": base + ok + ["-logistic_optimal_score", "0x1p-1"],
+        "overflow_score": base + ok + ["-logistic_priority_score", "1e400"],
+        "hex_float_threshold": base + ok + ["-masked_arm_threshold", "0x1p-1"],
+        "threshold_trailing_space": base + ok + ["-masked_arm_threshold", "0.5 "],
+        "denormal_threshold": base + ok + ["-masked_arm_threshold", "1e-320"],
+        "inf_plus_scores": base + ok + ["-logistic_optimal_score", "INFINITY", "-logistic_priority_score", "+.5"],
+        "hex_int": base + ok + ["-max_mip_overlap", "0x10"],
     }
 
 
@@ -50,7 +59,7 @@ FILES = ("all_mips.txt", "collapsed_mips.txt", "picked_mips.txt", "snp_mips.txt"
 STORE = os.path.join(ROOT, "tests", "golden", "error_cases.json")      # committed: the reference's exit status, stderr tail, output line counts + hashes per case
 
 
-NEEDS_DEVICE = ("reversed_interval", "bad_tag", "no_snp_file")           # cases that reach tile_regions with candidates to score
+NEEDS_DEVICE = ("reversed_interval", "bad_tag", "no_snp_file", "denormal_threshold", "inf_plus_scores")           # cases that reach tile_regions with candidates to score
 
 
 def lay_out(work: str) -> list:
