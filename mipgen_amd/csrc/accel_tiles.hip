@@ -207,7 +207,8 @@ static int build_svr_tiles(mipgen_accel* h)             // k_svr_dense (+ the re
                     const int Cmax_t = Cmax - r.ki0 * D.inc, ssmax = Cmax_t - D.min_sum, ssr = (r.kc - 1) * D.inc + D.max_sum - D.min_sum + 1;
                     const double ent = (npt + (npt + ssr - 1)) * (h->geom.n_e + h->geom.n_l) / 2.0 + (double)npt * ssr;
                     const double cost = 19.0 * ent + 100.0 * (npt + ssmax + 2 * Lmax) + 75000.0;
-                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc, (int)lvl, 0}; st.push_back(t); st_cost.push_back(cost); st_few.push_back(few ? 1 : 0); }
+                    const int fits = mipgen_svr_scores_fit_lds(npt, r.kc, D.n_pairs, ssr, ssmax, Lmax, n_arm, h->geom.group, h->geom.n_e, h->geom.n_l, h->geom.nchunk * h->geom.wpc * 64);
+                    for (int s2 = 0; s2 < 2; s2++) { SvrTile t = {i, s2, p0, npt, r.ki0, r.kc, (int)lvl, fits}; st.push_back(t); st_cost.push_back(cost); st_few.push_back(few ? 1 : 0); }
                 }
             }
         }

@@ -105,7 +105,8 @@ struct SvrTile {
     int32_t strand;
     int32_t p0, np;        // positions (0-based within region)
     int32_t ki0, kc;       // capture sizes ki0 .. ki0+kc-1 (0-based within the region's surviving list)
-    int32_t level, pad;    // dense SVR tiles: which of the region's capture-size runs this is (0 = the largest sizes; kernels_skip.hip)
+    int32_t level, pad;    // dense SVR tiles: which of the region's capture-size runs this is (0 = the largest sizes; kernels_skip.hip); pad = the tile's
+                           // scores fit the LDS staging area of the kernel's epilogue (whole-row stores), as the host has checked
 };
 
 // static thread geometry of the dense SVR kernel for a parameter set (computed on the host once)

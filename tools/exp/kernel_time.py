@@ -6,8 +6,9 @@ lib_path = sys.argv[2] if len(sys.argv) > 2 else None
 if lib_path:
     capi.LIB_PATH = os.path.join(R, lib_path); capi._lib = capi.load_library(capi.LIB_PATH)
 cfg = sys.argv[1] if len(sys.argv) > 1 else "practice62"
-if cfg == "practice62":
+if cfg.startswith("practice62"):
     genome, ivs = workloads.practice62()
+    if ":" in cfg: ivs = ivs[:int(cfg.split(":")[1])]        # practice62:N = the first N regions, never cut along the SV list (traffic scans)
     P = capi.make_params(140, 180, score_method=capi.SCORE_SVR)
     acc = capi.Accel(P)
     acc.load_model_file(workloads.svr_model_path("gpurun_out/bench_cache", genome, 1024))
@@ -22,6 +23,7 @@ else:
         gr = acc.upload(workloads.build_exome(acc, chrom_len, all_iv[:4096], P))
         ivs = [iv for iv, g in zip(all_iv[:4096], gr) if g.n_sizes == int(cfg[6:])]
     regions = workloads.build_exome(acc, chrom_len, ivs, P)
+if ":" in cfg: acc.set_sv_split(1)
 grids = acc.upload(regions)
 print(cfg, "regions", len(regions), "candidates", sum(g.count for g in grids), file=sys.stderr)
 if len(sys.argv) > 3:                       # phase ablation of a -DMIPGEN_DIAG build: 1 no scan, 2 no tables, 4 no candidate steps (timing only)
