@@ -410,6 +410,8 @@ def cpu_baseline(args, model_path: str, n_sv: int) -> dict:
                    "single_core_value": A[shortest]["n"] / A[shortest]["hot"],
                    "single_core_value_end_to_end": A[shortest]["n"] / A[shortest]["seconds"],
                    "end_to_end_value": n_all / wall,
+                   "value_is": "the sum of the per-process rates (each process over its own tile_regions time)",
+                   "end_to_end_value_is": "all candidates / the wall time of the slowest process (input stages and the longest region included)",
                    "cpu_model": cpu_model, "host_threads_available": cores_avail, "physical_cores": phys,
                    "cgroup_cpu_quota": None if quota == float("inf") else quota,
                    "scope": "reference binary, tile_regions only (enumeration + scoring + selection; from its 'bwa copy number analysis finished' line to exit), "
@@ -774,10 +776,9 @@ def main() -> None:
         if traffic_run:
             roof["traffic_measured_in_this_run"] = True
             roof["traffic_detail"] = traffic_run
-            roof["traffic_note"] = ("k_svr_dense under --pmc carries a per-launch constant of ~0.16 GB in each direction that does not scale with the batch "
-                                    "(exome, 2.6e8 candidates: WRITE_SIZE 2.19 GB for 2.08 GB of scores = 1.05x; this batch: +0.16 GB on 0.12 GB) - the size of one "
-                                    "wave-context save / restore of the fully occupied chip (256 CUs x (16 x 128 VGPRs x 256 B + 146 KB LDS) = 0.17 GB), not "
-                                    "traffic of the algorithm; tools/exp/wr_probe*.sh, DESIGN.md section 5")
+            roof["traffic_note"] = ("WRITE_SIZE = the scores (1.05x: 456-byte rows, 64-byte granules); FETCH_SIZE x 2 = the records + the inputs (the model once per "
+                                    "XCD's L2 = 14 MB, ~80 KB per tile of copy-table slices / bases / model rows fetched again); round 5's 2.4x was the "
+                                    "lane-by-lane store path of the headline tile shape, not a profiler constant (tools/exp/traffic_abl.sh, ctx_probe.sh)")
         elif traffic_src:
             roof["traffic_from_profile"] = traffic_src
             roof["traffic_measured_in_this_run"] = False
