@@ -72,6 +72,7 @@ static const char* k_doc =
     "                         capture-window uniqueness (mapping flag) = no other locus within one substitution; both on the GPU, bwa is not run\n"
     "  -gpus n   (extension) device workers, 0 = every visible GPU        -gpu_timing on   (extension) stage timings on stderr\n"
     "  -gpu_gather pcie|rccl   (extension) result windows come down every GPU's own PCIe link (default), or travel to GPU 0 over RCCL / xGMI first\n"
+    "                          (rccl: experimental - run with one rank on hardware and with 2 / 4 ranks against a CPU stand-in of RCCL only; librccl is loaded on first use)\n"
     "limits of this build (the reference has none): arm lengths up to 64 bases, 256 arm-length pairs\n";
 
 static void set_defaults(Options& o)

@@ -23,7 +23,7 @@ def test_probe_design_matches_the_reference(name, tmp_path):
     h = zlib.crc32(name.encode())
     extra = []
     if h % 3 == 1:
-        extra += ["-gpus", "2", "-gpu_window_candidates", str(20000 + h % 50000)]
+        extra += ["-gpus", str(2 + h % 3), "-gpu_window_candidates", str(20000 + h % 50000)]     # 2-4 device workers: the regions dealt in blocks
     elif h % 3 == 2:
         extra += ["-gpu_window_candidates", str(5000 + h % 100000), "-gpu_gather", "rccl"]
     run_cli(meta, str(tmp_path), extra=extra)

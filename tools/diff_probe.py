@@ -4,7 +4,7 @@ their inputs + the reference's output files laid out like the committed goldens 
 box with the snapshot), where tests/test_gpu_probe.py runs the drop-in command line on every one of them - with random device-worker / result-window /
 gather settings - and compares the files byte for byte.  A way to look for differences the fixed goldens do not reach; what it finds becomes a golden.
 
-    python3 tools/diff_probe.py [N = 40] [seed = 1] [long|extreme]   # ~ N x 3 s of reference time; extreme = option values at the edges; long = logistic designs of up to ten regions of 0.3-3 kb
+    python3 tools/diff_probe.py [N = 40] [seed = 1] [long|extreme|hard]   # hard = on the hard genome (ambiguity codes, lower case, '-', homopolymers, microsatellites, GC 20 / 70 %); ~ N x 3 s of reference time; extreme = option values at the edges; long = logistic designs of up to ten regions of 0.3-3 kb
                                                              # (the selection stage at length), ~ N x 30 s
     gpurun -- 'MIPGEN_PROBE=1 python -m pytest tests/test_gpu_probe.py -q -n 6'
 """
@@ -24,7 +24,7 @@ from mipgen_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden_probe")
 
 
-def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False, extreme: bool = False) -> dict:
+def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False, extreme: bool = False, hard: bool = False) -> dict:
     method = "logistic" if long_regions else str(rng.choice(["logistic", "logistic", "svr", "mixed"]))
     inc = int(rng.choice([1, 2, 3, 5, 5, 5, 10]))
     lo = int(rng.integers(100, 200))
@@ -56,8 +56,8 @@ def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: b
     n_iv = int(rng.integers(1, 11 if long_regions else 7))
     ivs = []
     bed_lines = []
-    chroms = ["2", "10", "X"] if multi else ["1"]
-    glen = 40000 if multi else 80000
+    chroms = ["2", "10", "X"] if multi else (["4"] if hard else ["1"])
+    glen = 40000 if multi else (36000 if hard else 80000)      # hard: the zones of synth.hard_genome end at 34,000
     used = 0
     for j in range(n_iv):
         room = (budget - used) // per_base - hi
@@ -131,6 +131,8 @@ def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: b
         d["bed_text"] = "\n".join(bed_lines) + "\n"
     else:
         d["ivs"] = ivs
+    if hard:
+        d["chrom"] = "4"
     if d["snps"] and rng.random() < 0.5:
         # VCF records beyond biallelic SNVs: insertions (ALT longer than REF), several ALT alleles, a position listed twice, a `chr` prefix on the
         # chromosome column (parse_vcf keys its table by that column as it stands, mipgen.cpp:945-947)
@@ -163,17 +165,22 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     genome2 = synth.random_genome(80000, 202, n_run_frac=0.002, n_run_len=8)                     # = tests/golden/genome2_chr1.fa.gz
     multi = {c: synth.random_genome(nb, sd, n_run_frac=0.002, n_run_len=7) for c, nb, sd in mg.MULTI_CHROMS}   # = genome3_chr*.fa.gz
+    hard = len(sys.argv) > 3 and sys.argv[3] == "hard"
+    genome4 = synth.hard_genome()                                                                # = tests/golden/genome4_chr4.fa.gz
     rng = np.random.default_rng(seed)
     t0 = time.time()
     made = 0
     for k in range(n):
-        is_multi = bool(rng.random() < 0.4)
+        is_multi = bool(rng.random() < 0.4) and not hard
         d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and sys.argv[3] == "long",
-                          extreme=len(sys.argv) > 3 and sys.argv[3] == "extreme")
+                          extreme=len(sys.argv) > 3 and sys.argv[3] == "extreme", hard=hard)
         if not (d.get("ivs") or d.get("bed_text", "").strip()):
             continue
         try:
-            mg.gen_design(multi if is_multi else genome2, d, "genome3" if is_multi else "genome2_chr1.fa.gz", out_root=OUT)
+            if hard:
+                mg.gen_design(genome4, d, "genome4_chr4.fa.gz", out_root=OUT)
+            else:
+                mg.gen_design(multi if is_multi else genome2, d, "genome3" if is_multi else "genome2_chr1.fa.gz", out_root=OUT)
             made += 1
         except (AssertionError, FileNotFoundError) as ex:  # the reference itself refuses the parameter set or ends without its files (a std::exception: exit
             # status 0, mipgen.cpp:2033-2036) - error behaviour is tools/error_probe.py's subject, not probed here
