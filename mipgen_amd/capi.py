@@ -300,6 +300,7 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_last_kernel_ms.restype = C.c_double
     lib.mipgen_accel_set_timing.argtypes = [vp, C.c_int32]
     lib.mipgen_accel_set_window_candidates.argtypes = [vp, C.c_int64]
+    lib.mipgen_accel_set_window_breaks.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
     lib.mipgen_accel_window_count.argtypes = [vp]
     lib.mipgen_accel_window_count.restype = C.c_int32
     i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
@@ -435,6 +436,11 @@ class Accel:
     # result windows (batches whose dense results exceed the result arrays)
     def set_window_candidates(self, max_candidates: int) -> None:
         self._check(self.lib.mipgen_accel_set_window_candidates(self.h, max_candidates))
+
+    def set_window_breaks(self, first_regions: Sequence[int]) -> None:
+        """Batch indices at which a result window of the following uploads must start whatever the candidate bound says (ABI 5)."""
+        arr = (C.c_int32 * max(len(first_regions), 1))(*first_regions)
+        self._check(self.lib.mipgen_accel_set_window_breaks(self.h, arr, len(first_regions)))
 
     def window_count(self) -> int:
         return int(self.lib.mipgen_accel_window_count(self.h))

@@ -150,6 +150,8 @@ void mipgen_accel_destroy(mipgen_accel* h)
     h->region_pos0.release(); h->region_base0.release(); h->col_tiles.release(); h->collapsed.release();
     h->cand_in.release(); h->cand_scores.release(); h->cand_feats.release(); h->cand_records.release(); h->cand_ints.release();
     h->win_img.release();
+    h->pb_cands.release(); h->pb_idx.release(); h->pb_scores.release(); h->pb_count.release(); h->surv_svr.release(); h->rs_keep.release(); h->rs_offs.release(); h->rs_idx.release();
+    h->sat_idx.release(); h->sat_count.release(); h->sat_cands.release(); h->sat_scores.release();
     h->svr_tiles_lvl.release(); h->svr_tiles_kept.release(); h->run_bounds.release(); h->run_pbs.release(); h->run_state.release(); h->run_keep.release();
     h->run_offs.release(); h->skip_count.release();
     h->lrc_seq.release(); h->lrc_out.release(); h->lrc_offs.release(); h->lrc_lens.release(); h->lrc_denoms.release(); h->partials.release();

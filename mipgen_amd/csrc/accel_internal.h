@@ -64,7 +64,9 @@ hipError_t mipgen_launch_replay_condense(hipStream_t, int n_regions, int total_p
                                          mipgen_survivor* survivors, unsigned long long* emitted_per_region);
 size_t mipgen_logistic_dense_lds_bytes(int np_all, int np, int ssr, int ssmax, int Lmax, int n_up, int n_dn);
 hipError_t mipgen_launch_logistic_dense(hipStream_t, int n_tiles, size_t lds_bytes, const DevParams*, const DevRegion*, const SvrTile*, const uint8_t*,
-                                        const int32_t*, const uint8_t*, const HostConsts*, double*, uint64_t*);
+                                        const int32_t*, const uint8_t*, const HostConsts*, double*, uint64_t*, int64_t* sat_idx, unsigned int* sat_count, unsigned int sat_cap);
+hipError_t mipgen_launch_index_candidates(hipStream_t, const DevParams*, const DevRegion*, int r0, int r1, const int64_t* idx, const unsigned int* count, unsigned int cap,
+                                          mipgen_candidate* out);
 struct FmtRegion { int32_t chr_off, chr_len, label_off, label_len, feature_start, feature_stop; int64_t rb0; };
 struct FmtConst { char middle[96]; int32_t middle_len; int32_t n_regions; int64_t first_index; };
 hipError_t mipgen_launch_fmt_count(hipStream_t, int64_t n_rb, int r0, const FmtConst*, const FmtRegion*, const DevParams*, const DevRegion*, const uint8_t* emitted, int64_t* cnt);
@@ -267,6 +269,12 @@ struct mipgen_accel {
     DevBuf<int64_t> pb_idx;
     DevBuf<double> pb_scores;
     DevBuf<unsigned int> pb_count;
+    // logistic candidates whose b^x lies in [2^53, 2^54) - their score turns on the last bit of the reference's pow (kernels_logistic_dense.hip) - listed by the
+    // dense kernel and re-scored in the reference's term order with the correctly rounded power before anything is replayed (rescore_saturated)
+    DevBuf<int64_t> sat_idx;
+    DevBuf<unsigned int> sat_count;
+    DevBuf<mipgen_candidate> sat_cands;
+    DevBuf<double> sat_scores;
     // flag image of the last mipgen_accel_window_uniqueness_begin: uint8 [win_sizes][win_total], region r at column win_roff[r]
     DevBuf<uint8_t> win_img;
     std::vector<int64_t> win_roff;

@@ -87,14 +87,28 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
     hipEvent_t* ev = nullptr;
     if (h->timing) { if (mipgen_ensure_events(h)) return MIPGEN_E_HIP; ev = &h->ev[4 * (size_t)w]; }
     if (ev) HIP_TRY(hipEventRecord(ev[0], h->stream));
-    if (method == MIPGEN_SCORE_LOGISTIC && h->ld_lds > 0)
-        // records + logistic scores from per-window tables (kernels_logistic_dense.hip)
+    unsigned int sat_cap = 0;
+    if (method == MIPGEN_SCORE_LOGISTIC && h->ld_lds > 0) {
+        // records + logistic scores from per-window tables (kernels_logistic_dense.hip); the kernel lists the candidates whose score turns on the last
+        // bit of the reference's pow (b^x in [2^53, 2^54): GC-rich microsatellites get there, nothing else)
+        sat_cap = (unsigned int)std::min<int64_t>(W.n_cand / 256 + 4096, (int64_t)1 << 22);
+        if (h->sat_idx.reserve(sat_cap) || h->sat_count.reserve(1) || h->sat_cands.reserve(sat_cap) || h->sat_scores.reserve(sat_cap)) return MIPGEN_E_NOMEM;
+        HIP_TRY(hipMemsetAsync(h->sat_count.p, 0, sizeof(unsigned int), h->stream));
         HIP_TRY(mipgen_launch_logistic_dense(h->stream, W.n_ld_tiles, h->ld_lds, h->dp, h->regions.p, h->ld_tiles.p + W.ld_tile0, h->bases.p, h->copy.p,
-                                             h->unmap.p, h->dconsts, h->scores.p, h->records.p));
-    else
+                                             h->unmap.p, h->dconsts, h->scores.p, h->records.p, h->sat_idx.p, h->sat_count.p, sat_cap));
+    } else
         HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
                                                h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
     if (ev) HIP_TRY(hipEventRecord(ev[1], h->stream));
+    if (sat_cap) {
+        // the listed candidates in the reference's own term order with the correctly rounded power (k_candidates: logistic_exponent_exact, pow_base_cr) - before
+        // the replay, the condense fold and the collapse compare anything.  (A list that overflows leaves its surplus with the dense kernel's value: there is no
+        // guarantee to break - the reference's own double is a coin there - and no region short of a megabase of (CCG)n fills it.)
+        HIP_TRY(mipgen_launch_index_candidates(h->stream, h->dp, h->regions.p, W.r0, W.r1, h->sat_idx.p, h->sat_count.p, sat_cap, h->sat_cands.p));
+        HIP_TRY(mipgen_launch_candidates(h->stream, (int)sat_cap, h->dp, h->regions.p, h->sat_cands.p, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->model.p, h->n_sv,
+                                         h->gamma, h->rho, MIPGEN_SCORE_LOGISTIC, h->sat_scores.p, nullptr, nullptr, nullptr, 1, h->sat_count.p));
+        HIP_TRY(mipgen_launch_scatter_scores(h->stream, h->sat_scores.p, h->sat_idx.p, (int)sat_cap, h->sat_count.p, h->scores.p, nullptr));
+    }
     // logistic scores that sit on a rounding midpoint of the six printed digits: re-scored in the reference's term order (dense windows of non-silent
     // designs; the silent path tests its survivors only)
     if (method == MIPGEN_SCORE_LOGISTIC && fix_dense) { if (int rc = fix_print_boundaries(h, W.r0, W.r1, nullptr, h->scores.p, h->records.p, W.n_cand, MIPGEN_SCORE_LOGISTIC)) return rc; }

@@ -72,7 +72,8 @@ __device__ const double EXP2_TAB[256] = EXP2_TAB_VALUES;
 __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
     const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, const SvrTile* __restrict__ tiles, int n_tiles,
     const uint8_t* __restrict__ bases, const int32_t* __restrict__ copy, const uint8_t* __restrict__ unmap,
-    const HostConsts* __restrict__ HC, double* __restrict__ scores, uint64_t* __restrict__ records
+    const HostConsts* __restrict__ HC, double* __restrict__ scores, uint64_t* __restrict__ records,
+    int64_t* __restrict__ sat_idx, unsigned int* __restrict__ sat_count, unsigned int sat_cap
 #ifdef MIPGEN_DIAG
     , unsigned long long* __restrict__ prof
 #endif
@@ -360,6 +361,19 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
                 if (special & (LD_COPY0 << 16)) score = __longlong_as_double(0xFFF8000000000000LL);
                 if (special & (MIPGEN_FLAG_GUARD << 16)) score = -1000.0;
             }
+            // Saturated scores (b^x >= 2^20: score within 1e-6 of 1 - GC-rich microsatellites get there): the candidates of a position pile up on the
+            // last few hundred doubles below 1.0, where the reference's comparisons (collapse / condense: strictly greater; :494: (int)score is 1 only for
+            // exactly 1.0) turn on the LAST bit.  There 1 + y is exact and y / (1 + y) moves by delta^2 * dy - nothing - with the 1e-13 this kernel's y
+            // is off the reference's, so the correctly rounded IEEE quotient IS the reference's double (tests/golden: design_hard_saturated_*; found by
+            // the probe on the hard genome: 16 of 3,540 such scores were an ulp off with the reciprocal route, 6 of 3,313 exact ones not exactly 1.0).
+            if (__builtin_expect(__ballot(ti >= (20 << 8)) != 0, 0)) {
+                if (ti >= (20 << 8) && !odd && special == 0) score = y / d;
+                // ... except where b^x reaches [2^53, 2^54): there 1 + y is a tie the reference rounds to even on the LAST bit of its pow, and its score -
+                // 1.0, or one / two ulps below - is a coin this kernel's y (1e-13 off) cannot call.  Those candidates are listed and re-scored in the
+                // reference's term order with the correctly rounded power (accel_score.hip: rescore_saturated; pow_base_cr.h) before anything is replayed.
+                const bool coin = valid && special == 0 && !odd && ti >= 53 * 256 - 1 && ti <= 54 * 256;
+                if (__ballot(coin) && coin && sat_count) { const unsigned int at = atomicAdd(sat_count, 1u); if (at < sat_cap) sat_idx[at] = out_row + a; }
+            }
             if (__builtin_expect(__ballot(have && !valid) != 0, 0)) { if (!valid) { rec = 0; score = 0.0; } }
             if (have) { *(uint64_t*)(rrow + a8) = rec; *(double*)(srow + a8) = score; }
             kci += NW;
@@ -387,16 +401,16 @@ extern "C" int mipgen_logistic_debug_dump(unsigned long long* host, int n)
 
 extern "C" hipError_t mipgen_launch_logistic_dense(hipStream_t stream, int n_tiles, size_t lds_bytes, const DevParams* P, const DevRegion* regions,
                                                    const SvrTile* tiles, const uint8_t* bases, const int32_t* copy, const uint8_t* unmap,
-                                                   const HostConsts* HC, double* scores, uint64_t* records)
+                                                   const HostConsts* HC, double* scores, uint64_t* records, int64_t* sat_idx, unsigned int* sat_count, unsigned int sat_cap)
 {
     if (n_tiles <= 0) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)k_logistic_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
 #ifdef MIPGEN_DIAG
     if (!g_ld_prof && hipMalloc((void**)&g_ld_prof, 512 * 8 * 5 * sizeof(unsigned long long)) != hipSuccess) g_ld_prof = nullptr;
-    hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records, g_ld_prof);
+    hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records, sat_idx, sat_count, sat_cap, g_ld_prof);
 #else
-    hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records);
+    hipLaunchKernelGGL(k_logistic_dense, dim3(n_tiles), dim3(LD_THREADS), lds_bytes, stream, P, regions, tiles, n_tiles, bases, copy, unmap, HC, scores, records, sat_idx, sat_count, sat_cap);
 #endif
     return hipGetLastError();
 }

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "device_utils.h"
 #include "logistic_device.h"
+#include "pow_base_cr.h"
 
 #define CAND_THREADS 256
 #define MAX_INSERT 1024
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidates(
                 x.v[MLV_JS] = jc < 16 ? c_junction_scores[jc] : 0.0;
                 x.v[MLV_LEC] = log_copy_dev(HC, ext_copy); x.v[MLV_LLC] = log_copy_dev(HC, lig_copy);
                 const double ex = logistic_exponent_exact(x);                     // every operation rounded on its own, as the reference's
-                const double y = pow(MIPGEN_LOGISTIC_BASE, ex);                 // SVMipv4.cpp:247
+                // SVMipv4.cpp:247: pow(2.71828, ex), correctly rounded (pow_base_cr.h: glibc's own double in 99.9 % of cases; the device math library's pow in 91 %)
+                const double y = fabs(ex) < 700.0 ? pow_base_cr(ex) : pow(MIPGEN_LOGISTIC_BASE, ex);
                 logistic = y / (1.0 + y);
             }
             if (scores) scores[blockIdx.x] = logistic;
@@ -597,6 +599,34 @@ __global__ __launch_bounds__(256) void k_print_boundary_scan(const DevParams* __
             out[at] = c; out_idx[at] = idx;
         }
     }
+}
+
+// dense indices of a window -> candidates (the decode of k_print_boundary_scan for a ready-made index list: the saturated logistic candidates the dense kernel listed)
+__global__ __launch_bounds__(256) void k_index_candidates(const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, int r0, int r1, const int64_t* __restrict__ idx_list,
+                                                          const unsigned int* __restrict__ count, unsigned int cap, mipgen_candidate* __restrict__ out)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || i >= *count) return;
+    const int64_t idx = idx_list[i];
+    const int A = P->n_pairs;
+    int lo = r0, hi = r1 - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (regions[mid].out_off <= idx) lo = mid; else hi = mid - 1; }
+    const DevRegion& R = regions[lo];
+    const int64_t local = idx - R.out_off;
+    const int a_i = (int)(local % A);
+    const int64_t row = local / A;
+    const int64_t rest = row >> 1;
+    mipgen_candidate c;
+    c.region = lo; c.scan_start = R.first_pos + (int)(rest / R.n_sizes); c.capture_size = P->max_capture - (R.k0 + (int)(rest % R.n_sizes)) * P->inc;
+    c.ext_len = P->arm_ext[a_i]; c.lig_len = P->arm_lig[a_i]; c.strand = (int)(row & 1);
+    out[i] = c;
+}
+extern "C" hipError_t mipgen_launch_index_candidates(hipStream_t stream, const DevParams* P, const DevRegion* regions, int r0, int r1, const int64_t* idx, const unsigned int* count,
+                                                     unsigned int cap, mipgen_candidate* out)
+{
+    if (cap == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_index_candidates, dim3((cap + 255) / 256), dim3(256), 0, stream, P, regions, r0, r1, idx, count, cap, out);
+    return hipGetLastError();
 }
 
 // `over` (host-mapped word, may be null): set when the scan listed more entries than the list holds - the surplus was not re-scored, the caller reports it

@@ -381,6 +381,15 @@ DESIGNS4 = [
               ("4", _Z["gc20"][0] + 1200, _Z["gc20"][0] + 1500, "gc20"), ("4", _Z["gc70"][0] + 1500, _Z["gc70"][0] + 1800, "gc70")],
          minC=152, maxC=162, sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=False, trf=False, bwa="hashed", model="svr_syn_200.model",
          extra=["-silent_mode", "on"]),
+    # SATURATED logistic scores (found by tools/diff_probe.py ... hard, designs 21076 and 21139): inside a (CCG)n run the exponent reaches 36.7-37.4, b^x
+    # lies in [2^53, 2^54), and the reference's score - exactly 1.0, or one / two ulps below - turns on the LAST bit of its pow (1 + y is a tie rounded
+    # to even); collapse / condense compare those doubles with a strict >.  The accelerator re-scores exactly those candidates in the reference's term
+    # order with a correctly rounded power (mipgen_amd/csrc/pow_base_cr.h) before anything is replayed.
+    dict(name="hard_saturated_logistic", method="logistic", chrom="4", ivs=[("4", 18743, 18893, "r0")], minC=160, maxC=180, sums=[40, 42, 45, 46], flank=3,
+         tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-seal_both_strands", "on"]),
+    dict(name="hard_saturated_mixed", method="mixed", chrom="4", ivs=[("4", 18656, 18658, "r0")], minC=123, maxC=173, sums=[41, 43, 46], flank=3, tags="5,0",
+         snps=False, trf=False, bwa="blocks", model="svr_syn_64.model",
+         extra=["-double_tile_strand_unaware", "on", "-masked_arm_threshold", "0.1", "-target_arm_copy", "50", "-max_arm_copy_product", "400", "-lig_min_length", "18"]),
 ]
 
 

@@ -454,6 +454,23 @@ def test_result_windows(genome):
     for f in ("cand_index", "record"):
         assert np.array_equal(v3[f], v1[f]), f
     assert np.array_equal(v3["score"], v1["score"], equal_nan=True)
+    # forced window starts (ABI 5: the multi-device front end deals region blocks, a window never spans two): with room for everything in one window
+    # the batch is cut exactly at the breaks; with one region per window the breaks change nothing; the results are the unbroken batch's
+    if len(regions) >= 3:
+        acc.set_window_candidates(0)
+        acc.set_window_breaks([1, len(regions) - 1])
+        grids4, s4, r4 = acc.score_regions(regions, capi.SCORE_LOGISTIC)
+        assert acc.window_count() == (3 if len(regions) > 2 else 2)
+        assert [acc.window_info(w)["first_region"] for w in range(acc.window_count())] == [0, 1, len(regions) - 1]
+        assert np.array_equal(s1, s4, equal_nan=True) and np.array_equal(r1, r4)
+        acc.score_condense_all(capi.SCORE_LOGISTIC)
+        e4, v4 = acc.download_survivors()
+        assert np.array_equal(e4, e1) and np.array_equal(v4["cand_index"], v1["cand_index"])
+        with pytest.raises(capi.AccelError):
+            acc.set_window_breaks([2, 1])                                          # not ascending
+        acc.set_window_breaks([])
+        acc.upload(regions)
+        assert acc.window_count() == 1
     acc.close()
 
 

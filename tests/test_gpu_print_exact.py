@@ -114,3 +114,37 @@ def test_logistic_scores_near_a_print_midpoint_are_rescored_in_the_reference_ord
         n_exact += s_on[idx] == ref
     assert n_exact > 0
     acc.close()
+
+
+def test_saturated_logistic_scores_are_the_references_doubles():
+    """Inside a (CCG)n run the logistic exponent reaches 36.7-37.4: b^x lies in [2^53, 2^54), 1 + y is a tie the reference rounds to even on the LAST
+    bit of its pow, and its score - exactly 1.0, or one / two ulps below - decides the strict comparisons of collapse / condense and the (int)
+    truncations of mipgen.cpp:494-497 (found by the differential probe on the hard genome; goldens design_hard_saturated_*).  The dense kernel takes the
+    correctly rounded quotient from 2^20 on (1 + y is exact below 2^53: its 1e-13 on y moves nothing) and lists the candidates of the tie binade, which are
+    re-scored in the reference's term order with a correctly rounded power before anything is replayed: every score of the band is the reference's double."""
+    from tests import helpers as H
+    meta = H.load_design("hard_saturated_logistic")
+    P = H.design_params(meta)
+    genome = H.golden_genome("genome4_chr4.fa.gz").upper()
+    regions = H.design_regions(meta, genome, P)
+    acc = capi.Accel(P)
+    grids, scores, records = acc.score_regions(regions, capi.SCORE_LOGISTIC)
+    g = grids[0]
+    _, o, _ = po.score_region_dense(P, regions[0], capi.SCORE_LOGISTIC, None)
+    s = np.asarray(scores[:g.count]); o = np.asarray(o)
+    band = np.isfinite(o) & (o >= 1.0 - 2.0 ** -20)
+    assert int(band.sum()) > 4000 and int((o == 1.0).sum()) > 3000                       # the region really saturates
+    tie = band & (o >= 1.0 - 3 * 2.0 ** -53) & (o < 1.0)                                  # one / two ulps below 1.0: only the tie binade produces these
+    assert int(tie.sum()) >= 10
+    bad = np.flatnonzero(band & (s.view(np.int64) != o.view(np.int64)))
+    assert bad.size == 0, (int(bad.size), [(int(k), float(o[k]), float(s[k])) for k in bad[:5]])
+    assert np.array_equal(s == 1.0, o == 1.0)
+    # the list route (mipgen_accel_score_candidates: k_candidates) on the tie binade alone
+    A = P.n_arm_pairs
+    cl = []
+    for k in np.flatnonzero(tie):
+        a = int(k % A); row = int(k // A); rest = row >> 1
+        cl.append((0, g.first_pos + rest // g.n_sizes, P.max_capture_size - (g.first_size_index + rest % g.n_sizes) * P.capture_increment, P.arm_ext[a], P.arm_lig[a], row & 1))
+    sl, _, _, _ = acc.score_candidates(cl, capi.SCORE_LOGISTIC)
+    assert np.array_equal(np.asarray(sl).view(np.int64), o[tie].view(np.int64))
+    acc.close()

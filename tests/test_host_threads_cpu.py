@@ -52,7 +52,7 @@ def _compare(meta, work):
                                           ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_mixed", 4), ("multichr_logistic_snps", 2),
                                           ("long_capture_logistic", 1), ("long_capture_svr", 2), ("empty_sum_lists", 2), ("no_arm_pairs", 1),
                                           ("both_arm_options", 2), ("wild_vcf_mixed", 2), ("edge_options", 1), ("edge_options_svr", 1),
-                                          ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2), ("hard_lowcomplexity_svr_silent", 4)])
+                                          ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2), ("hard_lowcomplexity_svr_silent", 4), ("hard_saturated_logistic", 2), ("hard_saturated_mixed", 2)])
 @pytest.mark.parametrize("gather", ["pcie", "rccl"])
 def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, workers, gather, tmp_path):
     """gather = rccl: the same designs through `-gpu_gather rccl` (mipgen_amd/host/gather.cpp) with TWO and FOUR communicator ranks - its RCCL / HIP
@@ -62,11 +62,12 @@ def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, 
         workers = 4 if workers in (1, 4) else 2
     if san == "address" and (name, workers) not in (("mixed_12_regions", 4), ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_logistic_snps", 2),
                                                     ("long_capture_logistic", 1), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2),
-                                                    ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2), ("hard_lowcomplexity_svr_silent", 4)):
-        pytest.skip("fourteen under ThreadSanitizer, twelve under AddressSanitizer + UBSan")
-    if san == "thread" and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent"):
+                                                    ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2), ("hard_lowcomplexity_svr_silent", 4),
+                                                    ("hard_saturated_logistic", 2), ("hard_saturated_mixed", 2)):
+        pytest.skip("sixteen under ThreadSanitizer, fourteen under AddressSanitizer + UBSan")
+    if san == "thread" and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent", "hard_saturated_logistic"):
         pytest.skip("the hard genome's large designs (a million records): AddressSanitizer; hard_mixed under both")
-    if gather == "rccl" and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent"):
+    if gather == "rccl" and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent", "hard_saturated_logistic"):
         pytest.skip("once is enough for the large hard designs")
     if san == "thread" and name == "edge_options":
         pytest.skip("190,000 records under ThreadSanitizer take a minute: AddressSanitizer only")
