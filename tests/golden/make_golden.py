@@ -387,6 +387,12 @@ DESIGNS4 = [
     # order with a correctly rounded power (mipgen_amd/csrc/pow_base_cr.h) before anything is replayed.
     dict(name="hard_saturated_logistic", method="logistic", chrom="4", ivs=[("4", 18743, 18893, "r0")], minC=160, maxC=180, sums=[40, 42, 45, 46], flank=3,
          tags="5,0", snps=True, trf=False, bwa="hashed", model=None, extra=["-seal_both_strands", "on"]),
+    # EXACT TIES: regions inside the (CA)65, (GGC)45 and (TG)68 runs with every copy number 1 - candidates shifted by the repeat's period have identical arms and
+    # inserts, so the reference scores them bit-identically and keeps the first (collapse / condense: strictly greater); the accelerator must tie them too
+    dict(name="hard_ties_svr", method="svr", chrom="4", ivs=[("4", 17900, 17930, "ca"), ("4", 18710, 18750, "ggc")], minC=120, maxC=130, sums=[40, 42, 44], flank=0,
+         tags="5,0", snps=False, trf=False, bwa="unique", model="svr_syn_200.model", extra=["-svr_optimal_score", "3.5"]),
+    dict(name="hard_ties_mixed", method="mixed", chrom="4", ivs=[("4", 19530, 19600, "tg")], minC=120, maxC=130, sums=[40, 41, 42], flank=0, tags="5,0", snps=False,
+         trf=False, bwa="unique", model="svr_syn_64.model", extra=[]),
     dict(name="hard_saturated_mixed", method="mixed", chrom="4", ivs=[("4", 18656, 18658, "r0")], minC=123, maxC=173, sums=[41, 43, 46], flank=3, tags="5,0",
          snps=False, trf=False, bwa="blocks", model="svr_syn_64.model",
          extra=["-double_tile_strand_unaware", "on", "-masked_arm_threshold", "0.1", "-target_arm_copy", "50", "-max_arm_copy_product", "400", "-lig_min_length", "18"]),
