@@ -26,7 +26,7 @@ extern "C" {
 size_t mipgen_logistic_lds_bytes(int span);
 hipError_t mipgen_launch_records_logistic(hipStream_t, int score, int n_tiles, int span_max, const DevParams*, const DevRegion*,
                                           const LogTile*, const uint8_t*, const int32_t*, const uint8_t*, const HostConsts*,
-                                          double*, uint64_t*);
+                                          double*, uint64_t*, int64_t* sat_idx, unsigned int* sat_count, unsigned int sat_cap);
 size_t mipgen_svr_lds_bytes_tile(int np, int kc_ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l, int n_threads);
 int mipgen_svr_scores_fit_lds(int np, int kc, int n_pairs, int ss_range, int ssmax, int Lmax, int n_arm, int group, int n_e, int n_l, int n_threads);
 hipError_t mipgen_launch_svr_dense(hipStream_t, int n_tiles, int n_tiles_few, size_t lds_bytes, const DevParams*, const SvrGeom*, const SvrGeom* geom_few,

@@ -88,17 +88,21 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
     if (h->timing) { if (mipgen_ensure_events(h)) return MIPGEN_E_HIP; ev = &h->ev[4 * (size_t)w]; }
     if (ev) HIP_TRY(hipEventRecord(ev[0], h->stream));
     unsigned int sat_cap = 0;
-    if (method == MIPGEN_SCORE_LOGISTIC && h->ld_lds > 0) {
-        // records + logistic scores from per-window tables (kernels_logistic_dense.hip); the kernel lists the candidates whose score turns on the last
-        // bit of the reference's pow (b^x in [2^53, 2^54): GC-rich microsatellites get there, nothing else)
+    if (method == MIPGEN_SCORE_LOGISTIC) {
+        // the logistic kernels list the candidates whose score turns on the last bit of the reference's pow (b^x in [2^53, 2^54): GC-rich
+        // microsatellites get there, nothing else)
         sat_cap = (unsigned int)std::min<int64_t>(W.n_cand / 256 + 4096, (int64_t)1 << 22);
         if (h->sat_idx.reserve(sat_cap) || h->sat_count.reserve(1) || h->sat_cands.reserve(sat_cap) || h->sat_scores.reserve(sat_cap)) return MIPGEN_E_NOMEM;
         HIP_TRY(hipMemsetAsync(h->sat_count.p, 0, sizeof(unsigned int), h->stream));
+    }
+    if (method == MIPGEN_SCORE_LOGISTIC && h->ld_lds > 0)
+        // records + logistic scores from per-window tables (kernels_logistic_dense.hip)
         HIP_TRY(mipgen_launch_logistic_dense(h->stream, W.n_ld_tiles, h->ld_lds, h->dp, h->regions.p, h->ld_tiles.p + W.ld_tile0, h->bases.p, h->copy.p,
                                              h->unmap.p, h->dconsts, h->scores.p, h->records.p, h->sat_idx.p, h->sat_count.p, sat_cap));
-    } else
+    else
         HIP_TRY(mipgen_launch_records_logistic(h->stream, method == MIPGEN_SCORE_LOGISTIC, W.n_log_tiles, h->log_span_max, h->dp, h->regions.p,
-                                               h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p));
+                                               h->log_tiles.p + W.log_tile0, h->bases.p, h->copy.p, h->unmap.p, h->dconsts, h->scores.p, h->records.p,
+                                               sat_cap ? h->sat_idx.p : nullptr, sat_cap ? h->sat_count.p : nullptr, sat_cap));
     if (ev) HIP_TRY(hipEventRecord(ev[1], h->stream));
     if (sat_cap) {
         // the listed candidates in the reference's own term order with the correctly rounded power (k_candidates: logistic_exponent_exact, pow_base_cr) - before

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
     const DevParams* __restrict__ P, const DevRegion* __restrict__ regions, const LogTile* __restrict__ tiles,
     int n_tiles, const uint8_t* __restrict__ bases, const int32_t* __restrict__ copy,
     const uint8_t* __restrict__ unmap, const HostConsts* __restrict__ HC, double* __restrict__ scores,
-    uint64_t* __restrict__ records)
+    uint64_t* __restrict__ records, int64_t* __restrict__ sat_idx, unsigned int* __restrict__ sat_count, unsigned int sat_cap)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LogTile tile = tiles[xcd_remap(blockIdx.x, n_tiles)];
@@ -182,7 +182,12 @@ __global__ __launch_bounds__(LOG_THREADS) void k_records_logistic(
                     x.v[MLV_JS] = jc < 16 ? c_junction_scores[jc] : 0.0;
                     x.v[MLV_LEC] = log_copy_dev(HC, ext_copy);
                     x.v[MLV_LLC] = log_copy_dev(HC, lig_copy);
-                    score = logistic_from_exponent_fast(HC, logistic_exponent(x));
+                    const double ex = logistic_exponent(x);
+                    score = logistic_from_exponent_fast(HC, ex);
+                    // b^x in [2^53, 2^54): the reference's score turns on the last bit of its pow there (kernels_logistic_dense.hip): listed for the
+                    // re-score in the reference's term order with the correctly rounded power (accel_score.hip)
+                    const double tb = ex * (HC->ln_base * 1.4426950408889634074);
+                    if (SCORE && sat_count && tb >= 52.99 && tb <= 54.01) { const unsigned int at = atomicAdd(sat_count, 1u); if (at < sat_cap) sat_idx[at] = out_base + idx; }
                 }
             }
         }
@@ -199,15 +204,15 @@ extern "C" size_t mipgen_logistic_lds_bytes(int span)
 extern "C" hipError_t mipgen_launch_records_logistic(
     hipStream_t stream, int score, int n_tiles, int span_max, const DevParams* P, const DevRegion* regions,
     const LogTile* tiles, const uint8_t* bases, const int32_t* copy, const uint8_t* unmap, const HostConsts* HC, double* scores,
-    uint64_t* records)
+    uint64_t* records, int64_t* sat_idx, unsigned int* sat_count, unsigned int sat_cap)
 {
     if (n_tiles <= 0) return hipSuccess;
     size_t lds = mipgen_logistic_lds_bytes(span_max);
     if (score)
         hipLaunchKernelGGL(k_records_logistic<true>, dim3(n_tiles), dim3(LOG_THREADS), lds, stream, P, regions, tiles, n_tiles,
-                           bases, copy, unmap, HC, scores, records);
+                           bases, copy, unmap, HC, scores, records, sat_idx, sat_count, sat_cap);
     else
         hipLaunchKernelGGL(k_records_logistic<false>, dim3(n_tiles), dim3(LOG_THREADS), lds, stream, P, regions, tiles, n_tiles,
-                           bases, copy, unmap, HC, scores, records);
+                           bases, copy, unmap, HC, scores, records, (int64_t*)nullptr, (unsigned int*)nullptr, 0u);
     return hipGetLastError();
 }

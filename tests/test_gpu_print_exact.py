@@ -116,7 +116,8 @@ def test_logistic_scores_near_a_print_midpoint_are_rescored_in_the_reference_ord
     acc.close()
 
 
-def test_saturated_logistic_scores_are_the_references_doubles():
+@pytest.mark.parametrize("route", ["dense", "fallback"])
+def test_saturated_logistic_scores_are_the_references_doubles(route):
     """Inside a (CCG)n run the logistic exponent reaches 36.7-37.4: b^x lies in [2^53, 2^54), 1 + y is a tie the reference rounds to even on the LAST
     bit of its pow, and its score - exactly 1.0, or one / two ulps below - decides the strict comparisons of collapse / condense and the (int)
     truncations of mipgen.cpp:494-497 (found by the differential probe on the hard genome; goldens design_hard_saturated_*).  The dense kernel takes the
@@ -125,17 +126,21 @@ def test_saturated_logistic_scores_are_the_references_doubles():
     from tests import helpers as H
     meta = H.load_design("hard_saturated_logistic")
     P = H.design_params(meta)
+    if route == "fallback":
+        # capture sizes 50 apart: the window tables of k_logistic_dense do not fit its LDS budget, k_records_logistic<true> scores the batch (and lists
+        # the tie binade just the same)
+        P = capi.make_params(120, 270, capture_increment=50, arm_pairs=synth.arm_pairs_from_sums(meta["sums"]))
     genome = H.golden_genome("genome4_chr4.fa.gz").upper()
-    regions = H.design_regions(meta, genome, P)
+    regions = H.design_regions(dict(meta, minC=P.min_capture_size), genome, P)
     acc = capi.Accel(P)
     grids, scores, records = acc.score_regions(regions, capi.SCORE_LOGISTIC)
     g = grids[0]
     _, o, _ = po.score_region_dense(P, regions[0], capi.SCORE_LOGISTIC, None)
     s = np.asarray(scores[:g.count]); o = np.asarray(o)
     band = np.isfinite(o) & (o >= 1.0 - 2.0 ** -20)
-    assert int(band.sum()) > 4000 and int((o == 1.0).sum()) > 3000                       # the region really saturates
+    assert int(band.sum()) > (4000 if route == "dense" else 500) and int((o == 1.0).sum()) > (3000 if route == "dense" else 100)   # the region really saturates
     tie = band & (o >= 1.0 - 3 * 2.0 ** -53) & (o < 1.0)                                  # one / two ulps below 1.0: only the tie binade produces these
-    assert int(tie.sum()) >= 10
+    assert int(tie.sum()) >= (10 if route == "dense" else 1)
     bad = np.flatnonzero(band & (s.view(np.int64) != o.view(np.int64)))
     assert bad.size == 0, (int(bad.size), [(int(k), float(o[k]), float(s[k])) for k in bad[:5]])
     assert np.array_equal(s == 1.0, o == 1.0)

@@ -165,15 +165,15 @@ def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     genome2 = synth.random_genome(80000, 202, n_run_frac=0.002, n_run_len=8)                     # = tests/golden/genome2_chr1.fa.gz
     multi = {c: synth.random_genome(nb, sd, n_run_frac=0.002, n_run_len=7) for c, nb, sd in mg.MULTI_CHROMS}   # = genome3_chr*.fa.gz
-    hard = len(sys.argv) > 3 and sys.argv[3] == "hard"
+    hard = len(sys.argv) > 3 and "hard" in sys.argv[3]                                           # (combinable: hardlong, hardextreme)
     genome4 = synth.hard_genome()                                                                # = tests/golden/genome4_chr4.fa.gz
     rng = np.random.default_rng(seed)
     t0 = time.time()
     made = 0
     for k in range(n):
         is_multi = bool(rng.random() < 0.4) and not hard
-        d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and sys.argv[3] == "long",
-                          extreme=len(sys.argv) > 3 and sys.argv[3] == "extreme", hard=hard)
+        d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and "long" in sys.argv[3],
+                          extreme=len(sys.argv) > 3 and "extreme" in sys.argv[3], hard=hard)
         if not (d.get("ivs") or d.get("bed_text", "").strip()):
             continue
         try:
