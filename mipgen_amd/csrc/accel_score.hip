@@ -91,7 +91,7 @@ static int score_window_impl(mipgen_accel* h, int w, int32_t method, bool fix_de
     if (method == MIPGEN_SCORE_LOGISTIC) {
         // the logistic kernels list the candidates whose score turns on the last bit of the reference's pow (b^x in [2^53, 2^54): GC-rich
         // microsatellites get there, nothing else)
-        sat_cap = (unsigned int)std::min<int64_t>(W.n_cand / 256 + 4096, (int64_t)1 << 22);
+        sat_cap = (unsigned int)std::min<int64_t>(W.n_cand / 4096 + 4096, (int64_t)1 << 20);      // (0.014 % of a (CCG)n region's candidates sit in the tie binade; the re-score grid is the capacity)
         if (h->sat_idx.reserve(sat_cap) || h->sat_count.reserve(1) || h->sat_cands.reserve(sat_cap) || h->sat_scores.reserve(sat_cap)) return MIPGEN_E_NOMEM;
         HIP_TRY(hipMemsetAsync(h->sat_count.p, 0, sizeof(unsigned int), h->stream));
     }
