@@ -366,6 +366,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
             // exactly 1.0) turn on the LAST bit.  There 1 + y is exact and y / (1 + y) moves by delta^2 * dy - nothing - with the 1e-13 this kernel's y
             // is off the reference's, so the correctly rounded IEEE quotient IS the reference's double (tests/golden: design_hard_saturated_*; found by
             // the probe on the hard genome: 16 of 3,540 such scores were an ulp off with the reciprocal route, 6 of 3,313 exact ones not exactly 1.0).
+#ifndef LD_NO_BAND                                                      // (A/B timing of the branch: tools/exp/scratch builds only)
             if (__builtin_expect(__ballot(ti >= (20 << 8)) != 0, 0)) {
                 if (ti >= (20 << 8) && !odd && special == 0) score = y / d;
                 // ... except where b^x reaches [2^53, 2^54): there 1 + y is a tie the reference rounds to even on the LAST bit of its pow, and its score -
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(LD_THREADS, 2) void k_logistic_dense(
                 const bool coin = valid && special == 0 && !odd && ti >= 53 * 256 - 1 && ti <= 54 * 256;
                 if (__ballot(coin) && coin && sat_count) { const unsigned int at = atomicAdd(sat_count, 1u); if (at < sat_cap) sat_idx[at] = out_row + a; }
             }
+#endif
             if (__builtin_expect(__ballot(have && !valid) != 0, 0)) { if (!valid) { rec = 0; score = 0.0; } }
             if (have) { *(uint64_t*)(rrow + a8) = rec; *(double*)(srow + a8) = score; }
             kci += NW;
