@@ -61,18 +61,19 @@ def test_threaded_driver_under_sanitizers_writes_the_reference_files(san, name, 
     if gather == "rccl":
         workers = 4 if workers in (1, 4) else 2
     if san == "address" and (name, workers) not in (("mixed_12_regions", 4), ("merge_flank_tags", 2), ("svr_small", 1), ("multichr_logistic_snps", 2),
-                                                    ("long_capture_logistic", 1), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2),
+                                                    ("long_capture_logistic", 1), ("long_capture_svr", 2), ("no_arm_pairs", 1), ("edge_options", 1), ("wild_vcf_mixed", 2),
                                                     ("hard_mixed", 2), ("hard_logistic", 4), ("hard_svr", 2), ("hard_lowcomplexity_svr_silent", 4),
                                                     ("hard_saturated_logistic", 2), ("hard_saturated_mixed", 2)):
         pytest.skip("sixteen under ThreadSanitizer, fourteen under AddressSanitizer + UBSan")
     if san == "thread" and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent", "hard_saturated_logistic"):
         pytest.skip("the hard genome's large designs (a million records): AddressSanitizer; hard_mixed under both")
-    if gather == "rccl" and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent", "hard_saturated_logistic"):
-        pytest.skip("once is enough for the large hard designs")
+    if gather == "rccl" and not os.environ.get("MIPGEN_SAN_FULL") and name in ("hard_logistic", "hard_svr", "hard_lowcomplexity_svr_silent", "hard_saturated_logistic",
+                                                                                 "long_capture_svr", "merge_flank_tags", "multichr_logistic_snps"):
+        pytest.skip("once is enough for the large designs (the CPU suite is run sequentially by the driver: minutes, not tens of them)")
     if san == "thread" and name == "edge_options":
         pytest.skip("190,000 records under ThreadSanitizer take a minute: AddressSanitizer only")
-    if san == "thread" and name == "long_capture_logistic":
-        pytest.skip("the 1,100-base captures (string lengths of the host side): AddressSanitizer; the SVR one under ThreadSanitizer")
+    if san == "thread" and name in ("long_capture_logistic", "long_capture_svr") and not os.environ.get("MIPGEN_SAN_FULL"):
+        pytest.skip("the 1,100-base captures (string lengths of the host side): AddressSanitizer (45 s each under ThreadSanitizer; MIPGEN_SAN_FULL=1 runs them)")
     meta = H.load_design(name)
     biggest = max(r[2] - r[1] for r in meta["intervals"])
     p = _run(san, meta, str(tmp_path), workers, extra=["-gpu_window_candidates", str(max(1000, biggest * 2000)), "-gpu_gather", gather])
@@ -139,6 +140,9 @@ def _waiting_seconds(err):
     return float(m.group(1)), float(m.group(2))
 
 
+_ONE_WORKER_WAIT = {}
+
+
 @pytest.mark.parametrize("gather", ["pcie", "rccl"])
 def test_device_workers_overlap_with_many_windows_per_worker(gather, tmp_path):
     """`mipgen -gpus 4` with MANY result windows per device must overlap its device workers: the regions are dealt to the devices in blocks (block b
@@ -159,6 +163,9 @@ def test_device_workers_overlap_with_many_windows_per_worker(gather, tmp_path):
     extra = ["-gpu_window_candidates", "1", "-gpu_timing", "on", "-gpu_gather", gather]     # one region per window: 62 windows, 15-16 per worker of four
     waits = {}
     for workers in (1, 4):
+        if workers == 1 and "one" in _ONE_WORKER_WAIT:                  # (the one-worker run is the same for both gather routes: there is no gather to speak of)
+            waits[1] = _ONE_WORKER_WAIT["one"]
+            continue
         work = str(tmp_path / f"w{workers}")
         p = _run(san, meta, work, workers, extra=extra, timeout=900)
         err = p.stderr.decode()
@@ -166,6 +173,8 @@ def test_device_workers_overlap_with_many_windows_per_worker(gather, tmp_path):
         assert "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
         _compare(meta, work)
         waits[workers] = _waiting_seconds(err)
+        if workers == 1:
+            _ONE_WORKER_WAIT["one"] = waits[1]
         m = __import__("re").search(r"in (\d+) region blocks on (\d+) device", err)
         assert m and int(m.group(2)) == workers and (workers == 1 or int(m.group(1)) >= 12 * workers), err[-2000:]
     assert waits[4][0] <= 0.4 * waits[1][0], f"device workers do not overlap: waiting {waits[4][0]:.2f} s with four workers, {waits[1][0]:.2f} s with one"
