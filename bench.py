@@ -773,9 +773,11 @@ def main() -> None:
         else:
             roof = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
                     "kernel": kern, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        roof["hbm_frac"] = hbm["frac"]; roof["hbm_achieved_gbs"] = hbm["achieved"]; roof["algorithmic_bytes_per_launch"] = alg_bytes      # (flat: see above)
         if traffic_run:
             roof["traffic_measured_in_this_run"] = True
             roof["traffic_detail"] = traffic_run
+            roof["traffic_fetch_bytes"] = traffic_run.get("fetch_bytes_corrected"); roof["traffic_write_bytes"] = traffic_run.get("write_bytes")
             roof["traffic_note"] = ("WRITE_SIZE = the scores (1.05x: 456-byte rows, 64-byte granules); FETCH_SIZE x 2 = the records + the inputs (the model once per "
                                     "XCD's L2 = 14 MB, ~80 KB per tile of copy-table slices / bases / model rows fetched again); round 5's 2.4x was the "
                                     "lane-by-lane store path of the headline tile shape, not a profiler constant (tools/exp/traffic_abl.sh, ctx_probe.sh)")
@@ -802,7 +804,11 @@ def main() -> None:
             "parity_checked": bool(gate), "parity_gate": gate,
             "kernels_ms": {kern: k_ms, "k_records": float(np.mean(records_ms)), "k_replay_condense(+memsets)": float(np.mean(replay_ms))},
         }
-        out["roofline"]["kernels_ms"] = out["kernels_ms"]    # (the driver's record keeps the standard objects whole: the per-kernel times ride in one of them)
+        # the driver's record keeps the SCALAR members of the standard objects (nested objects and lists are dropped there): the per-kernel times, the
+        # full-size exome figure and the per-K rates ride along as flat keys of `roofline` / `config`, beside the nested objects other readers use
+        out["roofline"]["kernels_ms"] = out["kernels_ms"]
+        out["roofline"]["k_records_ms"] = out["kernels_ms"]["k_records"]
+        out["roofline"]["k_replay_condense_ms"] = out["kernels_ms"]["k_replay_condense(+memsets)"]
         if exome_strong:
             exome_strong["compare_with"] = "exome_strong.value of the --gpus 1 line (the same BED on one GPU) - never with `value`, which is another workload"
             out["exome_strong"] = exome_strong
@@ -811,7 +817,13 @@ def main() -> None:
                                            "value": exome_strong["value"], "unit": "candidates/s", "seconds": exome_strong["seconds"],
                                            "dense_candidates": exome_strong["dense_candidates"], "regions": exome_strong["regions"], "n_gpus": world,
                                            "result_windows_rank0": exome_strong.get("result_windows_rank0")}
+            for k in ("value", "seconds", "dense_candidates", "regions", "result_windows_rank0"):
+                out["config"]["exome_full_" + k] = exome_strong.get(k)
+            out["config"]["exome_full_workload"] = out["config"]["exome_full"]["workload"]
             if "roofline" in exome_strong:
+                out["roofline"]["exome_full_frac"] = exome_strong["roofline"]["frac"]
+                out["roofline"]["exome_full_achieved_tflops"] = exome_strong["roofline"]["achieved"]
+                out["roofline"]["exome_full_table_entries_per_sv"] = exome_strong["roofline"]["table_entries_per_sv"]
                 r = exome_strong["roofline"]
                 out["roofline"]["exome_full"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
                                                  "table_entries_per_sv": r["table_entries_per_sv"], "hbm_frac": r["hbm"]["frac"],
@@ -843,6 +855,9 @@ def main() -> None:
                               "by_capture_sizes": by_k})
                 out["config"]["exome_by_capture_sizes"] = {k: {"candidates_per_s": v["candidates_per_s"], "candidates_share": v["candidates_share"],
                                                                "regions": v["regions"]} for k, v in by_k.items()}
+                for k, v in by_k.items():
+                    out["config"][f"exome_K{k}_candidates_per_s"] = v["candidates_per_s"]
+                    out["config"][f"exome_K{k}_candidates_share"] = v["candidates_share"]
             if args.sustain_seconds > 0:
                 # the headline again, long enough for an outside observer (the driver's GPU-busy sampler) to see: same step, >= 2 s
                 reps = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)
