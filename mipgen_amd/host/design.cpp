@@ -180,6 +180,8 @@ int mipgen_design_close(mipgen_design* d)
     if (!d) return 0;
     if (!d->closed) {
         d->flush_err();
+        // the writer thread of the selection stage holds picked / snp records that are not in the files yet
+        if (d->selector) { try { d->selector->finish(); } catch (std::exception& e) { d->failed = true; std::cerr << "[mipgen] writing the picked MIPs: " << e.what() << std::endl; } catch (...) { d->failed = true; } }
         Outputs& out = d->out;
         const Options& o = d->o;
         out.all.close(); out.collapsed.close(); out.picked.close(); out.snp.close();

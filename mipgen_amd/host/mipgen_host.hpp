@@ -13,6 +13,11 @@
 // Candidate construction + scoring (tile_regions' loop body, design_mip, get_score, get_parameters, predict_value)
 // is NOT here: it is the accelerator's job (include/mipgen_accel.h).
 #pragma once
+#include <exception>
+#include <deque>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <algorithm>
 #include <cstdint>
@@ -261,6 +266,11 @@ private:
 class Selector {
 public:
     Selector(const Options& o, const Tables& t, Outputs& out);
+    ~Selector();
+    // The picked / snp records are formatted and written by a WRITER thread: the pick stage is what bounds a logistic design (and any design once the
+    // scoring is spread over several devices), and print_details of 4-5 10^5 picked MIPs was a third of it.  One FIFO, one consumer: the files' order is
+    // the pick order.  finish() drains the queue and joins the thread (idempotent; before the files are closed); it rethrows what the writer caught.
+    void finish();
     // survivors: 2 per scan position ('+','-'); cand_index - index_base is the region-local dense index, cand_index < 0 = no survivor.
     // collapsed: optional result of the accelerator's collapse (2 entries per base from g.first_pos on: scan-start index of the
     // winning survivor per strand, or -1; n_bases of them); nullptr = collapse on the host
@@ -288,6 +298,14 @@ private:
     std::vector<uint8_t> touched_;                                         // scan positions created by operator[] (:1869)
     std::set<int> touched_outside_;
     GlibcRand rand_;
+    struct PickJob { const Region* r; Cand c; int64_t counter; };
+    std::thread writer_;
+    std::mutex wm_;
+    std::condition_variable wcv_;
+    std::deque<PickJob> wq_;
+    bool wstop_ = false, wstarted_ = false;
+    std::exception_ptr werr_;
+    void writer_loop();
     // table views
     CandPtr scan_m(int pos, int s) const
     {

@@ -334,7 +334,16 @@ Selector::CandPtr Selector::optimize_worst(PosSet& positions, int strand_to_use)
         }
         return last_free[strand];
     };
+    // consecutive bases are mostly covered by the same pair of survivors (a survivor is the best of ~100 bases): a base whose pair is the previous
+    // base's changes nothing - its candidate was compared already and `<` is strict - so it costs two integer compares, not the body below
+    int32_t last_c0 = -2, last_c1 = -2;
     positions.for_each([&](int pos) {
+        const long j = (long)pos - first_pos_;
+        if (j >= 0 && j < n_bases_) {
+            const int32_t c0 = col_[2 * j], c1 = col_[2 * j + 1];
+            if (c0 == last_c0 && c1 == last_c1) return;
+            last_c0 = c0; last_c1 = c1;
+        } else { last_c0 = -2; last_c1 = -2; }
         const CandPtr m0 = pos_m(pos, 0), m1 = pos_m(pos, 1);
         if (!m0 && !m1) return;
         CandPtr cur = nullptr, plus = nullptr, minus = nullptr;
@@ -414,9 +423,15 @@ void Selector::manage_picked(CandPtr mp, PosSet& positions)
     const Cand c = cand_of(mp);
     const Cand* m = &c;
     out_.picked_counter++;
-    out_.picked << format_record(o_, *r_, t_, *m, out_.picked_counter, false);
-    if (m->snp_count == 1 && m->snp_failed == '0') out_.snp << format_record(o_, *r_, t_, *m, out_.picked_counter, true);
-    else if (m->snp_failed == '1') out_.snp << ">Alternate MIP(s) could not be generated for SNP in arms of MIP #" << out_.picked_counter << std::endl;
+    {   // print_details of the picked MIP (+ its SNP record / the note of :1920-1923) on the writer thread, in pick order
+        std::unique_lock<std::mutex> lk(wm_);
+        if (!wstarted_) { wstarted_ = true; writer_ = std::thread([this] { writer_loop(); }); }
+        wcv_.wait(lk, [&] { return wq_.size() < 65536 || werr_; });
+        if (werr_) { std::exception_ptr e = werr_; lk.unlock(); std::rethrow_exception(e); }
+        const bool was_empty = wq_.empty();
+        wq_.push_back(PickJob{r_, c, out_.picked_counter});
+        if (was_empty) wcv_.notify_all();                            // (the writer only sleeps on an empty queue: no wake-up call per record)
+    }
     const int other = 1 - m->strand;
     auto& used = *used_cur_;
     if (o_.seal_both) {
@@ -429,6 +444,53 @@ void Selector::manage_picked(CandPtr mp, PosSet& positions)
     used[m->strand].insert_range(m->ext_start, m->ext_stop);
     used[m->strand].insert_range(m->lig_start, m->lig_stop);
     positions.erase_range(m->scan_start, m->scan_stop);
+}
+
+void Selector::writer_loop()
+{
+    try {
+        for (;;) {
+            std::deque<PickJob> batch;
+            {
+                std::unique_lock<std::mutex> lk(wm_);
+                wcv_.wait(lk, [&] { return wstop_ || !wq_.empty(); });
+                if (wq_.empty()) return;
+                const bool was_full = wq_.size() >= 65536;
+                batch.swap(wq_);
+                if (was_full) wcv_.notify_all();                     // (the selection thread only sleeps on a full queue)
+            }
+            for (const PickJob& j : batch) {
+                const Cand* m = &j.c;
+                out_.picked << format_record(o_, *j.r, t_, *m, j.counter, false);
+                if (m->snp_count == 1 && m->snp_failed == '0') out_.snp << format_record(o_, *j.r, t_, *m, j.counter, true);
+                else if (m->snp_failed == '1') out_.snp << ">Alternate MIP(s) could not be generated for SNP in arms of MIP #" << j.counter << std::endl;
+            }
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(wm_);
+        werr_ = std::current_exception();
+        wq_.clear();
+        wcv_.notify_all();
+    }
+}
+
+void Selector::finish()
+{
+    {
+        std::lock_guard<std::mutex> lk(wm_);
+        if (!wstarted_) return;
+        wstop_ = true;
+        wcv_.notify_all();
+    }
+    if (writer_.joinable()) writer_.join();
+    std::lock_guard<std::mutex> lk(wm_);
+    wstarted_ = false; wstop_ = false;
+    if (werr_) { std::exception_ptr e = werr_; werr_ = nullptr; std::rethrow_exception(e); }
+}
+
+Selector::~Selector()
+{
+    try { finish(); } catch (...) {}
 }
 
 // print_gaps, mipgen.cpp:1231-1259
