@@ -303,6 +303,9 @@ private:
     std::mutex wm_;
     std::condition_variable wcv_;
     std::deque<PickJob> wq_;
+    std::vector<PickJob> wlocal_;                                          // the selection thread's own batch: handed over 256 records at a time (a lock + a wake-up
+                                                                           // call per record cost as much as print_details itself did)
+    void hand_over();
     bool wstop_ = false, wstarted_ = false;
     std::exception_ptr werr_;
     void writer_loop();

@@ -423,15 +423,9 @@ void Selector::manage_picked(CandPtr mp, PosSet& positions)
     const Cand c = cand_of(mp);
     const Cand* m = &c;
     out_.picked_counter++;
-    {   // print_details of the picked MIP (+ its SNP record / the note of :1920-1923) on the writer thread, in pick order
-        std::unique_lock<std::mutex> lk(wm_);
-        if (!wstarted_) { wstarted_ = true; writer_ = std::thread([this] { writer_loop(); }); }
-        wcv_.wait(lk, [&] { return wq_.size() < 65536 || werr_; });
-        if (werr_) { std::exception_ptr e = werr_; lk.unlock(); std::rethrow_exception(e); }
-        const bool was_empty = wq_.empty();
-        wq_.push_back(PickJob{r_, c, out_.picked_counter});
-        if (was_empty) wcv_.notify_all();                            // (the writer only sleeps on an empty queue: no wake-up call per record)
-    }
+    // print_details of the picked MIP (+ its SNP record / the note of :1920-1923) on the writer thread, in pick order
+    wlocal_.push_back(PickJob{r_, c, out_.picked_counter});
+    if (wlocal_.size() >= 256) hand_over();
     const int other = 1 - m->strand;
     auto& used = *used_cur_;
     if (o_.seal_both) {
@@ -444,6 +438,19 @@ void Selector::manage_picked(CandPtr mp, PosSet& positions)
     used[m->strand].insert_range(m->ext_start, m->ext_stop);
     used[m->strand].insert_range(m->lig_start, m->lig_stop);
     positions.erase_range(m->scan_start, m->scan_stop);
+}
+
+void Selector::hand_over()
+{
+    if (wlocal_.empty()) return;
+    std::unique_lock<std::mutex> lk(wm_);
+    if (!wstarted_) { wstarted_ = true; writer_ = std::thread([this] { writer_loop(); }); }
+    wcv_.wait(lk, [&] { return wq_.size() < 65536 || werr_; });
+    if (werr_) { std::exception_ptr e = werr_; lk.unlock(); wlocal_.clear(); std::rethrow_exception(e); }
+    const bool was_empty = wq_.empty();
+    wq_.insert(wq_.end(), wlocal_.begin(), wlocal_.end());
+    wlocal_.clear();
+    if (was_empty) wcv_.notify_all();                                // (the writer only sleeps on an empty queue)
 }
 
 void Selector::writer_loop()
@@ -476,6 +483,7 @@ void Selector::writer_loop()
 
 void Selector::finish()
 {
+    hand_over();
     {
         std::lock_guard<std::mutex> lk(wm_);
         if (!wstarted_) return;

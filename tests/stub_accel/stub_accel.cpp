@@ -6,6 +6,9 @@
 // be compared with the reference's goldens there.  Knobs (environment, read here only):
 //   STUB_ACCEL_DEVICES=n        what mipgen_accel_device_count() reports (default 1)
 //   STUB_ACCEL_FAIL=dev:call:n  the n-th call (1-based) of mipgen_accel_<call> on a handle of device `dev` fails with MIPGEN_E_HIP
+//   STUB_ACCEL_FAKE=1           PROFILING ONLY: nothing is scored - every scan position and strand gets a fabricated survivor (hashed capture size, arm pair
+//                               and score; every copy number 1), the resident k-mer counter "counts" nothing, so that the HOST side of a 200,000-exon silent design
+//                               (input stage, block dealing, selection stage) can be timed and profiled on a machine without a GPU (tools/exp/host_profile.sh)
 // The collapse fold (mipgen.cpp:1616-1649) and the all_mips generation order (mipgen.cpp:421-491) are restated here; everything per candidate
 // comes from the oracle.
 #include <algorithm>
@@ -74,6 +77,9 @@ struct mipgen_accel {
 };
 
 namespace {
+
+bool fake_mode() { static const bool f = getenv("STUB_ACCEL_FAKE") != nullptr; return f; }
+inline uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 
 int max_scan_of(const mipgen_params& P, const mipgen_grid& g)
 {
@@ -192,11 +198,12 @@ int mipgen_accel_upload_regions(mipgen_accel* h, const mipgen_region* regions, i
     for (int i = 0; i < n; i++) {
         RegionStore& S = h->regions[(size_t)i];
         const mipgen_region& R = regions[i];
-        if (R.copy == MIPGEN_COPY_RESIDENT) return fail(MIPGEN_E_INVALID, "stub accelerator: resident copy tables are not supported");
+        if (R.copy == MIPGEN_COPY_RESIDENT && !fake_mode()) return fail(MIPGEN_E_INVALID, "stub accelerator: resident copy tables are not supported");
         S.r = R;
+        if (R.copy == MIPGEN_COPY_RESIDENT) S.r.copy = nullptr;
         S.seq.assign(R.seq, (size_t)R.seq_len); S.r.seq = S.seq.c_str();
         if (R.masked_seq) { S.masked.assign(R.masked_seq, (size_t)R.seq_len); S.r.masked_seq = S.masked.c_str(); }
-        if (R.copy) {
+        if (R.copy && R.copy != MIPGEN_COPY_RESIDENT) {
             S.copy.assign(MIPGEN_MAX_OLIGO + 1, std::vector<int32_t>());
             S.copy_ptrs.assign(MIPGEN_MAX_OLIGO + 1, nullptr);
             for (int l = 0; l <= MIPGEN_MAX_OLIGO; l++) if (R.copy[l]) { S.copy[(size_t)l].assign(R.copy[l], R.copy[l] + R.seq_len); S.copy_ptrs[(size_t)l] = S.copy[(size_t)l].data(); }
@@ -264,6 +271,7 @@ int mipgen_accel_score_window(mipgen_accel* h, int32_t w, int32_t method)
     INJECT(h, "score_window");
     if (method == MIPGEN_SCORE_SVR && !h->model) return fail(MIPGEN_E_MODEL, "SVR scoring requested but no model is loaded");
     const Win& W = h->windows[(size_t)w];
+    if (fake_mode()) { h->cur = w; h->scored = true; h->replayed = false; h->have_text = false; h->win_state[(size_t)w] = 0; return MIPGEN_OK; }
     h->scores.assign((size_t)W.n_cand, 0.0); h->records.assign((size_t)W.n_cand, 0);
     for (int i = W.r0; i < W.r1; i++) {
         const mipgen_grid& g = h->grids[(size_t)i];
@@ -279,6 +287,27 @@ int mipgen_accel_replay_condense(mipgen_accel* h)
     if (!h || !h->scored || h->cur < 0) return fail(MIPGEN_E_STATE, "replay requested before scoring");
     INJECT(h, "replay_condense");
     const Win& W = h->windows[(size_t)h->cur];
+    if (fake_mode()) {
+        // a fabricated survivor per scan position and strand: hashed capture size / arm pair / score (logistic-like in [0.3, 1), SVR-like in [0.8, 3)), copies 1
+        const int A = h->P.n_arm_pairs;
+        for (int i = W.r0; i < W.r1; i++) {
+            const mipgen_grid& g = h->grids[(size_t)i];
+            mipgen_survivor* sv = h->survivors.data() + 2 * h->region_pos0[(size_t)i];
+            h->emitted_per_region[(size_t)i] = g.count;
+            for (int pi = 0; pi < g.n_pos && g.n_sizes > 0; pi++)
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const uint64_t hsh = mix64(((uint64_t)(uint32_t)i << 32) ^ ((uint64_t)pi << 1) ^ (uint64_t)s2 ^ 0x9e3779b97f4a7c15ULL);
+                    const int ki = (int)(hsh % (uint64_t)g.n_sizes), a = (int)((hsh >> 20) % (uint64_t)A);
+                    const double u = (double)((hsh >> 11) & 0xFFFFFFFFFFFFFull) / 4503599627370496.0;
+                    mipgen_survivor& m = sv[2 * pi + s2];
+                    m.cand_index = g.offset + (((int64_t)pi * g.n_sizes + ki) * 2 + s2) * A + a;
+                    m.score = h->P.score_method == MIPGEN_SCORE_SVR ? 0.8 + 2.2 * u : 0.3 + 0.7 * u;
+                    m.record = (uint64_t)1 | ((uint64_t)1 << 16) | ((uint64_t)MIPGEN_FLAG_VALID << 48) | ((uint64_t)(hsh >> 60) << 56);
+                }
+        }
+        h->replayed = true; h->win_state[(size_t)h->cur] = 1;
+        return MIPGEN_OK;
+    }
     h->emitted.assign((size_t)W.n_cand, 0);
     for (int i = W.r0; i < W.r1; i++) {
         const mipgen_grid& g = h->grids[(size_t)i];
@@ -483,13 +512,22 @@ int mipgen_accel_synchronize(mipgen_accel* h)
 // the GPU k-mer counter: not in the stub (those paths need a GPU)
 int mipgen_accel_count_oligo_copies(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, int32_t, const int32_t*, int32_t* const*)
 { return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter"); }
-int mipgen_accel_count_oligo_copies_resident(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, int64_t*, const mipgen_big_copy**)
-{ return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter"); }
+int mipgen_accel_count_oligo_copies_resident(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, int64_t* n_big, const mipgen_big_copy** big)
+{
+    if (!fake_mode()) return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter");
+    if (n_big) *n_big = 0;
+    if (big) *big = nullptr;
+    return MIPGEN_OK;
+}
 int mipgen_accel_window_uniqueness(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, int32_t, const int32_t*, int32_t, uint8_t* const*)
 { return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter"); }
-int mipgen_accel_window_uniqueness_begin(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t, const char* const*, const int32_t*, const mipgen_window_bounds*, int32_t,
-                                         const int32_t*, int32_t, uint8_t*)
-{ return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter"); }
+int mipgen_accel_window_uniqueness_begin(mipgen_accel*, int32_t, const char* const*, const int64_t*, int32_t n_regions, const char* const*, const int32_t*, const mipgen_window_bounds*, int32_t,
+                                         const int32_t*, int32_t, uint8_t* any)
+{
+    if (!fake_mode()) return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter");
+    if (any) memset(any, 0, (size_t)n_regions);
+    return MIPGEN_OK;
+}
 int mipgen_accel_window_flags_region(mipgen_accel*, int32_t, uint8_t*) { return fail(MIPGEN_E_NODEVICE, "stub accelerator: no k-mer counter"); }
 int mipgen_accel_window_uniqueness_end(mipgen_accel*) { return MIPGEN_OK; }
 

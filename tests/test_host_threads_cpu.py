@@ -7,6 +7,7 @@ call position of every worker ends the run the way the reference ends (/root/ref
 line) - without a hang, a race or a leak of a worker."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -178,3 +179,23 @@ def test_device_workers_overlap_with_many_windows_per_worker(gather, tmp_path):
         m = __import__("re").search(r"in (\d+) region blocks on (\d+) device", err)
         assert m and int(m.group(2)) == workers and (workers == 1 or int(m.group(1)) >= 12 * workers), err[-2000:]
     assert waits[4][0] <= 0.4 * waits[1][0], f"device workers do not overlap: waiting {waits[4][0]:.2f} s with four workers, {waits[1][0]:.2f} s with one"
+
+
+def test_host_profile_harness_runs(tmp_path):
+    """tools/exp/host_profile.sh: the uninstrumented stub build with STUB_ACCEL_FAKE=1 (fabricated survivors, nothing scored) times the HOST side of an
+    exome-scale silent design on a machine without a GPU - DESIGN.md section 7's selection-stage numbers come from it.  Here: 400 exons, two stub
+    devices; the run ends well, picks MIPs and prints the stage-by-stage timing lines the notebook quotes.  (Timing harness only: no file of it is compared with anything.)"""
+    import fcntl
+    os.makedirs(os.path.join(STUB, "_build"), exist_ok=True)
+    with open(os.path.join(STUB, "_build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-s", "-j4", "-C", STUB, "SAN=none"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    env = dict(os.environ, STUB_ACCEL_FAKE="1", STUB_ACCEL_DEVICES="2", MIPGEN_CLI_BIN=os.path.join(STUB, "_build", "none", "mipgen"))
+    p = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "cli_exome.py"), "400", str(tmp_path / "w"), "exome", "logistic", "-gpus", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-3000:]
+    assert "pick stage: position sets" in out and "on 2 device worker(s)" in out, out[-3000:]
+    picked = int(__import__("re").search(r"(\d+) picked MIPs for 400 intervals", out).group(1))
+    assert picked >= 400

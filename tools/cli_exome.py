@@ -44,7 +44,9 @@ def main() -> None:
         method = sys.argv[4]
     synth.write_bed(os.path.join(work, "exome.bed"), ivs)
     exe = os.path.join(work, "mipgen")
-    os.symlink(os.path.join(ROOT, "mipgen_amd", "mipgen"), exe)
+    # MIPGEN_CLI_BIN: another build of the command line (tools/exp/host_profile.sh: the uninstrumented stub build of tests/stub_accel with STUB_ACCEL_FAKE=1,
+    # which times the HOST side of an exome-scale design on a machine without a GPU)
+    os.symlink(os.environ.get("MIPGEN_CLI_BIN", os.path.join(ROOT, "mipgen_amd", "mipgen")), exe)
     model = workloads.svr_model_path(os.path.join(work, "cache"), workloads.practice62()[0], 1024, rho=workloads.MODEL_RHO["regions5k" if config == "regions5k" else "exome"])
     shutil.copy(model, os.path.join(work, "mipgen_svr.model"))
     print(f"inputs: {len(ivs)} intervals on {len(chroms)} chromosomes written in {time.time() - t0:.1f} s", flush=True)
