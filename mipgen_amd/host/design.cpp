@@ -437,19 +437,16 @@ namespace {
 
 struct WindowResult {
     int r0 = 0, r1 = 0;                          // design-wide region range of the window
-    std::vector<mipgen_grid> grids;              // one per region; offsets relative to the window's first candidate
+    std::vector<mipgen_grid> grids;              // one per region; offsets batch-wide (the worker's batch)
     std::vector<int64_t> emitted;
-    std::vector<mipgen_survivor> surv;           // cand_index relative to the window's first candidate
+    std::vector<mipgen_survivor> surv;           // cand_index batch-wide, like the offsets of `grids` (the selection stage uses their difference only)
     std::vector<double> svr;                     // mixed designs: SVR score of every survivor (parallel to surv; NaN where none)
     std::vector<int32_t> collapsed;              // collapse_mips from the device: 2 entries per base, region after region
     std::vector<int64_t> col_off;                // first entry of every region of the window in `collapsed` (+ total)
-    std::vector<double> scores;
-    std::vector<uint64_t> records;
-    std::vector<uint8_t> mask;
     std::vector<char> text;                      // the window's all_mips records, formatted on the device, numbered from the worker's own first record
     // what the consumer reads: the vectors above (-gpu_gather pcie: the worker downloaded them) or the packed buffer of the RCCL gather
     const int64_t* emitted_p = nullptr;
-    mipgen_survivor* surv_p = nullptr;
+    const mipgen_survivor* surv_p = nullptr;
     const double* svr_p = nullptr;
     const int32_t* collapsed_p = nullptr;
     const char* text_p = nullptr;
@@ -466,6 +463,13 @@ struct WindowResult {
     bool last = false;
     int error = 0;
     std::string msg;
+    // a result object goes round (worker -> channel -> selection thread -> back to the worker: Channel::give_back): its vectors keep their pages, so a
+    // window costs no page faults after the first few (fresh vectors of 2 GB per exome were 0.5 s of the worker's time, a third of a logistic design's)
+    void reuse()
+    {
+        r0 = r1 = 0; emitted_p = nullptr; surv_p = nullptr; svr_p = nullptr; collapsed_p = nullptr; text_p = nullptr; text_n = 0;
+        on_device = false; views = mipgen_window_views(); c0 = n_surv = n_rec = own_before = 0; has_text = block_end = last = false; error = 0; msg.clear();
+    }
 };
 
 // the first failure of a run, shared by the device workers (a worker that only learns of the abort reports this one)
@@ -516,6 +520,17 @@ struct Channel {                                 // worker -> consumer, at most 
         return r;
     }
     void stop() { std::lock_guard<std::mutex> lk(m); abort = true; cv.notify_all(); }
+    // result objects the selection thread has finished with, for the worker to fill again (at most four exist per device: one being filled, two in
+    // flight, one being selected)
+    std::vector<std::unique_ptr<WindowResult>> spare;
+    void give_back(std::unique_ptr<WindowResult> r) { std::lock_guard<std::mutex> lk(m); if (spare.size() < 4) spare.push_back(std::move(r)); }
+    std::unique_ptr<WindowResult> fresh()
+    {
+        std::unique_ptr<WindowResult> r;
+        { std::lock_guard<std::mutex> lk(m); if (!spare.empty()) { r = std::move(spare.back()); spare.pop_back(); } }
+        if (r) r->reuse(); else r.reset(new WindowResult());
+        return r;
+    }
     // -gpu_gather rccl: windows of this worker whose arrays the consumer has finished reading from the worker's HBM (the worker must not overwrite
     // its text buffer, nor destroy its handle, before)
     int transferred = 0;
@@ -629,7 +644,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& block
     std::vector<mipgen_region> batch((size_t)n);
     for (int i = 0; i < n; i++) fill_accel_region(d->regions[(size_t)ridx[(size_t)i]], batch[(size_t)i], resident);
     std::vector<mipgen_grid> grids((size_t)n);
-    // silent designs keep only survivors, so a window may fill the HBM; otherwise its dense results come to the host (17 B per candidate)
+    // silent designs keep only survivors, so a window may fill the HBM; otherwise a window's all_mips text comes to the host (its dense results never do)
     mipgen_accel_set_window_candidates(h, d->window_candidates > 0 ? d->window_candidates : (o.silent ? 0 : (int64_t)64 << 20));   // (tests force several windows)
     if (mipgen_accel_set_window_breaks(h, breaks.data(), (int32_t)breaks.size())) { bail(19); return; }
     if (mipgen_accel_upload_regions(h, batch.data(), n, grids.data())) { bail(19); return; }
@@ -656,12 +671,11 @@ void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& block
         int32_t wr0 = 0, wn = 0;
         int64_t c0 = 0, nc = 0, p0 = 0, np = 0;
         mipgen_accel_window_info(h, w, &wr0, &wn, &c0, &nc, &p0, &np);
-        std::unique_ptr<WindowResult> res(new WindowResult());
+        std::unique_ptr<WindowResult> res = ch->fresh();
         res->r0 = wn > 0 ? ridx[(size_t)wr0] : 0; res->r1 = res->r0 + wn; res->last = w == nw - 1;
         res->block_end = block_ends_at[(size_t)(wr0 + wn)] != 0;
         if (wn > 0 && ridx[(size_t)(wr0 + wn - 1)] != res->r1 - 1) { mipgen_accel_destroy(h); fail_out(19, "internal: a result window spans two region blocks"); return; }
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
-        for (auto& g : res->grids) g.offset -= c0;
         if (!rccl) { res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np)); }
         if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
         if (mipgen_accel_collapse(h)) { bail(19); return; }
@@ -675,11 +689,7 @@ void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& block
         res->collapsed.resize((size_t)std::max<int64_t>(res->col_off[(size_t)wn], 1));
         if (mipgen_accel_download_collapsed(h, w, res->collapsed.data(), (int64_t)res->collapsed.size())) { bail(19); return; }
         }
-        if (!rccl && !o.silent && !text) {
-            res->scores.resize((size_t)nc); res->records.resize((size_t)nc); res->mask.resize((size_t)nc);
-            if (mipgen_accel_download_results(h, res->scores.data(), res->records.data(), c0, nc)) { bail(19); return; }
-        }
-        if (!rccl && mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), (o.silent || text) ? nullptr : res->mask.data(), (int64_t)res->mask.size())) { bail(19); return; }
+        if (!rccl && mipgen_accel_download_replay(h, res->emitted.data(), res->surv.data(), (int64_t)res->surv.size(), nullptr, 0)) { bail(19); return; }
         lap(3);
         if (text) {
             // print_details on the device: the records leave the GPU as text, the dense results never do
@@ -702,7 +712,6 @@ void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& block
             all_before += n_rec;
         }
         lap(4);
-        if (!rccl) for (auto& s : res->surv) if (s.cand_index >= 0) s.cand_index -= c0;
         if (o.score_method == MIPGEN_SCORE_MIXED) {
             // every survivor of the window through the SVR in one list call ON THE DEVICE (the pick stage re-scores a subset of them, mipgen.cpp:1523-1527,
             // 1873-1877): the candidate list is built from the survivor array in HBM, only the scores come down
@@ -944,11 +953,9 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             const mipgen_grid& g = w->grids[(size_t)bi];
             SurvivorRescorer rs;
             rs.w = w; rs.pos0 = pos0; rs.g = &g;
-            const bool dense = !w->scores.empty();
             try {
                 rc = mipgen_design_select_region_collapsed(d, w->r0 + bi, &g, w->surv_p + 2 * pos0, w->emitted_p[(size_t)bi],
-                                                 dense ? w->scores.data() + g.offset : nullptr, dense ? w->records.data() + g.offset : nullptr,
-                                                 dense ? w->mask.data() + g.offset : nullptr, w->collapsed_p + w->col_off[(size_t)bi],
+                                                 nullptr, nullptr, nullptr, w->collapsed_p + w->col_off[(size_t)bi],
                                                  (int32_t)((w->col_off[(size_t)bi + 1] - w->col_off[(size_t)bi]) / 2),
                                                  d->o.score_method == MIPGEN_SCORE_MIXED ? &SurvivorRescorer::fn : nullptr, &rs);
             } catch (int e) { rc = fail(MIPGEN_HOST_E_INPUT, e, "unable to tile sequences"); }
@@ -971,7 +978,9 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
                 t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
                 if (w->error) { worker_failed(w.get()); break; }
                 select_window(w.get());
-                if (w->block_end || w->last || rc) break;
+                const bool done = w->block_end || w->last || rc;
+                chans[(size_t)k]->give_back(std::move(w));                  // its vectors keep their pages for a later window
+                if (done) break;
             }
         }
     } else {
@@ -998,11 +1007,10 @@ extern "C" int mipgen_design_run(mipgen_design* d, int32_t n_devices)
             WindowResult* w = p->w.get();
             char* hb = gather->host(p->slot);
             w->emitted_p = (const int64_t*)(hb + p->off[0]);
-            w->surv_p = (mipgen_survivor*)(hb + p->off[1]);
+            w->surv_p = (const mipgen_survivor*)(hb + p->off[1]);
             w->collapsed_p = (const int32_t*)(hb + p->off[2]);
             w->svr_p = (const double*)(hb + p->off[3]);
             w->text_p = hb + p->off[4]; w->text_n = w->views.n_text_bytes;
-            for (int64_t q = 0; q < w->n_surv; q++) if (w->surv_p[q].cand_index >= 0) w->surv_p[q].cand_index -= w->c0;   // window-relative, like the grids
             select_window(w);
         };
         for (int b = 0; b < n_blocks && rc == 0; b++) {
