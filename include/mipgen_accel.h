@@ -56,7 +56,7 @@ extern "C" {
  * mipgen_accel_set_dynamic_skip / _skipped_candidates / _skip_state).
  * 4: new entry points only (mipgen_accel_rescore_survivors / _download_survivor_scores, mipgen_accel_window_views, mipgen_accel_synchronize).
  * 5: new entry point only (mipgen_accel_set_window_breaks: the multi-device front end deals its regions in blocks, a window never spans two). */
-#define MIPGEN_ACCEL_ABI_VERSION 5
+#define MIPGEN_ACCEL_ABI_VERSION 6
 
 #define MIPGEN_MAX_ARM_PAIRS 256     /* flattened (ext,lig) list, enumeration order */
 #define MIPGEN_N_FEATURES 192        /* SVMipv4.cpp:14 TOTAL_FEATURES */
@@ -271,6 +271,11 @@ int mipgen_accel_download_results(mipgen_accel* h, double* scores, uint64_t* rec
  * collapse result and the per-region emitted counts are kept.  Asynchronous; fetch with mipgen_accel_download_survivors /
  * mipgen_accel_download_collapsed. */
 int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method);
+/* ONE window that way (ABI 6): scored, replayed and condensed; what mipgen_accel_score_window + mipgen_accel_replay_condense leave for a caller that will
+ * never read the window's dense results (a -silent_mode front end that downloads window w while window w + 1 is scored): the print-exact re-score of
+ * mipgen_accel_set_print_exact then tests the 2 survivors per scan position - the only scores such a design prints, mipgen.cpp:1917 - instead of every
+ * dense candidate.  Follow with mipgen_accel_collapse / mipgen_accel_download_replay / mipgen_accel_download_collapsed as after mipgen_accel_replay_condense. */
+int mipgen_accel_score_condense_window(mipgen_accel* h, int32_t w, int32_t method);
 /* upload + score + download in one call: the literal replacement for the loop body of mipgen.cpp:446-497 */
 int mipgen_accel_score_regions(mipgen_accel* h, const mipgen_region* regions, int32_t n, int32_t method,
                                mipgen_grid* grids_out, double* scores, uint64_t* records, int64_t capacity);

@@ -23,7 +23,7 @@ MAX_OLIGO = 64
 
 SCORE_LOGISTIC, SCORE_SVR, SCORE_MIXED = 0, 1, 2
 
-ABI_VERSION = 5          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
+ABI_VERSION = 6          # include/mipgen_accel.h: MIPGEN_ACCEL_ABI_VERSION
 FLAG_VALID, FLAG_GUARD, FLAG_MAPPING, FLAG_MASKING, FLAG_SNP, FLAG_HAS_SNP_MIP = 1, 2, 4, 8, 16, 32
 
 
@@ -307,6 +307,7 @@ def load_library(path: Optional[str] = None):
     lib.mipgen_accel_window_info.argtypes = [vp, C.c_int32, i32p, i32p, i64p, i64p, i64p, i64p]
     lib.mipgen_accel_score_window.argtypes = [vp, C.c_int32, C.c_int32]
     lib.mipgen_accel_score_condense_all.argtypes = [vp, C.c_int32]
+    lib.mipgen_accel_score_condense_window.argtypes = [vp, C.c_int32, C.c_int32]
     lib.mipgen_accel_download_survivors.argtypes = [vp, i64p, C.POINTER(Survivor), C.c_int64]
     lib.mipgen_accel_survivors_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
     lib.mipgen_accel_set_sv_split.argtypes = [vp, C.c_int32]
@@ -340,7 +341,7 @@ def load_library(path: Optional[str] = None):
     for name in ("create", "load_model_file", "set_model", "model_info", "upload_regions", "score_resident",
                  "result_device_ptrs", "download_results", "score_regions", "score_candidates",
                  "long_range_content", "replay_condense", "download_replay", "set_timing", "set_window_candidates",
-                 "window_info", "score_window", "score_condense_all", "download_survivors", "survivors_device_ptr",
+                 "window_info", "score_window", "score_condense_all", "score_condense_window", "download_survivors", "survivors_device_ptr",
                  "set_sv_split", "set_print_exact", "set_logistic_subruns", "long_range_content_batch", "collapse", "region_bases", "download_collapsed", "count_oligo_copies", "count_oligo_copies_resident", "window_uniqueness", "window_uniqueness_begin", "window_flags_region", "window_uniqueness_end",
                  "format_all_mips", "download_text", "set_dynamic_skip", "skipped_candidates", "skip_state"):
         getattr(lib, "mipgen_accel_" + name).restype = C.c_int
@@ -357,7 +358,7 @@ EXPORTED_SYMBOLS = [
     "mipgen_accel_score_candidates", "mipgen_accel_long_range_content", "mipgen_accel_replay_condense",
     "mipgen_accel_download_replay", "mipgen_accel_last_kernel_ms", "mipgen_accel_set_timing",
     "mipgen_accel_set_window_candidates", "mipgen_accel_set_window_breaks", "mipgen_accel_window_count", "mipgen_accel_window_info", "mipgen_accel_score_window",
-    "mipgen_accel_score_condense_all", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
+    "mipgen_accel_score_condense_all", "mipgen_accel_score_condense_window", "mipgen_accel_download_survivors", "mipgen_accel_survivors_device_ptr",
     "mipgen_accel_set_sv_split", "mipgen_accel_long_range_content_batch", "mipgen_accel_collapse", "mipgen_accel_region_bases",
     "mipgen_accel_download_collapsed", "mipgen_accel_count_oligo_copies", "mipgen_accel_format_all_mips", "mipgen_accel_download_text",
     "mipgen_accel_count_oligo_copies_resident", "mipgen_accel_window_uniqueness", "mipgen_accel_window_uniqueness_begin", "mipgen_accel_window_flags_region",
@@ -457,6 +458,10 @@ class Accel:
 
     def score_condense_all(self, method: int) -> None:
         self._check(self.lib.mipgen_accel_score_condense_all(self.h, method))
+
+    def score_condense_window(self, w: int, method: int) -> None:
+        """One window scored, replayed and condensed for a caller that never reads its dense results (ABI 6): the print-exact re-score tests the survivors only."""
+        self._check(self.lib.mipgen_accel_score_condense_window(self.h, w, method))
 
     def download_survivors(self):
         nreg = len(self.grids)

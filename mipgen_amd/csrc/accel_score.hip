@@ -229,6 +229,17 @@ int mipgen_accel_score_resident(mipgen_accel* h, int32_t method)
     return mipgen_accel_score_window(h, 0, method);
 }
 
+int mipgen_accel_score_condense_window(mipgen_accel* h, int32_t w, int32_t method)
+{
+    if (int rc = check_scoring_args(h, method)) return rc;
+    if (w < 0 || w >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "window %d out of range (%zu windows)", w, h->windows.size());
+    HIP_TRY(hipSetDevice(h->device));
+    std::fill(h->ev_used.begin(), h->ev_used.end(), 0);
+    if (int rc = score_window_impl(h, w, method, false)) return rc;
+    if (int rc = replay_window_impl(h, false)) return rc;
+    return fix_print_boundaries_survivors(h, w, method);
+}
+
 int mipgen_accel_score_condense_all(mipgen_accel* h, int32_t method)
 {
     if (int rc = check_scoring_args(h, method)) return rc;

@@ -677,7 +677,8 @@ void worker_body(mipgen_design* d, int device, int k_worker, const Blocks& block
         if (wn > 0 && ridx[(size_t)(wr0 + wn - 1)] != res->r1 - 1) { mipgen_accel_destroy(h); fail_out(19, "internal: a result window spans two region blocks"); return; }
         res->grids.assign(grids.begin() + wr0, grids.begin() + wr0 + wn);
         if (!rccl) { res->emitted.resize((size_t)wn); res->surv.resize((size_t)(2 * np)); }
-        if (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h)) { bail(19); return; }
+        // a silent design never reads a window's dense results: scored, replayed and condensed in one call, the print-exact re-score on the survivors only
+        if (o.silent ? mipgen_accel_score_condense_window(h, w, method) : (mipgen_accel_score_window(h, w, method) || mipgen_accel_replay_condense(h))) { bail(19); return; }
         if (mipgen_accel_collapse(h)) { bail(19); return; }
         res->col_off.assign((size_t)wn + 1, 0);
         for (int bi = 0; bi < wn; bi++) {

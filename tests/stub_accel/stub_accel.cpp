@@ -282,6 +282,15 @@ int mipgen_accel_score_window(mipgen_accel* h, int32_t w, int32_t method)
     return MIPGEN_OK;
 }
 
+int mipgen_accel_replay_condense(mipgen_accel* h);
+int mipgen_accel_score_condense_window(mipgen_accel* h, int32_t w, int32_t method)      // ABI 6: what a silent front end calls per window
+{
+    if (!h || w < 0 || w >= (int32_t)h->windows.size()) return fail(MIPGEN_E_INVALID, "window out of range");
+    INJECT(h, "score_condense_window");
+    if (int rc = mipgen_accel_score_window(h, w, method)) return rc;
+    return mipgen_accel_replay_condense(h);
+}
+
 int mipgen_accel_replay_condense(mipgen_accel* h)
 {
     if (!h || !h->scored || h->cur < 0) return fail(MIPGEN_E_STATE, "replay requested before scoring");

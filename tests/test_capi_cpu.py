@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_struct_sizes():
     lib = capi.load_library()
-    assert lib.mipgen_accel_abi_version() == capi.ABI_VERSION == 5
+    assert lib.mipgen_accel_abi_version() == capi.ABI_VERSION == 6
     # layout agreed between ctypes and the C header (spot checks that catch padding mistakes)
     assert C.sizeof(capi.Grid) == 32
     assert C.sizeof(capi.Candidate) == 24

@@ -474,6 +474,45 @@ def test_result_windows(genome):
     acc.close()
 
 
+@pytest.mark.parametrize("name", ["logistic_default_arms", "svr_small", "mixed_12_regions", "hard_logistic", "hard_svr", "hard_saturated_logistic", "hard_ties_svr"])
+def test_score_condense_window_leaves_the_survivors_of_the_two_call_route(name, genome):
+    """mipgen_accel_score_condense_window (ABI 6: what the silent front end calls per result window) = mipgen_accel_score_window +
+    mipgen_accel_replay_condense for a caller that never reads the dense results: emitted counts and survivors - index, record and the score to the bit,
+    print-exact re-scores included (tested on the survivors only on this route, on every dense candidate on the other) - are the same, window after
+    window, and so is the collapse that follows."""
+    meta = H.load_design(name)
+    P = H.design_params(meta)
+    regions = H.design_regions(meta, _genome_of(meta, genome), P, lrc_fn=po.long_range_content)
+    method = capi.SCORE_SVR if meta["method"] == "svr" else capi.SCORE_LOGISTIC
+    acc = capi.Accel(P)
+    if meta["model"]:
+        acc.load_model_file(_model_path(meta))
+    grids = acc.upload(regions)
+    acc.set_window_candidates(int(max(g.count for g in grids)) + 1)              # one region per window
+    acc.upload(regions)
+    assert acc.window_count() >= 1
+    for w in range(acc.window_count()):
+        acc.score_window(w, method)
+        acc.replay_condense()
+        ea, va, _ = acc.download_replay(window=w)
+        acc.collapse()
+        ca = acc.download_collapsed(w)
+        acc.score_condense_window(w, method)
+        eb, vb, _ = acc.download_replay(want_mask=False, window=w)
+        acc.collapse()
+        cb = acc.download_collapsed(w)
+        assert np.array_equal(ea, eb), (name, w)
+        for f in ("cand_index", "record"):
+            assert np.array_equal(va[f], vb[f]), (name, w, f)
+        assert np.array_equal(va["score"].view(np.uint64), vb["score"].view(np.uint64)), (name, w)
+        assert np.array_equal(ca, cb), (name, w)
+        with pytest.raises(capi.AccelError):
+            acc.download_replay(want_mask=True, window=w)                         # the emitted flags are not kept on this route
+    with pytest.raises(capi.AccelError):
+        acc.score_condense_window(acc.window_count(), method)
+    acc.close()
+
+
 def test_copy_numbers_beyond_16_bits(genome):
     """bwa's X0 count is unbounded (mipgen.cpp:586-587); the 64-bit record saturates its copy fields at 65535.  The condense fold compares
     the true counts (a candidate with copy 70,000 beats one with 80,000 at :1709): the device fetches them from the copy table."""

@@ -111,6 +111,21 @@ def test_injected_accelerator_failure_ends_the_run_cleanly(san, call, device, nt
     assert "mip picking complete" not in open(os.path.join(str(tmp_path), "out.progress.txt")).read()
 
 
+@pytest.mark.parametrize("device,nth", [(0, 1), (1, 2)])
+def test_injected_failure_of_the_silent_route_ends_the_run_cleanly(san, device, nth, tmp_path):
+    """A silent design scores, replays and condenses a window in one call (mipgen_accel_score_condense_window, ABI 6): the same convention when that call
+    fails on the first worker's first window or on a middle worker's second."""
+    if san == "address" and not os.environ.get("MIPGEN_SAN_FULL"):
+        pytest.skip("swept under ThreadSanitizer")
+    meta = H.load_design("mixed_12_regions")                            # (the design of the sweep above, run silent)
+    p = _run(san, meta, str(tmp_path), 4, extra=["-gpu_window_candidates", "30000", "-silent_mode", "on"],
+             env_extra={"STUB_ACCEL_FAIL": f"{device}:score_condense_window:{nth}"}, timeout=300)
+    err = p.stderr.decode()
+    assert "ThreadSanitizer" not in err and "AddressSanitizer" not in err and "runtime error" not in err, err[-3000:]
+    assert "injected failure of score_condense_window" in err and p.returncode == 1, (p.returncode, err[-2000:])
+    assert "unable to tile sequences due to circumstance" in err and "mip picking complete" not in err
+
+
 RCCL_SWEEP = [("accel", "window_views", 1, 2), ("accel", "synchronize", 3, 1), ("accel", "format_all_mips", 2, 2), ("rccl", "ncclCommInitAll", 0, 1),
               ("rccl", "ncclGroupEnd", 0, 1), ("rccl", "ncclGroupEnd", 0, 5), ("rccl", "hipMemcpyAsync", 0, 3), ("rccl", "hipEventSynchronize", 0, 2),
               ("rccl", "hipMalloc", 0, 2)]
