@@ -590,6 +590,24 @@ def main() -> None:
         if not only or d["name"] in only:
             gen_design(genome4, d, "genome4_chr4.fa.gz")
 
+    # BASELINE configs[3] in small: the first 1,000 exons of the synthetic exome (chromosome "1" cut behind them), capture 150-170 (five sizes), 57 arm pairs,
+    # -silent_mode on - the selection stage over a thousand neighbouring regions (2,000+ picks, the rand() stream, the used-arm sets from exon to exon), 1.4e8
+    # dense candidates: 25 minutes of the reference per design
+    cl, ex = workloads.exome_layout()
+    ex = [iv for iv in ex if iv.chrom == "1"][:1000]
+    genome5 = workloads.exome_chromosome("1", cl["1"])[:ex[-1].bed_end + 4400]
+    if not only or any(n.startswith("exome1000") for n in only):
+        with gzip.GzipFile(os.path.join(HERE, "genome5_chr1.fa.gz"), "wb", mtime=0) as gz:
+            gz.write(b">chr1\n")
+            for i in range(0, len(genome5), 60):
+                gz.write(genome5[i:i + 60] + b"\n")
+    d5 = dict(name="exome1000_logistic_silent", method="logistic", ivs=[(iv.chrom, iv.bed_start, iv.bed_end, iv.label) for iv in ex], minC=150, maxC=170,
+              sums=[40, 41, 42, 43, 44, 45], flank=0, tags="5,0", snps=True, trf=True, bwa="hashed", model=None, extra=["-silent_mode", "on"], chrom="1")
+    d6 = dict(d5, name="exome1000_mixed_silent", method="mixed", model="svr_syn_64.model", trf=False, bwa="blocks")
+    for d in (d5, d6):
+        if not only or d["name"] in only:
+            gen_design(genome5, d, "genome5_chr1.fa.gz")
+
 
 if __name__ == "__main__":
     main()

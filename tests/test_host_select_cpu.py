@@ -22,7 +22,7 @@ DESIGNS = sorted(d[len("design_"):] for d in os.listdir(H.GOLDEN) if d.startswit
 # (tests/test_gpu_cli.py), the CPU suite keeps all the others
 # (the silent low-complexity SVR design of the hard genome - 7.4e5 candidates under a 200-SV model - runs through the whole command line on the
 # oracle-backed stub in tests/test_host_threads_cpu.py instead)
-HEAVY = {"practice62_config2_svr", "hard_lowcomplexity_svr_silent"}
+HEAVY = {"practice62_config2_svr", "hard_lowcomplexity_svr_silent", "exome1000_logistic_silent", "exome1000_mixed_silent"}   # (the last two: 1.4e8 candidates each - GPU only)
 DESIGNS = [d for d in DESIGNS if d not in HEAVY]
 
 
