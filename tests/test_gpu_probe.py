@@ -3,6 +3,7 @@
 forced result windows and either gather route.  Runs with MIPGEN_PROBE=1 where the directory exists (a fresh clone has none: the committed goldens are
 tests/golden/)."""
 import os
+import shutil
 import zlib
 
 import pytest
@@ -31,3 +32,4 @@ def test_probe_design_matches_the_reference(name, tmp_path):
         H.compare_outputs(meta, str(tmp_path), keys=("picked_mips", "snp_mips"), check_all=False)
     else:
         H.compare_outputs(meta, str(tmp_path))
+    shutil.rmtree(str(tmp_path), ignore_errors=True)          # (a campaign of thousands of designs: FASTQ / SAM / all_mips files of a passed design are not kept)

@@ -2,6 +2,7 @@
 with AddressSanitizer + UBSan): every probe design must reproduce the reference's files - this pins the ORACLE (the checker of the HIP path) and the host
 side on hundreds of random parameter sets without a GPU.  Opt-in like its GPU twin: MIPGEN_PROBE=1 where tests/golden_probe/ exists."""
 import os
+import shutil
 import zlib
 
 import pytest
@@ -24,3 +25,4 @@ def test_probe_design_on_the_oracle_backed_stub(san, name, tmp_path):  # noqa: F
     p = _run(san, meta, str(tmp_path), workers, extra=["-gpu_window_candidates", str(5000 + h % 100000)])
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     _compare(meta, str(tmp_path))
+    shutil.rmtree(str(tmp_path), ignore_errors=True)          # (thousands of designs: the files of a passed one are not kept)
