@@ -4,7 +4,7 @@ their inputs + the reference's output files laid out like the committed goldens 
 box with the snapshot), where tests/test_gpu_probe.py runs the drop-in command line on every one of them - with random device-worker / result-window /
 gather settings - and compares the files byte for byte.  A way to look for differences the fixed goldens do not reach; what it finds becomes a golden.
 
-    python3 tools/diff_probe.py [N = 40] [seed = 1] [long|extreme|hard]   # hard = on the hard genome (ambiguity codes, lower case, '-', homopolymers, microsatellites, GC 20 / 70 %); ~ N x 3 s of reference time; extreme = option values at the edges; long = logistic designs of up to ten regions of 0.3-3 kb
+    python3 tools/diff_probe.py [N = 40] [seed = 1] [long|extreme|hard|silent]   # (combinable: hardsilent; silent = every design with -silent_mode on) hard = on the hard genome (ambiguity codes, lower case, '-', homopolymers, microsatellites, GC 20 / 70 %); ~ N x 3 s of reference time; extreme = option values at the edges; long = logistic designs of up to ten regions of 0.3-3 kb
                                                              # (the selection stage at length), ~ N x 30 s
     gpurun -- 'MIPGEN_PROBE=1 python -m pytest tests/test_gpu_probe.py -q -n 6'
 """
@@ -24,7 +24,7 @@ from mipgen_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden_probe")
 
 
-def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False, extreme: bool = False, hard: bool = False) -> dict:
+def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: bool = False, extreme: bool = False, hard: bool = False, all_silent: bool = False) -> dict:
     method = "logistic" if long_regions else str(rng.choice(["logistic", "logistic", "svr", "mixed"]))
     inc = int(rng.choice([1, 2, 3, 5, 5, 5, 10]))
     lo = int(rng.integers(100, 200))
@@ -120,7 +120,7 @@ def random_design(rng: np.random.Generator, k: int, multi: bool, long_regions: b
         maybe(0.2, "-half_seal_both_strands", "on")
         maybe(0.15, "-logistic_heuristic", "off")
         maybe(0.15, "-check_copy_number", "off")
-    silent = rng.random() < 0.15
+    silent = rng.random() < 0.15 or all_silent
     if silent:
         extra += ["-silent_mode", "on"]
     d = dict(name=f"probe{k:03d}", method=method, minC=lo, maxC=hi, sums=sums, arm_lengths=arm_lengths,
@@ -173,7 +173,7 @@ def main() -> None:
     for k in range(n):
         is_multi = bool(rng.random() < 0.4) and not hard
         d = random_design(rng, seed * 1000 + k, is_multi, long_regions=len(sys.argv) > 3 and "long" in sys.argv[3],
-                          extreme=len(sys.argv) > 3 and "extreme" in sys.argv[3], hard=hard)
+                          extreme=len(sys.argv) > 3 and "extreme" in sys.argv[3], hard=hard, all_silent=len(sys.argv) > 3 and "silent" in sys.argv[3])
         if not (d.get("ivs") or d.get("bed_text", "").strip()):
             continue
         try:
@@ -182,6 +182,7 @@ def main() -> None:
             else:
                 mg.gen_design(multi if is_multi else genome2, d, "genome3" if is_multi else "genome2_chr1.fa.gz", out_root=OUT)
             made += 1
+            shutil.rmtree("/tmp/mipgen_golden_" + d["name"], ignore_errors=True)     # (the reference's FASTQ / SAM / all_mips files: gigabytes per long design)
         except (AssertionError, FileNotFoundError) as ex:  # the reference itself refuses the parameter set or ends without its files (a std::exception: exit
             # status 0, mipgen.cpp:2033-2036) - error behaviour is tools/error_probe.py's subject, not probed here
             print("reference failed on", d["name"], str(ex)[-300:].replace("\n", " | "))
