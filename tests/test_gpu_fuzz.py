@@ -82,6 +82,11 @@ def test_random_configuration(cfg):
             assert int(em[0]) == n_emit and np.array_equal(mask, omask), (cfg[:4], method, "replay")
             osurv = po.condense_region(P, rd, scores, records, omask)
             assert np.array_equal(sv["cand_index"], osurv["cand_index"]) and np.array_equal(sv["record"], osurv["record"]), (cfg[:4], method, "condense")
+            # the one-call window route of a silent front end (ABI 6): the same survivors, scores to the bit
+            acc.score_condense_window(0, method)
+            em2, sv2, _ = acc.download_replay(want_mask=False)
+            assert int(em2[0]) == n_emit and all(np.array_equal(sv2[f], sv[f]) for f in ("cand_index", "record")), (cfg[:4], method, "condense_window")
+            assert np.array_equal(sv2["score"].view(np.uint64), sv["score"].view(np.uint64)), (cfg[:4], method, "condense_window scores")
         else:                                        # large grids: sampled candidates through the per-candidate oracle
             valid = np.nonzero((capi.rec_flags(records) & capi.FLAG_VALID) != 0)[0]
             A = P.n_arm_pairs
